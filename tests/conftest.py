@@ -1,0 +1,44 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+GOLDEN_DIR = os.path.join(REPO, "tests", "golden")
+VG_MEET_GROUPS = [4, 6, 9, 19, 12]
+GQA_MEET_GROUPS = [5, 10, 20, 65]
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def golden_names():
+    return sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith(".npz"))
+
+
+def load_golden(name):
+    """Returns (fixture dict, regenerated state dict, regenerated input batch)."""
+    from veto_amd import synth
+    g = dict(np.load(os.path.join(GOLDEN_DIR, name + ".npz")))
+    layers, heads = int(g["layers"]), int(g["heads"])
+    dataset = str(g["dataset"])
+    n_obj, n_rel = (151, 51) if dataset == "VG" else (201, 101)
+    num_objs = [int(x) for x in g["num_objs"]]
+    if int(g["meet"]):
+        groups = [int(x) for x in g["group_sizes"]]
+        sd = synth.meet_state_dict(0, groups, layers=layers, num_obj_cls=n_obj)
+    else:
+        sd = synth.predictor_state_dict(0, layers=layers, num_obj_cls=n_obj, num_rel_cls=n_rel)
+    batch = synth.synthetic_batch(7, len(num_objs), num_objs, num_obj_cls=n_obj)
+    g["_layers"], g["_heads"], g["_n_obj"], g["_n_rel"] = layers, heads, n_obj, n_rel
+    return g, sd, batch
+
+
+@pytest.fixture(scope="session")
+def repo_root():
+    return REPO

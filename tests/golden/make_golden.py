@@ -1,0 +1,241 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in this directory by running the REAL reference.
+
+Runs only in the build container (needs /root/reference); the GPU box never runs
+it.  Nothing of the reference is copied: the script imports
+`pysgg.modeling.roi_heads.relation_head.roi_relation_predictors` from
+/root/reference with stand-ins for third-party modules that are absent here
+(yacs, ipdb, h5py, cv2, torchvision, apex, ...), loads the
+portable-RNG weights of `veto_amd.synth`, runs VETOPredictor /
+VETOPredictor_MEET in eval mode on CPU fp32 and stores inputs-by-recipe +
+outputs-by-value as .npz.
+
+    python tests/golden/make_golden.py            # writes tests/golden/*.npz
+
+Cases (weights seed 0, data seed 7):
+    predcls_n10_l6h6, predcls_n36_l6h6, predcls_n10_l4h8, predcls_n36_l4h8,
+    sgcls_n10_l6h6, ragged_l4h8 (3 images of 5/1/9 boxes, the 1-box image using
+    the [[0,0]] placeholder pair of sampling.py:50-51), meet_n10_l6h6,
+    meet_sgcls_n10_l6h6, gqa-sized meet head list, train losses for predcls.
+"""
+import os
+import sys
+import types
+from unittest import mock
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, REPO)
+
+from veto_amd import synth  # noqa: E402
+
+
+# ---------------------------------------------------------------------------
+# Import the reference with stand-ins for absent third-party modules.
+# ---------------------------------------------------------------------------
+
+class _CN(dict):
+    """Minimal stand-in for yacs.config.CfgNode (attribute access over a dict)."""
+
+    def __init__(self, init=None, **kw):
+        super().__init__()
+        if init:
+            for k, v in init.items():
+                self[k] = v
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError:
+            raise AttributeError(k)
+
+    def __setattr__(self, k, v):
+        self[k] = v
+
+    def clone(self):
+        import copy
+        return copy.deepcopy(self)
+
+    def freeze(self):
+        pass
+
+    def defrost(self):
+        pass
+
+
+def import_reference():
+    yacs = types.ModuleType("yacs")
+    yacs_config = types.ModuleType("yacs.config")
+    yacs_config.CfgNode = _CN
+    yacs.config = yacs_config
+    sys.modules["yacs"] = yacs
+    sys.modules["yacs.config"] = yacs_config
+    for name in [
+        "ipdb", "h5py", "cv2", "pycocotools", "pycocotools.mask", "pycocotools.coco",
+        "pycocotools.cocoeval", "torchvision", "torchvision.ops", "torchvision.transforms",
+        "torchvision.transforms.functional", "torchvision.models", "torchvision.models.resnet",
+        "torchvision.datasets", "torchvision.datasets.coco", "pysgg._C", "graphviz", "apex",
+        "apex.amp", "gpustat", "tensorboardX", "termcolor", "overrides", "torchvision.ops.boxes",
+        "torchvision.ops.misc", "torchvision.models.detection", "matplotlib", "matplotlib.pyplot",
+        "seaborn", "PIL", "PIL.Image", "PIL.ImageDraw",
+    ]:
+        if name not in sys.modules:
+            try:
+                __import__(name)
+            except Exception:
+                sys.modules[name] = mock.MagicMock(name=name)
+    if not hasattr(torch, "_six"):
+        six = types.ModuleType("torch._six")
+        six.PY37 = True
+        six.PY3 = True
+        six.string_classes = (str,)
+        six.int_classes = (int,)
+        torch._six = six
+        sys.modules["torch._six"] = six
+    sys.path.insert(0, REF)
+    import pysgg.modeling.roi_heads.relation_head.roi_relation_predictors as P
+    from pysgg.config import cfg
+    from pysgg.structures.bounding_box import BoxList
+    return P, cfg, BoxList
+
+
+def configure(P, cfg, mode, layers, heads, predictor="VETOPredictor", dataset="VG"):
+    rh = cfg.MODEL.ROI_RELATION_HEAD
+    rh.PREDICTOR = predictor
+    rh.USE_GT_BOX = True
+    rh.USE_GT_OBJECT_LABEL = (mode == "predcls")
+    rh.VETOTRANSFORMER.ENC_LAYERS = layers
+    rh.VETOTRANSFORMER.NHEADS = heads
+    rh.VETOTRANSFORMER.T_INPUT_DIM = 576
+    cfg.GLOBAL_SETTING.DATASET_CHOICE = dataset
+    cfg.GLOBAL_SETTING.BETA_LOSS = False
+    cfg.ENSEMBLE_LEARNING.EXPERT_GROUP = False
+    cfg.ENSEMBLE_LEARNING.TYPE = "group"
+    n_obj, n_rel = (151, 51) if dataset == "VG" else (201, 101)
+    stats = {"obj_classes": ["c%d" % i for i in range(n_obj)],
+             "rel_classes": ["r%d" % i for i in range(n_rel)]}
+    P.get_dataset_statistics = lambda c: stats
+    P.obj_edge_vectors = lambda names, wv_dir, wv_dim: torch.zeros(len(names), wv_dim)
+    return n_obj, n_rel
+
+
+def make_proposals(BoxList, batch, mode):
+    props, start = [], 0
+    for n in batch["num_objs"]:
+        sl = slice(start, start + n)
+        b = BoxList(torch.from_numpy(batch["boxes"][sl]), batch["image_size"], mode="xyxy")
+        b.add_field("labels", torch.from_numpy(batch["labels"][sl]))
+        if mode != "predcls":
+            b.add_field("predict_logits", torch.from_numpy(batch["predict_logits"][sl]))
+            b.add_field("pred_labels", torch.from_numpy(batch["pred_labels"][sl]))
+        props.append(b)
+        start += n
+    return props
+
+
+def test_pairs(num_objs):
+    """prepare_test_pairs of sampling.py:31-52 (GT-box branch), run verbatim through torch."""
+    out = []
+    for n in num_objs:
+        cand = torch.ones((n, n)) - torch.eye(n)
+        idxs = torch.nonzero(cand).view(-1, 2)
+        out.append(idxs if len(idxs) > 0 else torch.zeros((1, 2), dtype=torch.int64))
+    return out
+
+
+def load_sd(module, sd_np):
+    sd = {k: torch.from_numpy(np.asarray(v)) for k, v in sd_np.items()}
+    missing, unexpected = module.load_state_dict(sd, strict=False)
+    # Only buffers we do not synthesise may be missing.
+    assert not unexpected, unexpected
+    assert all("criterion" in m or "CE_loss" in m for m in missing), missing
+
+
+def run_case(P, cfg, BoxList, name, mode, layers, heads, num_objs, meet=False, dataset="VG",
+             train=False):
+    n_obj, n_rel = configure(P, cfg, mode, layers, heads,
+                             "VETOPredictor_MEET" if meet else "VETOPredictor", dataset)
+    torch.manual_seed(0)
+    if meet:
+        model = P.VETOPredictor_MEET(cfg, 512)
+        groups = list(model.max_group_element_number_list)
+        sd = synth.meet_state_dict(0, groups, layers=layers, num_obj_cls=n_obj)
+    else:
+        model = P.VETOPredictor(cfg, 512)
+        sd = synth.predictor_state_dict(0, layers=layers, num_obj_cls=n_obj, num_rel_cls=n_rel)
+    load_sd(model, sd)
+    model.eval()
+    batch = synth.synthetic_batch(7, len(num_objs), list(num_objs), num_obj_cls=n_obj)
+    props = make_proposals(BoxList, batch, mode)
+    pairs = test_pairs(batch["num_objs"])
+    rgb = torch.from_numpy(batch["roi_features"])
+    dep = torch.from_numpy(batch["roi_depth_features"])
+    out = {"layers": layers, "heads": heads, "num_objs": np.array(batch["num_objs"]),
+           "mode": mode, "dataset": dataset, "meet": int(meet)}
+    with torch.no_grad():
+        res = model(props, pairs, None, None, roi_features=rgb, roi_depth_features=dep)
+    obj_dists, rel_dists = res[0], res[1]
+    out["pair_idx"] = torch.cat(pairs, 0).numpy()
+    out["obj_dists_argmax"] = torch.cat([o.argmax(1) for o in obj_dists]).numpy()
+    if meet:
+        for k, v in rel_dists.items():
+            out["rel_" + k] = v.numpy()
+        out["incre_idx_list"] = np.array(res[3])
+        out["group_sizes"] = np.array(groups)
+    else:
+        out["rel_dists"] = torch.cat(list(rel_dists), 0).numpy()
+        # intermediate probes through the reference's own sub-modules
+        with torch.no_grad():
+            tr = model.fusion_transformer
+            hooks = {}
+            h = tr.transformer.register_forward_hook(lambda m, i, o: hooks.__setitem__("tokens", o))
+            model(props, pairs, None, None, roi_features=rgb, roi_depth_features=dep)
+            h.remove()
+        tok = hooks["tokens"]
+        step = 7 if tok.shape[0] < 200 else 97
+        out["tokens_sample"] = tok[::step, :, ::9].numpy()  # strided sample of [P,19,576]
+        out["tokens_step"] = step
+    if train and not meet:
+        model.train()
+        # dropout off so the loss is deterministic; BN keeps batch statistics (train semantics)
+        for m in model.modules():
+            if isinstance(m, torch.nn.Dropout):
+                m.p = 0.0
+        P_tot = sum(len(p) for p in pairs)
+        rel_labels = torch.from_numpy(synth.integers(7, "rel_labels", (P_tot,), 0, n_rel))
+        splits = [len(p) for p in pairs]
+        res = model(props, pairs, list(rel_labels.split(splits)), None, roi_features=rgb,
+                    roi_depth_features=dep)
+        out["train_rel_loss"] = np.array(res[2]["rel_loss"].item(), dtype=np.float64)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    sz = os.path.getsize(path)
+    key = "rel_dists" if not meet else "rel_group_0"
+    print("%-24s %s %s  |max|=%.3f  %d bytes" % (name, mode, out[key].shape, np.abs(out[key]).max(), sz))
+
+
+def main():
+    torch.set_num_threads(8)
+    P, cfg, BoxList = import_reference()
+    run_case(P, cfg, BoxList, "predcls_n10_l6h6", "predcls", 6, 6, [10], train=True)
+    run_case(P, cfg, BoxList, "predcls_n10_l4h8", "predcls", 4, 8, [10])
+    run_case(P, cfg, BoxList, "predcls_n36_l6h6", "predcls", 6, 6, [36])
+    run_case(P, cfg, BoxList, "predcls_n36_l4h8", "predcls", 4, 8, [36])
+    run_case(P, cfg, BoxList, "sgcls_n10_l6h6", "sgcls", 6, 6, [10])
+    run_case(P, cfg, BoxList, "ragged_l4h8", "predcls", 4, 8, [5, 1, 9])
+    run_case(P, cfg, BoxList, "meet_n10_l6h6", "predcls", 6, 6, [10], meet=True)
+    run_case(P, cfg, BoxList, "meet_sgcls_n10_l6h6", "sgcls", 6, 6, [10], meet=True)
+    run_case(P, cfg, BoxList, "meet_gqa_n6_l4h8", "predcls", 4, 8, [6], meet=True, dataset="GQA")
+    # BETA_LOSS data (roi_relation_predictors.py:4058-4066 reads this pickle): 51 predicate counts
+    import pickle
+    with open(os.path.join(REF, "pred_counts.pkl"), "rb") as f:
+        counts = np.asarray(pickle.load(f), dtype=np.float64)
+    np.savetxt(os.path.join(HERE, "pred_counts.txt"), counts, fmt="%.1f")
+
+
+if __name__ == "__main__":
+    main()
