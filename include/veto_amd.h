@@ -1,0 +1,130 @@
+/*
+ * veto_amd.h -- C ABI of the MI355X-native VETO relation-prediction hot path.
+ *
+ * The reference has NO FFI on this path: VETOPredictor is pure Python/PyTorch
+ * (pysgg/modeling/roi_heads/relation_head/roi_relation_predictors.py:3997-4139 and
+ * model_veto.py:6-146).  The boundary a maintainer binds is therefore the predictor's own
+ * forward, flattened to raw device pointers:
+ *
+ *   veto_create            <- VETOPredictor.__init__            roi_relation_predictors.py:3999-4071
+ *   veto_load_weights      <- nn.Module.load_state_dict keys    SURVEY.md section 8(b) key list
+ *   veto_forward           <- VETOPredictor.forward (eval)      roi_relation_predictors.py:4074-4139
+ *                             Ensemble.forward (MEET, eval)     roi_relation_predictors.py:3752-3853
+ *   veto_enumerate_pairs   <- RelationSampling.prepare_test_pairs   sampling.py:31-52 (GT-box branch)
+ *
+ * Conventions: every pointer marked "device" is a HIP device pointer valid on cfg.device;
+ * `stream` is a hipStream_t passed as void* (NULL = default stream); all work is enqueued on that
+ * stream and nothing synchronises it.  Functions return 0 on success, a negative veto_status
+ * otherwise; veto_last_error() gives a thread-local message.  No exceptions cross the boundary.
+ * A handle is not thread-safe; use one handle per stream/thread.
+ */
+#ifndef VETO_AMD_H_
+#define VETO_AMD_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct veto_handle_s* veto_handle_t;
+
+enum veto_status {
+  VETO_OK = 0,
+  VETO_ERR_INVALID = -1,      /* bad argument / unsupported configuration */
+  VETO_ERR_HIP = -2,          /* a HIP runtime call failed */
+  VETO_ERR_WEIGHTS = -3,      /* forward called before every weight was loaded */
+  VETO_ERR_WORKSPACE = -4     /* workspace too small */
+};
+
+enum veto_precision {
+  VETO_PRECISE = 0,  /* 3-term split-bf16 MFMA, meets the 1e-3 logit tolerance (default) */
+  VETO_FAST = 1      /* single bf16 MFMA pass, ~1e-2 logit error; reported separately */
+};
+
+/* MODEL.ROI_RELATION_HEAD.VETOTRANSFORMER.* (config/defaults.py:331-338) + class counts. */
+typedef struct veto_config {
+  int32_t struct_size;     /* sizeof(veto_config_t), for ABI evolution */
+  int32_t dim;             /* T_INPUT_DIM; must be 576 (model_veto.py:105-113 force it) */
+  int32_t layers;          /* ENC_LAYERS */
+  int32_t heads;           /* NHEADS; must divide 576 with 576/heads % 4 == 0 */
+  int32_t patch;           /* PATCH_SIZE; must be 2 */
+  int32_t channels;        /* ROI channels per modality; must be 256 */
+  int32_t resolution;      /* POOLER_RESOLUTION; must be 8 */
+  int32_t num_obj_cls;     /* 151 (VG) / 201 (GQA); <= 256 */
+  int32_t embed_dim;       /* 200 */
+  int32_t num_out;         /* head width: num_rel_cls (51/101) or sum_k (g_k + 2) for MEET */
+  int32_t precision;       /* enum veto_precision */
+  int32_t device;          /* HIP device ordinal */
+  int32_t max_chunk_pairs; /* pairs processed per pass (bounds the workspace); 0 = default */
+} veto_config_t;
+
+typedef struct veto_inputs {
+  int32_t struct_size;        /* sizeof(veto_inputs_t) */
+  int32_t n_obj;              /* total objects over the batch */
+  int32_t n_pair;             /* total pairs over the batch */
+  int32_t n_img;              /* images in the batch */
+  const float* roi_rgb;       /* device [n_obj, 256, 8, 8]  roi_features        (relation_head.py:140-141) */
+  const float* roi_depth;     /* device [n_obj, 256, 8, 8]  roi_depth_features                              */
+  const float* boxes;         /* device [n_obj, 4]  BoxList.bbox */
+  int32_t box_mode;           /* 0 = xyxy, 1 = xywh (BoxList.mode) */
+  int32_t reserved0;
+  const int64_t* obj_labels;  /* device [n_obj]; predcls GT labels, or MEET sgcls argmax labels; or NULL */
+  const float* obj_logits;    /* device [n_obj, num_obj_cls]; vanilla sgcls soft embedding; or NULL */
+  const int64_t* rel_pairs;   /* device [n_pair, 2] image-local (subj, obj), images concatenated */
+  const int32_t* img_obj_offset;   /* device [n_img + 1] exclusive prefix sum of objects per image */
+  const int32_t* img_pair_offset;  /* device [n_img + 1] exclusive prefix sum of pairs per image */
+} veto_inputs_t;
+
+/* Optional extra outputs (all may be NULL); used by the parity tests. */
+typedef struct veto_debug_outputs {
+  int32_t struct_size;
+  int32_t reserved0;
+  int64_t* subj_inds;   /* device [n_pair] global subject index  (roi_relation_predictors.py:4112) */
+  int64_t* obj_inds;    /* device [n_pair] global object index   (:4113) */
+  float* tokens;        /* device [n_pair, 19, 576] transformer input (model_veto.py:52-64) */
+  float* cls;           /* device [n_pair, 576] final CLS feature (model_veto.py:23) */
+} veto_debug_outputs_t;
+
+const char* veto_last_error(void);
+const char* veto_version(void);
+
+int veto_create(const veto_config_t* cfg, veto_handle_t* out);
+int veto_destroy(veto_handle_t h);
+
+/* Number of weight tensors the handle expects and the i-th expected name/numel. Names are the
+ * reference state-dict keys relative to the predictor, e.g.
+ * "fusion_transformer.transformer.layers.0.0.fn.to_qkv.weight"; for MEET the K heads are passed
+ * row-concatenated as "rel_out.weight"/"rel_out.bias". */
+int veto_num_weights(veto_handle_t h);
+int veto_weight_info(veto_handle_t h, int index, const char** name, size_t* numel);
+/* Copies `numel` fp32 values from `src` (device or host pointer) on `stream`. */
+int veto_load_weights(veto_handle_t h, const char* name, const float* src, size_t numel, void* stream);
+
+size_t veto_workspace_bytes(veto_handle_t h, int32_t n_obj, int32_t n_pair);
+
+/* Eval forward.  out_logits: device [n_pair, num_out] fp32. */
+int veto_forward(veto_handle_t h, void* stream, const veto_inputs_t* in, void* workspace,
+                 size_t workspace_bytes, float* out_logits, const veto_debug_outputs_t* dbg);
+
+/* out: device [max(n*(n-1), 1), 2] int64, row-major (i, j), i != j; [[0,0]] when n <= 1. */
+int veto_enumerate_pairs(void* stream, int32_t n, int64_t* out);
+
+/* ---- measurement hooks (bench.py): per-kernel device time from hipEvents on `stream` ---------- */
+int veto_profile_enable(veto_handle_t h, int32_t on);
+/* Synchronises the recorded events; returns the number of distinct kernels. */
+int veto_profile_collect(veto_handle_t h);
+int veto_profile_entry(veto_handle_t h, int index, const char** name, double* total_ms, int64_t* launches,
+                       double* flops_per_launch, double* bytes_per_launch);
+int veto_profile_reset(veto_handle_t h);
+
+/* ---- test hook: C[M,N] = A[M,K] . W[N,K]^T (+bias) through the production split-bf16 GEMM ------ */
+int veto_debug_gemm(void* stream, const float* a, const float* w, const float* bias, float* c, int32_t m,
+                    int32_t n, int32_t k, int32_t precision, void* workspace, size_t workspace_bytes);
+size_t veto_debug_gemm_workspace_bytes(int32_t m, int32_t n, int32_t k);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VETO_AMD_H_ */

@@ -1,0 +1,61 @@
+"""The slice of the reference's yacs config the VETO predictor reads
+(pysgg/config/defaults.py:296-345,847-864; configs/VETO_final.yaml:57-81,135-154).
+
+`CfgNode` is an attribute-access dict so that either this object or the reference's own frozen
+yacs `cfg` can be handed to the predictor constructors."""
+import copy
+
+
+class CfgNode(dict):
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError:
+            raise AttributeError(k)
+
+    def __setattr__(self, k, v):
+        self[k] = v
+
+    def clone(self):
+        return copy.deepcopy(self)
+
+
+def default_config():
+    c = CfgNode()
+    c.MODEL = CfgNode()
+    c.MODEL.DEVICE = "cuda"
+    rh = c.MODEL.ROI_RELATION_HEAD = CfgNode()
+    rh.PREDICTOR = "VETOPredictor"
+    rh.USE_GT_BOX = True
+    rh.USE_GT_OBJECT_LABEL = True
+    rh.POOLER_RESOLUTION = 8                      # VETO_final.yaml:57
+    rh.MAX_PROPOSAL_PAIR = 2048
+    rh.CONTEXT_HIDDEN_DIM = 512
+    rh.CONTEXT_POOLING_DIM = 4096
+    vt = rh.VETOTRANSFORMER = CfgNode()
+    vt.PATCH_SIZE = 2
+    vt.T_INPUT_DIM = 576
+    vt.ENC_LAYERS = 6
+    vt.NHEADS = 6
+    vt.EMB_DROPOUT = 0.35
+    vt.T_DROPOUT = 0.35
+    c.GLOBAL_SETTING = CfgNode()
+    c.GLOBAL_SETTING.DATASET_CHOICE = "VG"
+    c.GLOBAL_SETTING.USE_BIAS = True
+    c.GLOBAL_SETTING.BETA_LOSS = False
+    c.GCL_SETTING = CfgNode()
+    c.GCL_SETTING.GROUP_SPLIT_MODE = "divide4"
+    c.GCL_SETTING.ZERO_LABEL_PADDING_MODE = "rand_insert"
+    c.ENSEMBLE_LEARNING = CfgNode()
+    c.ENSEMBLE_LEARNING.ENABLED = False
+    c.ENSEMBLE_LEARNING.TYPE = ["group"]
+    c.ENSEMBLE_LEARNING.EXPERT_GROUP = False      # VETO_final.yaml:154
+    c.TEST = CfgNode()
+    c.TEST.RELATION = CfgNode()
+    c.TEST.RELATION.LATER_NMS_PREDICTION_THRES = 0.3
+    c.GLOVE_DIR = ""
+    # veto_amd extensions (absent from the reference config; read with getattr defaults)
+    c.VETO_AMD = CfgNode()
+    c.VETO_AMD.PRECISION = "precise"              # "precise" (3-term split bf16) | "fast" (bf16)
+    c.VETO_AMD.MAX_CHUNK_PAIRS = 0
+    return c

@@ -1,0 +1,35 @@
+// Shared device helpers for the VETO relation-head kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace veto {
+
+constexpr int kDim = 576;        // T_INPUT_DIM; forced by proj_d(512)+proj_v(64), model_veto.py:105-113
+constexpr int kTokens = 19;      // cls + 16 patches + location + class, model_veto.py:56-63
+constexpr int kPatchTokens = 16;
+constexpr int kPosDim = 128;     // pos_embed Linear(4,128), roi_relation_predictors.py:4042-4047
+constexpr int kWave = 64;
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+// x ~= hi + lo with hi = bf16(x), lo = bf16(x - hi): 16 significand bits in two bf16.
+__device__ __forceinline__ void split_bf16(float x, __bf16& hi, __bf16& lo) {
+  hi = (__bf16)x;
+  lo = (__bf16)(x - (float)hi);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+__device__ __forceinline__ float gelu_erf(float x) {
+  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+
+}  // namespace veto

@@ -1,0 +1,180 @@
+// Split-bf16 MFMA GEMM for the token-wise Linear layers of the VETO relation transformer
+// (to_qkv / to_out / FeedForward of model_veto.py:78-96,137-143 and the per-object patch
+// projection derived from model_veto.py:103-113).
+//
+//   C[M,N] = A[M,K] . W[N,K]^T        (nn.Linear layout: both operands K-contiguous)
+//
+// A and W are each held as two bf16 planes (hi, lo) with x ~= hi + lo (16 significand bits).
+// PRECISE (NTERMS=3): A_hi.W_hi + A_lo.W_hi + A_hi.W_lo, fp32 accumulate  -> ~2^-16 relative,
+// which is what the 1e-3 logit bar needs (plain bf16 misses it by 14x).
+// FAST (NTERMS=1): A_hi.W_hi only.
+//
+// Tile 256(M) x 192(N) x 32(K), 8 waves (4 along M x 2 along N), v_mfma_f32_16x16x32_bf16.
+// The MFMA is issued "swapped" (weights as the A operand, activations as the B operand) so that
+// each lane ends up with 4 CONSECUTIVE output columns of one row -> 16-byte epilogue accesses.
+// LDS: two stages of {A_hi, A_lo, W_hi, W_lo} = 2 x 56 KiB, filled by global_load_lds_dwordx4
+// (no VGPR staging).  Each 16-row x 64-byte chunk is one wave-instruction; the XOR swizzle of the
+// 16-byte k-chunks is applied on the per-lane SOURCE address and again on the ds_read_b128 address
+// (the LDS destination of an LDS-DMA is lane-linear), which makes the fragment reads conflict-free.
+#include "common.h"
+#include "kernels.h"
+
+namespace veto {
+
+namespace {
+
+constexpr int BM = 256, BN = 192, BK = 32;
+constexpr int kStageBytes = (2 * BM + 2 * BN) * BK * 2;  // 57344
+constexpr int kAHi = 0, kALo = BM * 64, kWHi = 2 * BM * 64, kWLo = 2 * BM * 64 + BN * 64;
+
+__device__ __forceinline__ void glds16(const char* src, char* lds_dst) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                   (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+
+template <int NTERMS, int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_split_kernel(GemmArgs g) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * kStageBytes];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = w >> 1, wn = w & 1;
+
+  // XCD-aware tile order: blocks b and b+8 share an XCD (round-robin dispatch), so give each XCD a
+  // contiguous run of logical tiles; consecutive logical tiles walk N fastest and therefore re-use
+  // the same 256-row activation panel out of that XCD's L2.  Speed only, never correctness.
+  const int nwg = gridDim.x, orig = blockIdx.x;
+  const int xcd = orig & 7, q8 = nwg >> 3, r8 = nwg & 7;
+  const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
+  const int tile_n = logical % g.tiles_n;
+  const int tile_m = logical / g.tiles_n;
+
+  const int K = g.K;
+  // ---- per-lane source pointers of this wave's 16-row chunks (7 per stage) -------------------
+  const int rr = lane >> 2;                       // row inside the 16-row chunk
+  const int fs = (4 - (rr >> 2)) & 3;             // swizzle key of that row
+  const int qs = (lane & 3) ^ fs;                 // source k-chunk that lands in LDS slot lane&3
+  const char* src[7];
+#pragma unroll
+  for (int i = 0; i < 7; ++i) {
+    const int c = w + 8 * i;                      // chunk id, wave-uniform
+    const __bf16* base;
+    int row;
+    if (c < 16) { base = g.a_hi; row = tile_m * BM + c * 16; }
+    else if (c < 32) { base = g.a_lo; row = tile_m * BM + (c - 16) * 16; }
+    else if (c < 44) { base = g.w_hi; row = tile_n * BN + (c - 32) * 16; }
+    else { base = g.w_lo; row = tile_n * BN + (c - 44) * 16; }
+    src[i] = (const char*)(base + (size_t)(row + rr) * K + qs * 8);
+  }
+
+  auto load_stage = [&](int stage, int kt) {
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+      const int c = w + 8 * i;
+      if (NTERMS == 1 && ((c >= 16 && c < 32) || c >= 44)) continue;  // lo planes unused
+      glds16(src[i] + (size_t)kt * (BK * 2), smem + stage * kStageBytes + c * 1024);
+    }
+  };
+
+  // ---- fragment read offsets ------------------------------------------------------------------
+  const int fr = lane & 15, fq = lane >> 4;
+  const int frag_off = fr * 64 + ((fq ^ ((4 - (fr >> 2)) & 3)) << 4);
+  const int a_off = (wm * 64) * 64 + frag_off;    // activation rows of this wave (4 tiles of 16)
+  const int w_off = (wn * 96) * 64 + frag_off;    // weight rows of this wave (6 tiles of 16)
+
+  f32x4 acc[6][4];
+#pragma unroll
+  for (int n = 0; n < 6; ++n)
+#pragma unroll
+    for (int m = 0; m < 4; ++m) acc[n][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = K / BK;
+  load_stage(0, 0);
+  for (int kt = 0; kt < nk; ++kt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (kt + 1 < nk) load_stage((kt + 1) & 1, kt + 1);
+    const char* st = smem + (kt & 1) * kStageBytes;
+    bf16x8 ah[4], al[4], wh[6], wl[6];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      ah[m] = *(const bf16x8*)(st + kAHi + a_off + m * 1024);
+      if (NTERMS == 3) al[m] = *(const bf16x8*)(st + kALo + a_off + m * 1024);
+    }
+#pragma unroll
+    for (int n = 0; n < 6; ++n) {
+      wh[n] = *(const bf16x8*)(st + kWHi + w_off + n * 1024);
+      if (NTERMS == 3) wl[n] = *(const bf16x8*)(st + kWLo + w_off + n * 1024);
+    }
+#pragma unroll
+    for (int n = 0; n < 6; ++n)
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        if (NTERMS == 3) {
+          acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[n], ah[m], acc[n][m], 0, 0, 0);
+          acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[n], al[m], acc[n][m], 0, 0, 0);
+        }
+        acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[n], ah[m], acc[n][m], 0, 0, 0);
+      }
+  }
+
+  // ---- epilogue: lane holds C[row = m-tile row lane&15][4 consecutive cols (lane>>4)*4..+3] ----
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    const int row = tile_m * BM + wm * 64 + m * 16 + (lane & 15);
+    if (row >= g.M) continue;
+#pragma unroll
+    for (int n = 0; n < 6; ++n) {
+      const int col = tile_n * BN + wn * 96 + n * 16 + (lane >> 4) * 4;
+      f32x4 v = acc[n][m];
+      if (g.bias) {
+        const f32x4 b = *(const f32x4*)(g.bias + col);
+        v += b;
+      }
+      if (EPI == EPI_RESID) {
+        const f32x4 r = *(const f32x4*)(g.resid + (size_t)row * g.ldr + col);
+        v += r;
+      }
+      if (EPI == EPI_GELU_SPLIT) {
+        bf16x4 hi, lo;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          __bf16 h, l;
+          split_bf16(gelu_erf(v[e]), h, l);
+          hi[e] = h;
+          lo[e] = l;
+        }
+        *(bf16x4*)(g.c_hi + (size_t)row * g.ldc + col) = hi;
+        *(bf16x4*)(g.c_lo + (size_t)row * g.ldc + col) = lo;
+      } else {
+        *(f32x4*)(g.c + (size_t)row * g.ldc + col) = v;
+      }
+    }
+  }
+}
+
+template <int NTERMS>
+hipError_t launch_terms(const GemmArgs& g, int epi, hipStream_t s) {
+  dim3 grid(g.tiles_m * g.tiles_n), block(512);
+  switch (epi) {
+    case EPI_F32: hipLaunchKernelGGL((gemm_split_kernel<NTERMS, EPI_F32>), grid, block, 0, s, g); break;
+    case EPI_RESID: hipLaunchKernelGGL((gemm_split_kernel<NTERMS, EPI_RESID>), grid, block, 0, s, g); break;
+    case EPI_GELU_SPLIT: hipLaunchKernelGGL((gemm_split_kernel<NTERMS, EPI_GELU_SPLIT>), grid, block, 0, s, g); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+}  // namespace
+
+int gemm_rows_padded(int m) { return (m + BM - 1) / BM * BM; }
+
+hipError_t launch_gemm_split(GemmArgs g, int epi, int precision, hipStream_t s) {
+  if (g.N % BN != 0 || g.K % BK != 0 || g.M <= 0) return hipErrorInvalidValue;
+  g.tiles_m = (g.M + BM - 1) / BM;
+  g.tiles_n = g.N / BN;
+  return precision == 0 ? launch_terms<3>(g, epi, s) : launch_terms<1>(g, epi, s);
+}
+
+}  // namespace veto

@@ -1,0 +1,92 @@
+// Internal launch interface between the C-ABI host code (veto_abi.hip) and the kernels.
+#pragma once
+#include "common.h"
+
+namespace veto {
+
+enum Epi { EPI_F32 = 0, EPI_RESID = 1, EPI_GELU_SPLIT = 2 };
+
+struct GemmArgs {
+  const __bf16* a_hi;  // [rows padded to 256, K]
+  const __bf16* a_lo;
+  const __bf16* w_hi;  // [N, K]
+  const __bf16* w_lo;
+  const float* bias;   // [N] or nullptr
+  const float* resid;  // EPI_RESID: row r at resid + r*ldr
+  float* c;            // EPI_F32 / EPI_RESID: row r at c + r*ldc
+  __bf16* c_hi;        // EPI_GELU_SPLIT
+  __bf16* c_lo;
+  int M, N, K;
+  long ldr;
+  int ldc;
+  int tiles_m, tiles_n;  // filled by launch_gemm_split
+};
+
+int gemm_rows_padded(int m);
+hipError_t launch_gemm_split(GemmArgs g, int epi, int precision, hipStream_t s);
+
+// ---- weight preparation (once per weight upload) ---------------------------------------------
+hipError_t launch_split_planes(const float* src, __bf16* hi, __bf16* lo, size_t n, hipStream_t s);
+// W_cat [1152, 2048] hi/lo + bias_cat [1152] from proj_d [512,2048], proj_v [64,2048]
+hipError_t launch_build_patch_weight(const float* wd, const float* bd, const float* wv, const float* bv,
+                                     __bf16* hi, __bf16* lo, float* bias_cat, hipStream_t s);
+// dst[k][half*576 + j] = src[j][half*kin + k]   (src is [576, 2*kin])
+hipError_t launch_transpose_pair_proj(const float* src, float* dst, int kin, hipStream_t s);
+// dst[k][c] = src[c][k]  (src [n_out, 576])
+hipError_t launch_transpose_head(const float* src, float* dst, int n_out, hipStream_t s);
+
+// ---- per-object stage --------------------------------------------------------------------------
+struct ObjPrepArgs {
+  const float* boxes;        // [n_obj, 4]
+  int box_mode;              // 0 xyxy, 1 xywh
+  const int64_t* labels;     // predcls / MEET: embedding lookup
+  const float* obj_logits;   // sgcls: softmax(logits) @ E
+  const float* embed;        // [num_obj_cls, embed_dim]
+  int num_obj_cls, embed_dim;
+  const float* bn_w; const float* bn_b; const float* bn_mean; const float* bn_var;  // [4]
+  const float* pos_w; const float* pos_b;   // [128,4], [128]
+  const float* loc_wt; const float* loc_b;  // [128][1152] transposed, [576]
+  const float* cls_wt; const float* cls_b;  // [embed_dim][1152] transposed, [576]
+  float* lc;                 // out [n_obj, 2, 1152]: (location | class) x (subj(+bias) | obj)
+  float* pos_out;            // optional debug [n_obj,128]
+  int n_obj;
+};
+hipError_t launch_obj_prep(const ObjPrepArgs& a, hipStream_t s);
+// rgb/depth [n_obj, 256, 8, 8] -> patch rows [n_obj*16, 2048] hi/lo (depth features first)
+hipError_t launch_patchify(const float* depth, const float* rgb, __bf16* hi, __bf16* lo, int n_obj,
+                           hipStream_t s);
+
+// ---- pair stage --------------------------------------------------------------------------------
+hipError_t launch_pair_indices(const int64_t* rel_pairs, const int32_t* img_obj_off,
+                               const int32_t* img_pair_off, int n_img, int n_pair, int32_t* subj,
+                               int32_t* obj, int64_t* subj64, int64_t* obj64, hipStream_t s);
+hipError_t launch_enumerate_pairs(int n, int64_t* out, hipStream_t s);
+
+struct AssembleArgs {
+  const float* patch_tab;   // [n_obj*16, 1152]
+  const float* lc;          // [n_obj, 2, 1152]
+  const float* cls_token;   // [576]
+  const float* pos_embedding;  // [576]
+  const float* ln_w; const float* ln_b;  // layer-0 attention PreNorm
+  const int32_t* subj; const int32_t* obj;  // this chunk's pairs
+  float* x;                 // [n_pair*19, 576]
+  __bf16* a_hi; __bf16* a_lo;  // LN(x) planes
+  int n_pair;
+};
+hipError_t launch_assemble(const AssembleArgs& a, hipStream_t s);
+
+// LayerNorm(eps 1e-5) of `rows` rows (row r at x + r*ldx) -> hi/lo planes [rows, 576]
+hipError_t launch_layernorm(const float* x, long ldx, const float* w, const float* b, __bf16* hi,
+                            __bf16* lo, int rows, hipStream_t s);
+
+struct AttnArgs {
+  const float* qkv;        // [n_pair*19, 1728]
+  __bf16* o_hi; __bf16* o_lo;  // [rows, 576]; rows = n_pair*19, or n_pair when cls_only
+  int n_pair, heads, cls_only;
+};
+hipError_t launch_attention(const AttnArgs& a, hipStream_t s);
+
+hipError_t launch_head(const float* cls, const float* wt, const float* bias, float* out, int n_pair,
+                       int n_out, hipStream_t s);
+
+}  // namespace veto

@@ -1,0 +1,576 @@
+// Host side of the C ABI (include/veto_amd.h): weight store, workspace carving and the launch
+// sequence of one eval forward of VETOPredictor / the MEET Ensemble trunk
+// (roi_relation_predictors.py:4074-4139, :3752-3853; model_veto.py:15-26).
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/veto_amd.h"
+#include "kernels.h"
+
+using namespace veto;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+  do {                                                                                             \
+    hipError_t e__ = (expr);                                                                       \
+    if (e__ != hipSuccess) return fail(VETO_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e__)); \
+  } while (0)
+
+struct Param {
+  std::string name;
+  size_t numel = 0;
+  size_t offset = 0;  // floats into the raw arena
+  bool loaded = false;
+};
+
+struct SplitW {
+  __bf16* hi = nullptr;
+  __bf16* lo = nullptr;
+};
+
+struct LayerW {
+  const float *ln1_w, *ln1_b, *ln2_w, *ln2_b, *out_b, *fc1_b, *fc2_b;
+  SplitW qkv, out, fc1, fc2;
+};
+
+struct ProfRec {
+  int name_id;
+  hipEvent_t start, stop;
+  double flops, bytes;
+};
+
+size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+}  // namespace
+
+struct veto_handle_s {
+  veto_config_t cfg;
+  int dh = 0;
+  int chunk = 0;
+  std::vector<Param> params;
+  std::map<std::string, int> index;
+  float* raw = nullptr;      // fp32 copies of every state-dict tensor
+  char* derived = nullptr;   // split planes, transposes, folded tables
+  bool dirty = true;
+  std::vector<LayerW> layers;
+  SplitW patch_w;
+  float* patch_bias = nullptr;
+  float* loc_wt = nullptr;
+  float* cls_wt = nullptr;
+  float* head_wt = nullptr;
+  // profiling
+  bool prof_on = false;
+  std::vector<std::string> prof_names;
+  std::vector<ProfRec> prof_recs;
+  std::vector<hipEvent_t> event_pool;
+  struct Agg { double ms = 0; int64_t n = 0; double flops = 0, bytes = 0; };
+  std::vector<Agg> prof_agg;
+
+  const float* p(const std::string& name) const { return raw + params[index.at(name)].offset; }
+  void add(const std::string& name, size_t numel) {
+    Param q;
+    q.name = name;
+    q.numel = numel;
+    index[name] = (int)params.size();
+    params.push_back(q);
+  }
+};
+
+namespace {
+
+const char* kT = "fusion_transformer.transformer.";
+
+std::string lname(int l, const char* rest) {
+  char buf[160];
+  snprintf(buf, sizeof(buf), "%slayers.%d.%s", kT, l, rest);
+  return buf;
+}
+
+int prof_id(veto_handle_t h, const char* name) {
+  for (size_t i = 0; i < h->prof_names.size(); ++i)
+    if (h->prof_names[i] == name) return (int)i;
+  h->prof_names.push_back(name);
+  h->prof_agg.emplace_back();
+  return (int)h->prof_names.size() - 1;
+}
+
+struct ProfScope {
+  veto_handle_t h;
+  hipStream_t s;
+  int rec = -1;
+  ProfScope(veto_handle_t h_, hipStream_t s_, const char* name, double flops, double bytes) : h(h_), s(s_) {
+    if (!h || !h->prof_on) return;
+    ProfRec r;
+    r.name_id = prof_id(h, name);
+    r.flops = flops;
+    r.bytes = bytes;
+    for (hipEvent_t* e : {&r.start, &r.stop}) {
+      if (!h->event_pool.empty()) { *e = h->event_pool.back(); h->event_pool.pop_back(); }
+      else if (hipEventCreate(e) != hipSuccess) return;
+    }
+    hipEventRecord(r.start, s);
+    h->prof_recs.push_back(r);
+    rec = (int)h->prof_recs.size() - 1;
+  }
+  ~ProfScope() {
+    if (rec >= 0) hipEventRecord(h->prof_recs[rec].stop, s);
+  }
+};
+
+int finalize_weights(veto_handle_t h, hipStream_t s) {
+  for (const Param& q : h->params)
+    if (!q.loaded) return fail(VETO_ERR_WEIGHTS, "weight '%s' was never loaded", q.name.c_str());
+  const int L = h->cfg.layers;
+  for (int l = 0; l < L; ++l) {
+    LayerW& w = h->layers[l];
+    HIP_TRY(launch_split_planes(h->p(lname(l, "0.fn.to_qkv.weight")), w.qkv.hi, w.qkv.lo, (size_t)3 * kDim * kDim, s));
+    HIP_TRY(launch_split_planes(h->p(lname(l, "0.fn.to_out.0.weight")), w.out.hi, w.out.lo, (size_t)kDim * kDim, s));
+    HIP_TRY(launch_split_planes(h->p(lname(l, "1.fn.net.0.weight")), w.fc1.hi, w.fc1.lo, (size_t)2 * kDim * kDim, s));
+    HIP_TRY(launch_split_planes(h->p(lname(l, "1.fn.net.3.weight")), w.fc2.hi, w.fc2.lo, (size_t)2 * kDim * kDim, s));
+  }
+  const std::string pe = std::string(kT) + "patch_embed.";
+  HIP_TRY(launch_build_patch_weight(h->p(pe + "proj_d.weight"), h->p(pe + "proj_d.bias"), h->p(pe + "proj_v.weight"),
+                                    h->p(pe + "proj_v.bias"), h->patch_w.hi, h->patch_w.lo, h->patch_bias, s));
+  HIP_TRY(launch_transpose_pair_proj(h->p("location_projection.0.weight"), h->loc_wt, kPosDim, s));
+  HIP_TRY(launch_transpose_pair_proj(h->p("class_projection.0.weight"), h->cls_wt, h->cfg.embed_dim, s));
+  HIP_TRY(launch_transpose_head(h->p("rel_out.weight"), h->head_wt, h->cfg.num_out, s));
+  h->dirty = false;
+  return VETO_OK;
+}
+
+struct Workspace {
+  int32_t *subj, *obj;
+  float* lc;
+  __bf16 *pa_hi, *pa_lo;
+  float* patch_tab;
+  float* x;
+  __bf16 *a_hi, *a_lo;
+  char* big;
+  float* xc;
+  __bf16 *ac_hi, *ac_lo, *hc_hi, *hc_lo;
+  size_t total;
+};
+
+// Carves (or, with base == nullptr, just sizes) the workspace.
+Workspace carve(char* base, int n_obj, int n_pair, int chunk) {
+  Workspace w;
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    char* ptr = base ? base + off : nullptr;
+    off += align_up(bytes, 256);
+    return ptr;
+  };
+  const size_t prow = (size_t)gemm_rows_padded(n_obj * 16);
+  const size_t mpad = (size_t)gemm_rows_padded(chunk * kTokens);
+  const size_t cpad = (size_t)gemm_rows_padded(chunk);
+  w.subj = (int32_t*)take((size_t)n_pair * 4);
+  w.obj = (int32_t*)take((size_t)n_pair * 4);
+  w.lc = (float*)take((size_t)n_obj * 2 * 2 * kDim * 4);
+  w.pa_hi = (__bf16*)take(prow * 2048 * 2);
+  w.pa_lo = (__bf16*)take(prow * 2048 * 2);
+  w.patch_tab = (float*)take((size_t)n_obj * 16 * 2 * kDim * 4);
+  w.x = (float*)take(mpad * kDim * 4);
+  w.a_hi = (__bf16*)take(mpad * kDim * 2);
+  w.a_lo = (__bf16*)take(mpad * kDim * 2);
+  w.big = take(mpad * 3 * kDim * 4);  // qkv fp32 [mpad,1728]; later the MLP hidden hi/lo [mpad,1152] x2
+  w.xc = (float*)take(cpad * kDim * 4);
+  w.ac_hi = (__bf16*)take(cpad * kDim * 2);
+  w.ac_lo = (__bf16*)take(cpad * kDim * 2);
+  w.hc_hi = (__bf16*)take(cpad * 2 * kDim * 2);
+  w.hc_lo = (__bf16*)take(cpad * 2 * kDim * 2);
+  w.total = off;
+  return w;
+}
+
+int run_gemm(veto_handle_t h, hipStream_t s, const char* name, const __bf16* a_hi, const __bf16* a_lo,
+             const SplitW& w, const float* bias, const float* resid, long ldr, float* c, __bf16* c_hi,
+             __bf16* c_lo, int ldc, int M, int N, int K, int epi) {
+  GemmArgs g{};
+  g.a_hi = a_hi; g.a_lo = a_lo; g.w_hi = w.hi; g.w_lo = w.lo;
+  g.bias = bias; g.resid = resid; g.c = c; g.c_hi = c_hi; g.c_lo = c_lo;
+  g.M = M; g.N = N; g.K = K; g.ldr = ldr; g.ldc = ldc;
+  const double flops = 2.0 * M * (double)N * K;
+  const double bytes = 4.0 * ((double)M * K + (double)N * K) + (double)M * N * (epi == EPI_RESID ? 8.0 : 4.0);
+  ProfScope ps(h, s, name, flops, bytes);
+  HIP_TRY(launch_gemm_split(g, epi, h->cfg.precision, s));
+  return VETO_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* veto_last_error(void) { return g_err.c_str(); }
+const char* veto_version(void) { return "veto_amd 0.1 (gfx950)"; }
+
+int veto_create(const veto_config_t* cfg, veto_handle_t* out) {
+  if (!cfg || !out) return fail(VETO_ERR_INVALID, "null argument");
+  if (cfg->struct_size != (int32_t)sizeof(veto_config_t)) return fail(VETO_ERR_INVALID, "veto_config_t size mismatch");
+  if (cfg->dim != kDim) return fail(VETO_ERR_INVALID, "T_INPUT_DIM must be 576 (proj_d 512 + proj_v 64), got %d", cfg->dim);
+  if (cfg->patch != 2 || cfg->channels != 256 || cfg->resolution != 8)
+    return fail(VETO_ERR_INVALID, "only PATCH_SIZE 2, 256 channels, POOLER_RESOLUTION 8 are supported");
+  if (cfg->layers < 1 || cfg->layers > 64) return fail(VETO_ERR_INVALID, "bad ENC_LAYERS %d", cfg->layers);
+  if (cfg->heads < 1 || kDim % cfg->heads != 0 || (kDim / cfg->heads) % 4 != 0)
+    return fail(VETO_ERR_INVALID, "NHEADS %d must divide 576 with head dim %% 4 == 0", cfg->heads);
+  if (cfg->num_obj_cls < 2 || cfg->num_obj_cls > 256 || cfg->embed_dim < 1 || cfg->embed_dim > 256)
+    return fail(VETO_ERR_INVALID, "num_obj_cls/embed_dim out of range");
+  if (cfg->num_out < 1 || cfg->num_out > 4096) return fail(VETO_ERR_INVALID, "bad num_out %d", cfg->num_out);
+  if (cfg->precision != VETO_PRECISE && cfg->precision != VETO_FAST) return fail(VETO_ERR_INVALID, "bad precision");
+  HIP_TRY(hipSetDevice(cfg->device));
+
+  veto_handle_t h = new veto_handle_s();
+  h->cfg = *cfg;
+  h->dh = kDim / cfg->heads;
+  h->chunk = cfg->max_chunk_pairs > 0 ? cfg->max_chunk_pairs : 32768;
+  const int E = cfg->embed_dim, L = cfg->layers;
+  h->add("obj_embed.weight", (size_t)cfg->num_obj_cls * E);
+  h->add("class_projection.0.weight", (size_t)kDim * 2 * E);
+  h->add("class_projection.0.bias", kDim);
+  h->add("pos_embed.0.weight", 4);
+  h->add("pos_embed.0.bias", 4);
+  h->add("pos_embed.0.running_mean", 4);
+  h->add("pos_embed.0.running_var", 4);
+  h->add("pos_embed.1.weight", (size_t)kPosDim * 4);
+  h->add("pos_embed.1.bias", kPosDim);
+  h->add("location_projection.0.weight", (size_t)kDim * 2 * kPosDim);
+  h->add("location_projection.0.bias", kDim);
+  h->add(std::string(kT) + "cls_token", kDim);
+  h->add(std::string(kT) + "pos_embedding", kDim);
+  h->add(std::string(kT) + "patch_embed.proj_d.weight", (size_t)512 * 2048);
+  h->add(std::string(kT) + "patch_embed.proj_d.bias", 512);
+  h->add(std::string(kT) + "patch_embed.proj_v.weight", (size_t)64 * 2048);
+  h->add(std::string(kT) + "patch_embed.proj_v.bias", 64);
+  for (int l = 0; l < L; ++l) {
+    h->add(lname(l, "0.norm.weight"), kDim);
+    h->add(lname(l, "0.norm.bias"), kDim);
+    h->add(lname(l, "0.fn.to_qkv.weight"), (size_t)3 * kDim * kDim);
+    h->add(lname(l, "0.fn.to_out.0.weight"), (size_t)kDim * kDim);
+    h->add(lname(l, "0.fn.to_out.0.bias"), kDim);
+    h->add(lname(l, "1.norm.weight"), kDim);
+    h->add(lname(l, "1.norm.bias"), kDim);
+    h->add(lname(l, "1.fn.net.0.weight"), (size_t)2 * kDim * kDim);
+    h->add(lname(l, "1.fn.net.0.bias"), 2 * kDim);
+    h->add(lname(l, "1.fn.net.3.weight"), (size_t)2 * kDim * kDim);
+    h->add(lname(l, "1.fn.net.3.bias"), kDim);
+  }
+  h->add("rel_out.weight", (size_t)cfg->num_out * kDim);
+  h->add("rel_out.bias", cfg->num_out);
+  size_t off = 0;
+  for (Param& q : h->params) {
+    q.offset = off;
+    off += align_up(q.numel, 64);
+  }
+  hipError_t e = hipMalloc((void**)&h->raw, off * sizeof(float));
+  if (e != hipSuccess) { delete h; return fail(VETO_ERR_HIP, "hipMalloc(raw weights): %s", hipGetErrorString(e)); }
+
+  // derived weights
+  size_t doff = 0;
+  auto dtake = [&](size_t bytes) { size_t o = doff; doff += align_up(bytes, 256); return o; };
+  std::vector<size_t> lo_(L * 8);
+  for (int l = 0; l < L; ++l) {
+    lo_[l * 8 + 0] = dtake((size_t)3 * kDim * kDim * 2); lo_[l * 8 + 1] = dtake((size_t)3 * kDim * kDim * 2);
+    lo_[l * 8 + 2] = dtake((size_t)kDim * kDim * 2);     lo_[l * 8 + 3] = dtake((size_t)kDim * kDim * 2);
+    lo_[l * 8 + 4] = dtake((size_t)2 * kDim * kDim * 2); lo_[l * 8 + 5] = dtake((size_t)2 * kDim * kDim * 2);
+    lo_[l * 8 + 6] = dtake((size_t)2 * kDim * kDim * 2); lo_[l * 8 + 7] = dtake((size_t)2 * kDim * kDim * 2);
+  }
+  const size_t o_pw_hi = dtake((size_t)2 * kDim * 2048 * 2), o_pw_lo = dtake((size_t)2 * kDim * 2048 * 2);
+  const size_t o_pb = dtake((size_t)2 * kDim * 4);
+  const size_t o_loc = dtake((size_t)kPosDim * 2 * kDim * 4);
+  const size_t o_cls = dtake((size_t)E * 2 * kDim * 4);
+  const size_t o_head = dtake((size_t)kDim * cfg->num_out * 4);
+  e = hipMalloc((void**)&h->derived, doff);
+  if (e != hipSuccess) { hipFree(h->raw); delete h; return fail(VETO_ERR_HIP, "hipMalloc(derived weights): %s", hipGetErrorString(e)); }
+  h->layers.resize(L);
+  for (int l = 0; l < L; ++l) {
+    LayerW& w = h->layers[l];
+    char* d = h->derived;
+    w.qkv = {(__bf16*)(d + lo_[l * 8 + 0]), (__bf16*)(d + lo_[l * 8 + 1])};
+    w.out = {(__bf16*)(d + lo_[l * 8 + 2]), (__bf16*)(d + lo_[l * 8 + 3])};
+    w.fc1 = {(__bf16*)(d + lo_[l * 8 + 4]), (__bf16*)(d + lo_[l * 8 + 5])};
+    w.fc2 = {(__bf16*)(d + lo_[l * 8 + 6]), (__bf16*)(d + lo_[l * 8 + 7])};
+    w.ln1_w = h->p(lname(l, "0.norm.weight")); w.ln1_b = h->p(lname(l, "0.norm.bias"));
+    w.ln2_w = h->p(lname(l, "1.norm.weight")); w.ln2_b = h->p(lname(l, "1.norm.bias"));
+    w.out_b = h->p(lname(l, "0.fn.to_out.0.bias"));
+    w.fc1_b = h->p(lname(l, "1.fn.net.0.bias"));
+    w.fc2_b = h->p(lname(l, "1.fn.net.3.bias"));
+  }
+  h->patch_w = {(__bf16*)(h->derived + o_pw_hi), (__bf16*)(h->derived + o_pw_lo)};
+  h->patch_bias = (float*)(h->derived + o_pb);
+  h->loc_wt = (float*)(h->derived + o_loc);
+  h->cls_wt = (float*)(h->derived + o_cls);
+  h->head_wt = (float*)(h->derived + o_head);
+  *out = h;
+  return VETO_OK;
+}
+
+int veto_destroy(veto_handle_t h) {
+  if (!h) return VETO_OK;
+  for (ProfRec& r : h->prof_recs) { hipEventDestroy(r.start); hipEventDestroy(r.stop); }
+  for (hipEvent_t e : h->event_pool) hipEventDestroy(e);
+  hipFree(h->raw);
+  hipFree(h->derived);
+  delete h;
+  return VETO_OK;
+}
+
+int veto_num_weights(veto_handle_t h) { return h ? (int)h->params.size() : fail(VETO_ERR_INVALID, "null handle"); }
+
+int veto_weight_info(veto_handle_t h, int index, const char** name, size_t* numel) {
+  if (!h || index < 0 || index >= (int)h->params.size()) return fail(VETO_ERR_INVALID, "bad weight index");
+  if (name) *name = h->params[index].name.c_str();
+  if (numel) *numel = h->params[index].numel;
+  return VETO_OK;
+}
+
+int veto_load_weights(veto_handle_t h, const char* name, const float* src, size_t numel, void* stream) {
+  if (!h || !name || !src) return fail(VETO_ERR_INVALID, "null argument");
+  auto it = h->index.find(name);
+  if (it == h->index.end()) return fail(VETO_ERR_INVALID, "unknown weight '%s'", name);
+  Param& q = h->params[it->second];
+  if (q.numel != numel) return fail(VETO_ERR_INVALID, "weight '%s': expected %zu elements, got %zu", name, q.numel, numel);
+  HIP_TRY(hipMemcpyAsync(h->raw + q.offset, src, numel * sizeof(float), hipMemcpyDefault, (hipStream_t)stream));
+  q.loaded = true;
+  h->dirty = true;
+  return VETO_OK;
+}
+
+size_t veto_workspace_bytes(veto_handle_t h, int32_t n_obj, int32_t n_pair) {
+  if (!h || n_obj <= 0 || n_pair <= 0) return 0;
+  const int chunk = n_pair < h->chunk ? n_pair : h->chunk;
+  return carve(nullptr, n_obj, n_pair, chunk).total;
+}
+
+int veto_forward(veto_handle_t h, void* stream, const veto_inputs_t* in, void* workspace,
+                 size_t workspace_bytes, float* out_logits, const veto_debug_outputs_t* dbg) {
+  if (!h || !in || !out_logits) return fail(VETO_ERR_INVALID, "null argument");
+  if (in->struct_size != (int32_t)sizeof(veto_inputs_t)) return fail(VETO_ERR_INVALID, "veto_inputs_t size mismatch");
+  if (dbg && dbg->struct_size != (int32_t)sizeof(veto_debug_outputs_t)) return fail(VETO_ERR_INVALID, "veto_debug_outputs_t size mismatch");
+  if (in->n_obj <= 0 || in->n_pair <= 0 || in->n_img <= 0) return fail(VETO_ERR_INVALID, "empty batch (n_obj=%d n_pair=%d n_img=%d)", in->n_obj, in->n_pair, in->n_img);
+  if (!in->roi_rgb || !in->roi_depth || !in->boxes || !in->rel_pairs || !in->img_obj_offset || !in->img_pair_offset)
+    return fail(VETO_ERR_INVALID, "missing input pointer");
+  if (!in->obj_labels && !in->obj_logits) return fail(VETO_ERR_INVALID, "need obj_labels or obj_logits");
+  if ((size_t)in->n_obj * 16 > (size_t)1 << 30 || (size_t)in->n_pair * kTokens > (size_t)1 << 30)
+    return fail(VETO_ERR_INVALID, "batch too large");
+  hipStream_t s = (hipStream_t)stream;
+  HIP_TRY(hipSetDevice(h->cfg.device));
+  if (h->dirty) {
+    int rc = finalize_weights(h, s);
+    if (rc != VETO_OK) return rc;
+  }
+  const int n_obj = in->n_obj, n_pair = in->n_pair;
+  const int chunk = n_pair < h->chunk ? n_pair : h->chunk;
+  const size_t need = carve(nullptr, n_obj, n_pair, chunk).total;
+  if (!workspace || workspace_bytes < need) return fail(VETO_ERR_WORKSPACE, "workspace too small: need %zu bytes, got %zu", need, workspace_bytes);
+  if (((uintptr_t)workspace & 255) != 0) return fail(VETO_ERR_WORKSPACE, "workspace must be 256-byte aligned");
+  Workspace ws = carve((char*)workspace, n_obj, n_pair, chunk);
+  const int L = h->cfg.layers, H = h->cfg.heads, n_out = h->cfg.num_out;
+  const std::string T = kT;
+
+  // ---- stage 0: pair indices + per-object partial products ------------------------------------
+  {
+    ProfScope ps(h, s, "pair_indices", 0, (double)n_pair * 24);
+    HIP_TRY(launch_pair_indices(in->rel_pairs, in->img_obj_offset, in->img_pair_offset, in->n_img, n_pair, ws.subj,
+                                ws.obj, dbg ? dbg->subj_inds : nullptr, dbg ? dbg->obj_inds : nullptr, s));
+  }
+  {
+    ObjPrepArgs a{};
+    a.boxes = in->boxes; a.box_mode = in->box_mode; a.labels = in->obj_labels; a.obj_logits = in->obj_logits;
+    a.embed = h->p("obj_embed.weight"); a.num_obj_cls = h->cfg.num_obj_cls; a.embed_dim = h->cfg.embed_dim;
+    a.bn_w = h->p("pos_embed.0.weight"); a.bn_b = h->p("pos_embed.0.bias");
+    a.bn_mean = h->p("pos_embed.0.running_mean"); a.bn_var = h->p("pos_embed.0.running_var");
+    a.pos_w = h->p("pos_embed.1.weight"); a.pos_b = h->p("pos_embed.1.bias");
+    a.loc_wt = h->loc_wt; a.loc_b = h->p("location_projection.0.bias");
+    a.cls_wt = h->cls_wt; a.cls_b = h->p("class_projection.0.bias");
+    a.lc = ws.lc; a.pos_out = nullptr; a.n_obj = n_obj;
+    ProfScope ps(h, s, "obj_prep", 2.0 * n_obj * 2 * kDim * (kPosDim + h->cfg.embed_dim), (double)n_obj * 2 * 2 * kDim * 4);
+    HIP_TRY(launch_obj_prep(a, s));
+  }
+  {
+    ProfScope ps(h, s, "patchify", 0, (double)n_obj * 2 * 256 * 64 * (4 + 4));
+    HIP_TRY(launch_patchify(in->roi_depth, in->roi_rgb, ws.pa_hi, ws.pa_lo, n_obj, s));
+  }
+  {
+    int rc = run_gemm(h, s, "gemm_patch", ws.pa_hi, ws.pa_lo, h->patch_w, h->patch_bias, nullptr, 0, ws.patch_tab,
+                      nullptr, nullptr, 2 * kDim, n_obj * 16, 2 * kDim, 2048, EPI_F32);
+    if (rc) return rc;
+  }
+
+  // ---- pairs, in chunks that bound the workspace ----------------------------------------------
+  for (int c0 = 0; c0 < n_pair; c0 += chunk) {
+    const int np = (n_pair - c0 < chunk) ? n_pair - c0 : chunk;
+    const int M = np * kTokens;
+    float* qkv = (float*)ws.big;
+    __bf16* h_hi = (__bf16*)ws.big;
+    __bf16* h_lo = h_hi + (size_t)gemm_rows_padded(chunk * kTokens) * 2 * kDim;
+    {
+      AssembleArgs a{};
+      a.patch_tab = ws.patch_tab; a.lc = ws.lc; a.cls_token = h->p(T + "cls_token");
+      a.pos_embedding = h->p(T + "pos_embedding");
+      a.ln_w = h->layers[0].ln1_w; a.ln_b = h->layers[0].ln1_b;
+      a.subj = ws.subj + c0; a.obj = ws.obj + c0; a.x = ws.x; a.a_hi = ws.a_hi; a.a_lo = ws.a_lo; a.n_pair = np;
+      ProfScope ps(h, s, "assemble_tokens", 0, (double)M * kDim * (4 + 4) + (double)np * 18 * 2 * kDim * 4);
+      HIP_TRY(launch_assemble(a, s));
+    }
+    if (dbg && dbg->tokens)
+      HIP_TRY(hipMemcpyAsync(dbg->tokens + (size_t)c0 * kTokens * kDim, ws.x, (size_t)M * kDim * 4, hipMemcpyDeviceToDevice, s));
+    for (int l = 0; l < L; ++l) {
+      const LayerW& w = h->layers[l];
+      const bool last = (l == L - 1);
+      int rc = run_gemm(h, s, "gemm_qkv", ws.a_hi, ws.a_lo, w.qkv, nullptr, nullptr, 0, qkv, nullptr, nullptr, 3 * kDim,
+                        M, 3 * kDim, kDim, EPI_F32);
+      if (rc) return rc;
+      {
+        AttnArgs a{};
+        a.qkv = qkv; a.n_pair = np; a.heads = H; a.cls_only = last ? 1 : 0;
+        a.o_hi = last ? ws.ac_hi : ws.a_hi;
+        a.o_lo = last ? ws.ac_lo : ws.a_lo;
+        const double nq = last ? 1 : kTokens;
+        ProfScope ps(h, s, last ? "attention_cls" : "attention", 4.0 * np * nq * kTokens * kDim,
+                     (double)M * 3 * kDim * 4 + (double)np * nq * kDim * 4);
+        HIP_TRY(launch_attention(a, s));
+      }
+      if (!last) {
+        rc = run_gemm(h, s, "gemm_out", ws.a_hi, ws.a_lo, w.out, w.out_b, ws.x, kDim, ws.x, nullptr, nullptr, kDim, M,
+                      kDim, kDim, EPI_RESID);
+        if (rc) return rc;
+        {
+          ProfScope ps(h, s, "layernorm", 0, (double)M * kDim * 8);
+          HIP_TRY(launch_layernorm(ws.x, kDim, w.ln2_w, w.ln2_b, ws.a_hi, ws.a_lo, M, s));
+        }
+        rc = run_gemm(h, s, "gemm_fc1", ws.a_hi, ws.a_lo, w.fc1, w.fc1_b, nullptr, 0, nullptr, h_hi, h_lo, 2 * kDim, M,
+                      2 * kDim, kDim, EPI_GELU_SPLIT);
+        if (rc) return rc;
+        rc = run_gemm(h, s, "gemm_fc2", h_hi, h_lo, w.fc2, w.fc2_b, ws.x, kDim, ws.x, nullptr, nullptr, kDim, M, kDim,
+                      2 * kDim, EPI_RESID);
+        if (rc) return rc;
+        {
+          const LayerW& nx = h->layers[l + 1];
+          ProfScope ps(h, s, "layernorm", 0, (double)M * kDim * 8);
+          HIP_TRY(launch_layernorm(ws.x, kDim, nx.ln1_w, nx.ln1_b, ws.a_hi, ws.a_lo, M, s));
+        }
+      } else {
+        // Only x[:, 0] of the last layer is consumed (model_veto.py:23): out-proj, FeedForward and
+        // both residuals run on the CLS row of each pair (row p*19 of x -> compact row p).
+        rc = run_gemm(h, s, "gemm_out_cls", ws.ac_hi, ws.ac_lo, w.out, w.out_b, ws.x, (long)kTokens * kDim, ws.xc,
+                      nullptr, nullptr, kDim, np, kDim, kDim, EPI_RESID);
+        if (rc) return rc;
+        {
+          ProfScope ps(h, s, "layernorm_cls", 0, (double)np * kDim * 8);
+          HIP_TRY(launch_layernorm(ws.xc, kDim, w.ln2_w, w.ln2_b, ws.ac_hi, ws.ac_lo, np, s));
+        }
+        rc = run_gemm(h, s, "gemm_fc1_cls", ws.ac_hi, ws.ac_lo, w.fc1, w.fc1_b, nullptr, 0, nullptr, ws.hc_hi, ws.hc_lo,
+                      2 * kDim, np, 2 * kDim, kDim, EPI_GELU_SPLIT);
+        if (rc) return rc;
+        rc = run_gemm(h, s, "gemm_fc2_cls", ws.hc_hi, ws.hc_lo, w.fc2, w.fc2_b, ws.xc, kDim, ws.xc, nullptr, nullptr, kDim,
+                      np, kDim, 2 * kDim, EPI_RESID);
+        if (rc) return rc;
+      }
+    }
+    {
+      ProfScope ps(h, s, "head", 2.0 * np * kDim * n_out, (double)np * (kDim + n_out) * 4);
+      HIP_TRY(launch_head(ws.xc, h->head_wt, h->p("rel_out.bias"), out_logits + (size_t)c0 * n_out, np, n_out, s));
+    }
+    if (dbg && dbg->cls)
+      HIP_TRY(hipMemcpyAsync(dbg->cls + (size_t)c0 * kDim, ws.xc, (size_t)np * kDim * 4, hipMemcpyDeviceToDevice, s));
+  }
+  return VETO_OK;
+}
+
+int veto_enumerate_pairs(void* stream, int32_t n, int64_t* out) {
+  if (n < 0 || !out) return fail(VETO_ERR_INVALID, "bad argument");
+  HIP_TRY(launch_enumerate_pairs(n, out, (hipStream_t)stream));
+  return VETO_OK;
+}
+
+int veto_profile_enable(veto_handle_t h, int32_t on) {
+  if (!h) return fail(VETO_ERR_INVALID, "null handle");
+  h->prof_on = on != 0;
+  return VETO_OK;
+}
+
+int veto_profile_collect(veto_handle_t h) {
+  if (!h) return fail(VETO_ERR_INVALID, "null handle");
+  for (ProfRec& r : h->prof_recs) {
+    HIP_TRY(hipEventSynchronize(r.stop));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, r.start, r.stop));
+    auto& a = h->prof_agg[r.name_id];
+    a.ms += ms;
+    a.n += 1;
+    a.flops = r.flops;
+    a.bytes = r.bytes;
+    h->event_pool.push_back(r.start);
+    h->event_pool.push_back(r.stop);
+  }
+  h->prof_recs.clear();
+  return (int)h->prof_names.size();
+}
+
+int veto_profile_entry(veto_handle_t h, int index, const char** name, double* total_ms, int64_t* launches,
+                       double* flops_per_launch, double* bytes_per_launch) {
+  if (!h || index < 0 || index >= (int)h->prof_names.size()) return fail(VETO_ERR_INVALID, "bad profile index");
+  if (name) *name = h->prof_names[index].c_str();
+  if (total_ms) *total_ms = h->prof_agg[index].ms;
+  if (launches) *launches = h->prof_agg[index].n;
+  if (flops_per_launch) *flops_per_launch = h->prof_agg[index].flops;
+  if (bytes_per_launch) *bytes_per_launch = h->prof_agg[index].bytes;
+  return VETO_OK;
+}
+
+int veto_profile_reset(veto_handle_t h) {
+  if (!h) return fail(VETO_ERR_INVALID, "null handle");
+  for (ProfRec& r : h->prof_recs) { h->event_pool.push_back(r.start); h->event_pool.push_back(r.stop); }
+  h->prof_recs.clear();
+  for (auto& a : h->prof_agg) a = veto_handle_s::Agg();
+  return VETO_OK;
+}
+
+size_t veto_debug_gemm_workspace_bytes(int32_t m, int32_t n, int32_t k) {
+  if (m <= 0 || n <= 0 || k <= 0) return 0;
+  const size_t mp = (size_t)gemm_rows_padded(m);
+  return align_up(mp * k * 2, 256) * 2 + align_up((size_t)n * k * 2, 256) * 2;
+}
+
+int veto_debug_gemm(void* stream, const float* a, const float* w, const float* bias, float* c, int32_t m, int32_t n,
+                    int32_t k, int32_t precision, void* workspace, size_t workspace_bytes) {
+  if (!a || !w || !c || !workspace) return fail(VETO_ERR_INVALID, "null argument");
+  if (workspace_bytes < veto_debug_gemm_workspace_bytes(m, n, k)) return fail(VETO_ERR_WORKSPACE, "workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  const size_t mp = (size_t)gemm_rows_padded(m);
+  char* base = (char*)workspace;
+  __bf16* a_hi = (__bf16*)base;
+  __bf16* a_lo = (__bf16*)(base + align_up(mp * k * 2, 256));
+  __bf16* w_hi = (__bf16*)(base + 2 * align_up(mp * k * 2, 256));
+  __bf16* w_lo = (__bf16*)((char*)w_hi + align_up((size_t)n * k * 2, 256));
+  HIP_TRY(hipMemsetAsync(base, 0, 2 * align_up(mp * k * 2, 256), s));
+  HIP_TRY(launch_split_planes(a, a_hi, a_lo, (size_t)m * k, s));
+  HIP_TRY(launch_split_planes(w, w_hi, w_lo, (size_t)n * k, s));
+  GemmArgs g{};
+  g.a_hi = a_hi; g.a_lo = a_lo; g.w_hi = w_hi; g.w_lo = w_lo; g.bias = bias; g.c = c;
+  g.M = m; g.N = n; g.K = k; g.ldc = n;
+  hipError_t e = launch_gemm_split(g, EPI_F32, precision, s);
+  if (e != hipSuccess) return fail(e == hipErrorInvalidValue ? VETO_ERR_INVALID : VETO_ERR_HIP,
+                                   "gemm launch failed (N must be a multiple of 192, K of 32): %s", hipGetErrorString(e));
+  return VETO_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,152 @@
+"""ctypes binding of the C ABI declared in include/veto_amd.h (libveto_amd.so).
+
+There is no fallback: if the library is missing or a call fails, this raises.
+"""
+import ctypes
+import os
+from ctypes import (POINTER, Structure, byref, c_char_p, c_double, c_float, c_int, c_int32, c_int64,
+                    c_size_t, c_void_p)
+
+_LIB = None
+
+EXPORTS = [
+    "veto_last_error", "veto_version", "veto_create", "veto_destroy", "veto_num_weights",
+    "veto_weight_info", "veto_load_weights", "veto_workspace_bytes", "veto_forward",
+    "veto_enumerate_pairs", "veto_profile_enable", "veto_profile_collect", "veto_profile_entry",
+    "veto_profile_reset", "veto_debug_gemm", "veto_debug_gemm_workspace_bytes",
+]
+
+VETO_PRECISE, VETO_FAST = 0, 1
+
+
+class VetoConfig(Structure):
+    _fields_ = [(n, c_int32) for n in (
+        "struct_size", "dim", "layers", "heads", "patch", "channels", "resolution", "num_obj_cls",
+        "embed_dim", "num_out", "precision", "device", "max_chunk_pairs")]
+
+
+class VetoInputs(Structure):
+    _fields_ = [
+        ("struct_size", c_int32), ("n_obj", c_int32), ("n_pair", c_int32), ("n_img", c_int32),
+        ("roi_rgb", c_void_p), ("roi_depth", c_void_p), ("boxes", c_void_p),
+        ("box_mode", c_int32), ("reserved0", c_int32),
+        ("obj_labels", c_void_p), ("obj_logits", c_void_p), ("rel_pairs", c_void_p),
+        ("img_obj_offset", c_void_p), ("img_pair_offset", c_void_p),
+    ]
+
+
+class VetoDebugOutputs(Structure):
+    _fields_ = [
+        ("struct_size", c_int32), ("reserved0", c_int32),
+        ("subj_inds", c_void_p), ("obj_inds", c_void_p), ("tokens", c_void_p), ("cls", c_void_p),
+    ]
+
+
+class VetoError(RuntimeError):
+    pass
+
+
+def library_path():
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libveto_amd.so")
+
+
+def load_library():
+    """Loads libveto_amd.so (building it with hipcc first if it is absent). Raises if impossible."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = library_path()
+    if not os.path.exists(path):
+        from .build import build_native
+        build_native()
+    lib = ctypes.CDLL(path)
+    lib.veto_last_error.restype = c_char_p
+    lib.veto_version.restype = c_char_p
+    lib.veto_create.argtypes = [POINTER(VetoConfig), POINTER(c_void_p)]
+    lib.veto_destroy.argtypes = [c_void_p]
+    lib.veto_num_weights.argtypes = [c_void_p]
+    lib.veto_weight_info.argtypes = [c_void_p, c_int, POINTER(c_char_p), POINTER(c_size_t)]
+    lib.veto_load_weights.argtypes = [c_void_p, c_char_p, c_void_p, c_size_t, c_void_p]
+    lib.veto_workspace_bytes.argtypes = [c_void_p, c_int32, c_int32]
+    lib.veto_workspace_bytes.restype = c_size_t
+    lib.veto_forward.argtypes = [c_void_p, c_void_p, POINTER(VetoInputs), c_void_p, c_size_t, c_void_p,
+                                 POINTER(VetoDebugOutputs)]
+    lib.veto_enumerate_pairs.argtypes = [c_void_p, c_int32, c_void_p]
+    lib.veto_profile_enable.argtypes = [c_void_p, c_int32]
+    lib.veto_profile_collect.argtypes = [c_void_p]
+    lib.veto_profile_entry.argtypes = [c_void_p, c_int, POINTER(c_char_p), POINTER(c_double), POINTER(c_int64),
+                                       POINTER(c_double), POINTER(c_double)]
+    lib.veto_profile_reset.argtypes = [c_void_p]
+    lib.veto_debug_gemm.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32,
+                                    c_int32, c_void_p, c_size_t]
+    lib.veto_debug_gemm_workspace_bytes.argtypes = [c_int32, c_int32, c_int32]
+    lib.veto_debug_gemm_workspace_bytes.restype = c_size_t
+    _LIB = lib
+    return lib
+
+
+def check(rc):
+    if rc < 0:
+        raise VetoError("veto_amd native call failed (%d): %s" % (rc, load_library().veto_last_error().decode()))
+    return rc
+
+
+class Engine:
+    """Owns one veto_handle_t. Thin: every method maps 1:1 onto a C-ABI call."""
+
+    def __init__(self, layers, heads, num_obj_cls, num_out, precision=VETO_PRECISE, device=0, dim=576,
+                 embed_dim=200, max_chunk_pairs=0):
+        self.lib = load_library()
+        cfg = VetoConfig(ctypes.sizeof(VetoConfig), dim, layers, heads, 2, 256, 8, num_obj_cls, embed_dim,
+                         num_out, precision, device, max_chunk_pairs)
+        self.cfg = cfg
+        h = c_void_p()
+        check(self.lib.veto_create(byref(cfg), byref(h)))
+        self.handle = h
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.veto_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def weight_specs(self):
+        out = []
+        for i in range(check(self.lib.veto_num_weights(self.handle))):
+            name, numel = c_char_p(), c_size_t()
+            check(self.lib.veto_weight_info(self.handle, i, byref(name), byref(numel)))
+            out.append((name.value.decode(), numel.value))
+        return out
+
+    def load_weight(self, name, ptr, numel, stream=0):
+        check(self.lib.veto_load_weights(self.handle, name.encode(), c_void_p(ptr), numel, c_void_p(stream)))
+
+    def workspace_bytes(self, n_obj, n_pair):
+        return self.lib.veto_workspace_bytes(self.handle, n_obj, n_pair)
+
+    def forward(self, stream, inputs, workspace_ptr, workspace_bytes, out_ptr, dbg=None):
+        check(self.lib.veto_forward(self.handle, c_void_p(stream), byref(inputs), c_void_p(workspace_ptr),
+                                    workspace_bytes, c_void_p(out_ptr), byref(dbg) if dbg is not None else None))
+
+    def profile_enable(self, on):
+        check(self.lib.veto_profile_enable(self.handle, 1 if on else 0))
+
+    def profile_reset(self):
+        check(self.lib.veto_profile_reset(self.handle))
+
+    def profile(self):
+        """Returns {kernel: dict(total_ms, launches, flops_per_launch, bytes_per_launch)}."""
+        n = check(self.lib.veto_profile_collect(self.handle))
+        out = {}
+        for i in range(n):
+            name, ms, cnt, fl, by = c_char_p(), c_double(), c_int64(), c_double(), c_double()
+            check(self.lib.veto_profile_entry(self.handle, i, byref(name), byref(ms), byref(cnt), byref(fl), byref(by)))
+            if cnt.value:
+                out[name.value.decode()] = dict(total_ms=ms.value, launches=cnt.value,
+                                                flops_per_launch=fl.value, bytes_per_launch=by.value)
+        return out

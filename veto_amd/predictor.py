@@ -1,0 +1,411 @@
+"""MI355X-native `VETOPredictor` / `VETOPredictor_MEET` behind the reference's plugin API.
+
+Mirrors pysgg/modeling/roi_heads/relation_head/roi_relation_predictors.py:3876-4139:
+  * registered under the same names in a registry of the same protocol (veto_amd.registry),
+  * same constructor `Predictor(config, in_channels)` and the same `forward` signature,
+  * same 6-tuple return (SURVEY.md section 8b "Return"),
+  * same state-dict key names, so reference checkpoints load unchanged.
+
+The modules below are PARAMETER CONTAINERS: the arithmetic of the eval forward runs in
+libveto_amd.so (hand-written HIP, include/veto_amd.h) on the tensors' own device and stream.
+There is no PyTorch or CPU fallback; if the library is missing, or the inputs are not on a HIP
+device, forward raises.
+"""
+import ctypes
+import math
+import warnings
+
+import torch
+from torch import nn
+
+from . import meet_tables, native
+from .registry import ROI_RELATION_PREDICTOR
+
+_STATISTICS_PROVIDER = None
+_EMBEDDING_PROVIDER = None
+
+
+def set_statistics_provider(fn):
+    """fn(config) -> {'obj_classes': [...], 'rel_classes': [...]} (replaces the reference's
+    pysgg.data.get_dataset_statistics, data/build.py:27-77, when pysgg is not importable)."""
+    global _STATISTICS_PROVIDER
+    _STATISTICS_PROVIDER = fn
+
+
+def set_embedding_provider(fn):
+    """fn(obj_classes, wv_dir, wv_dim) -> FloatTensor [len(obj_classes), wv_dim] (replaces
+    utils_motifs.obj_edge_vectors, utils_motifs.py:151-171)."""
+    global _EMBEDDING_PROVIDER
+    _EMBEDDING_PROVIDER = fn
+
+
+def _dataset_statistics(config):
+    if _STATISTICS_PROVIDER is not None:
+        return _STATISTICS_PROVIDER(config)
+    try:
+        from pysgg.data import get_dataset_statistics  # type: ignore
+        return get_dataset_statistics(config)
+    except ImportError:
+        n_obj, n_rel = meet_tables.NUM_CLASSES[config.GLOBAL_SETTING.DATASET_CHOICE]
+        return {"obj_classes": ["obj_%d" % i for i in range(n_obj)],
+                "rel_classes": ["rel_%d" % i for i in range(n_rel)]}
+
+
+def _embedding_vectors(obj_classes, wv_dir, wv_dim):
+    if _EMBEDDING_PROVIDER is not None:
+        return _EMBEDDING_PROVIDER(obj_classes, wv_dir, wv_dim)
+    try:
+        from pysgg.modeling.roi_heads.relation_head.utils_motifs import obj_edge_vectors  # type: ignore
+        return obj_edge_vectors(obj_classes, wv_dir=wv_dir, wv_dim=wv_dim)
+    except ImportError:
+        warnings.warn("veto_amd: GloVe loader unavailable; obj_embed initialised N(0,1) "
+                      "(load a checkpoint or call set_embedding_provider)")
+        return torch.randn(len(obj_classes), wv_dim)
+
+
+def _mode(config):
+    rh = config.MODEL.ROI_RELATION_HEAD
+    if rh.USE_GT_BOX:
+        return "predcls" if rh.USE_GT_OBJECT_LABEL else "sgcls"
+    return "sgdet"
+
+
+def _precision(config):
+    ext = getattr(config, "VETO_AMD", None)
+    name = getattr(ext, "PRECISION", "precise") if ext is not None else "precise"
+    if name not in ("precise", "fast"):
+        raise ValueError("VETO_AMD.PRECISION must be 'precise' or 'fast', got %r" % (name,))
+    return native.VETO_PRECISE if name == "precise" else native.VETO_FAST
+
+
+def _max_chunk(config):
+    ext = getattr(config, "VETO_AMD", None)
+    return int(getattr(ext, "MAX_CHUNK_PAIRS", 0)) if ext is not None else 0
+
+
+# ---------------------------------------------------------------------------------------------------
+# Parameter containers with the reference's attribute names (=> identical state-dict keys).
+# ---------------------------------------------------------------------------------------------------
+
+class _Holder(nn.Module):
+    """A module that only owns sub-modules/parameters; the compute lives in the HIP library."""
+
+    def forward(self, *a, **k):  # pragma: no cover
+        raise RuntimeError("parameter container: the forward pass runs in libveto_amd.so")
+
+
+def _attention_params(dim, dropout):
+    m = _Holder()
+    m.to_qkv = nn.Linear(dim, 3 * dim, bias=False)
+    m.to_out = nn.Sequential(nn.Linear(dim, dim), nn.Dropout(dropout))
+    return m
+
+
+def _feedforward_params(dim, hidden):
+    m = _Holder()
+    m.net = nn.Sequential(nn.Linear(dim, hidden), nn.GELU(), nn.Dropout(0.0), nn.Linear(hidden, dim),
+                          nn.Dropout(0.0))
+    return m
+
+
+def _prenorm(dim, fn):
+    m = _Holder()
+    m.norm = nn.LayerNorm(dim)
+    m.fn = fn
+    return m
+
+
+def _transformer_params(config, in_channels):
+    vt = config.MODEL.ROI_RELATION_HEAD.VETOTRANSFORMER
+    dim, patch = vt.T_INPUT_DIM, vt.PATCH_SIZE
+    if dim != 576:
+        # same constraint as the reference: proj_d (512) + proj_v (64) are hard-wired, so any other
+        # T_INPUT_DIM fails at the token concat (model_veto.py:105-113)
+        raise ValueError("VETOTRANSFORMER.T_INPUT_DIM must be 576, got %d" % dim)
+    inner = _Holder()
+    inner.patch_embed = _Holder()
+    pdim = in_channels * 2 * patch * patch
+    inner.patch_embed.proj_d = nn.Linear(pdim, 512)
+    inner.patch_embed.proj_v = nn.Linear(pdim, 64)
+    inner.cls_token = nn.Parameter(torch.randn(1, 1, dim))
+    inner.pos_embedding = nn.Parameter(torch.randn(1, 1, dim))
+    inner.pos_drop = nn.Dropout(vt.EMB_DROPOUT)
+    inner.layers = nn.ModuleList(
+        nn.ModuleList([_prenorm(dim, _attention_params(dim, vt.T_DROPOUT)),
+                       _prenorm(dim, _feedforward_params(dim, 2 * dim))])
+        for _ in range(vt.ENC_LAYERS))
+    outer = _Holder()
+    outer.transformer = inner
+    outer.to_cls_token = nn.Identity()
+    return outer
+
+
+def _xavier_linear(in_f, out_f):
+    lin = nn.Linear(in_f, out_f, bias=True)
+    nn.init.xavier_normal_(lin.weight)
+    return lin
+
+
+def _build_trunk(m, config, num_obj_cls, with_embed2):
+    """Adds the modules shared by VETOPredictor (:4014-4053) and Ensemble (:3668-3704) to `m`."""
+    dim = config.MODEL.ROI_RELATION_HEAD.VETOTRANSFORMER.T_INPUT_DIM
+    embed_dim = 200
+    if with_embed2:
+        m.obj_embed2 = nn.Embedding(num_obj_cls, embed_dim)
+    m.obj_embed = nn.Embedding(num_obj_cls, embed_dim)
+    m.class_projection = nn.Sequential(nn.Linear(2 * embed_dim, dim), nn.ReLU(inplace=True))
+    m.bbox_embed = nn.Sequential(nn.Linear(9, 32), nn.ReLU(inplace=True), nn.Dropout(0.1),
+                                 nn.Linear(32, 128), nn.ReLU(inplace=True), nn.Dropout(0.1))
+    m.pos_embed = nn.Sequential(nn.BatchNorm1d(4, momentum=0.001), nn.Linear(4, 128), nn.ReLU(inplace=True),
+                                nn.Dropout(0.1))
+    m.location_projection = nn.Sequential(nn.Linear(256, dim), nn.ReLU(inplace=True))
+    m.fusion_transformer = _transformer_params(config, in_channels=256)
+
+
+_TRUNK_KEYS = None
+
+
+class _NativeForward:
+    """Shared device-side plumbing: engine lifetime, weight upload, workspace, one C-ABI forward."""
+
+    def _native_init(self, config, trunk, num_obj_cls, head_modules):
+        vt = config.MODEL.ROI_RELATION_HEAD.VETOTRANSFORMER
+        self._layers, self._heads = int(vt.ENC_LAYERS), int(vt.NHEADS)
+        self._num_obj_cls = num_obj_cls
+        self._head_modules = head_modules
+        self._num_out = sum(h.out_features for h in head_modules)
+        self._precision = _precision(config)
+        self._max_chunk = _max_chunk(config)
+        object.__setattr__(self, "_trunk", trunk)  # not a sub-module registration
+        self._engine = None
+        self._engine_device = None
+        self._uploaded = None
+        self._workspace = None
+
+    def _weight_tensors(self):
+        t = self._trunk
+        sd = {k: v for k, v in t.state_dict().items()}
+        out = {k: sd[k] for k in sd if k.startswith(("obj_embed.", "class_projection.0.", "pos_embed.",
+                                                     "location_projection.0.", "fusion_transformer."))}
+        out.pop("pos_embed.0.num_batches_tracked", None)
+        heads = self._head_modules
+        out["rel_out.weight"] = torch.cat([h.weight for h in heads], 0) if len(heads) > 1 else heads[0].weight
+        out["rel_out.bias"] = torch.cat([h.bias for h in heads], 0) if len(heads) > 1 else heads[0].bias
+        return out
+
+    def _version(self):
+        return tuple((p.data_ptr(), p._version) for p in list(self._trunk.parameters()) + list(self._trunk.buffers()))
+
+    def _ensure_engine(self, device):
+        if device.type != "cuda":
+            raise RuntimeError("veto_amd: the predictor runs only on a HIP device (got %s); there is no CPU path" % device)
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        if self._engine is None or self._engine_device != idx:
+            if self._engine is not None:
+                self._engine.close()
+            self._engine = native.Engine(self._layers, self._heads, self._num_obj_cls, self._num_out,
+                                         precision=self._precision, device=idx, max_chunk_pairs=self._max_chunk)
+            self._engine_device = idx
+            self._uploaded = None
+        ver = self._version()
+        if self._uploaded != ver:
+            tensors = self._weight_tensors()
+            stream = torch.cuda.current_stream(device).cuda_stream
+            keep = []
+            for name, numel in self._engine.weight_specs():
+                t = tensors[name].detach().to(device=device, dtype=torch.float32).contiguous()
+                if t.numel() != numel:
+                    raise RuntimeError("veto_amd: weight %s has %d elements, expected %d" % (name, t.numel(), numel))
+                keep.append(t)
+                self._engine.load_weight(name, t.data_ptr(), numel, stream)
+            torch.cuda.current_stream(device).synchronize()  # `keep` may be freed after this
+            self._uploaded = ver
+        return self._engine
+
+    def _run_native(self, proposals, rel_pair_idxs, roi_features, roi_depth_features, labels, logits,
+                    debug=False):
+        device = roi_features.device
+        eng = self._ensure_engine(device)
+        n_objs = [len(p) for p in proposals]
+        n_pairs = [int(p.shape[0]) for p in rel_pair_idxs]
+        n_obj, n_pair = sum(n_objs), sum(n_pairs)
+        if tuple(roi_features.shape[1:]) != (256, 8, 8) or tuple(roi_depth_features.shape[1:]) != (256, 8, 8):
+            raise ValueError("roi features must be [N, 256, 8, 8], got %s / %s"
+                             % (tuple(roi_features.shape), tuple(roi_depth_features.shape)))
+        if roi_features.shape[0] != n_obj or roi_depth_features.shape[0] != n_obj:
+            raise ValueError("roi feature rows (%d) != total proposals (%d)" % (roi_features.shape[0], n_obj))
+        f32 = dict(device=device, dtype=torch.float32)
+        rgb = roi_features.detach().to(**f32).contiguous()
+        dep = roi_depth_features.detach().to(**f32).contiguous()
+        boxes = torch.cat([p.bbox for p in proposals], 0).to(**f32).contiguous()
+        mode = proposals[0].mode
+        pairs = torch.cat([p.reshape(-1, 2) for p in rel_pair_idxs], 0).to(device=device, dtype=torch.int64).contiguous()
+        obj_off = torch.tensor([0] + list(_cumsum(n_objs)), dtype=torch.int32, device=device)
+        pair_off = torch.tensor([0] + list(_cumsum(n_pairs)), dtype=torch.int32, device=device)
+        lab = labels.to(device=device, dtype=torch.int64).contiguous() if labels is not None else None
+        lg = logits.detach().to(**f32).contiguous() if logits is not None else None
+
+        need = eng.workspace_bytes(n_obj, n_pair)
+        if self._workspace is None or self._workspace.numel() < need or self._workspace.device != device:
+            self._workspace = None
+            self._workspace = torch.empty(need, dtype=torch.uint8, device=device)
+        out = torch.empty((n_pair, self._num_out), **f32)
+        inp = native.VetoInputs()
+        inp.struct_size = ctypes.sizeof(native.VetoInputs)
+        inp.n_obj, inp.n_pair, inp.n_img = n_obj, n_pair, len(proposals)
+        inp.roi_rgb, inp.roi_depth, inp.boxes = rgb.data_ptr(), dep.data_ptr(), boxes.data_ptr()
+        inp.box_mode = 0 if mode == "xyxy" else 1
+        inp.obj_labels = lab.data_ptr() if lab is not None else None
+        inp.obj_logits = lg.data_ptr() if lg is not None else None
+        inp.rel_pairs = pairs.data_ptr()
+        inp.img_obj_offset, inp.img_pair_offset = obj_off.data_ptr(), pair_off.data_ptr()
+        dbg, extras = None, None
+        if debug:
+            extras = {"subj_inds": torch.empty(n_pair, dtype=torch.int64, device=device),
+                      "obj_inds": torch.empty(n_pair, dtype=torch.int64, device=device),
+                      "tokens": torch.empty((n_pair, 19, 576), **f32),
+                      "cls": torch.empty((n_pair, 576), **f32)}
+            dbg = native.VetoDebugOutputs()
+            dbg.struct_size = ctypes.sizeof(native.VetoDebugOutputs)
+            dbg.subj_inds, dbg.obj_inds = extras["subj_inds"].data_ptr(), extras["obj_inds"].data_ptr()
+            dbg.tokens, dbg.cls = extras["tokens"].data_ptr(), extras["cls"].data_ptr()
+        stream = torch.cuda.current_stream(device).cuda_stream
+        eng.forward(stream, inp, self._workspace.data_ptr(), self._workspace.numel(), out.data_ptr(), dbg)
+        # the inputs above are referenced by enqueued kernels: keep them alive on this stream
+        for t in (rgb, dep, boxes, pairs, obj_off, pair_off, lab, lg):
+            if t is not None:
+                t.record_stream(torch.cuda.current_stream(device))
+        self.last_debug = extras
+        return out, n_objs, n_pairs
+
+
+def _cumsum(xs):
+    s = 0
+    for x in xs:
+        s += x
+        yield s
+
+
+def _cat_field(proposals, name):
+    return torch.cat([p.get_field(name) for p in proposals], 0)
+
+
+_TRAIN_MSG = ("veto_amd: training forward/backward of the fused HIP path is not built yet "
+              "(SURVEY.md section 8(f) row f3); call .eval() for inference")
+
+
+@ROI_RELATION_PREDICTOR.register("VETOPredictor")
+class VETOPredictor(nn.Module, _NativeForward):
+    def __init__(self, config, in_channels):
+        super().__init__()
+        self.mode = _mode(config)
+        statistics = _dataset_statistics(config)
+        self.obj_classes, self.rel_classes = statistics["obj_classes"], statistics["rel_classes"]
+        self.num_obj_cls, self.num_rel_cls = len(self.obj_classes), len(self.rel_classes)
+        self.embed_dim = 200
+        _build_trunk(self, config, self.num_obj_cls, with_embed2=True)
+        vecs = _embedding_vectors(self.obj_classes, getattr(config, "GLOVE_DIR", ""), self.embed_dim)
+        with torch.no_grad():
+            self.obj_embed.weight.copy_(vecs)
+        dim = config.MODEL.ROI_RELATION_HEAD.VETOTRANSFORMER.T_INPUT_DIM
+        self.rel_out = _xavier_linear(dim, self.num_rel_cls)
+        self.beta_loss = bool(config.GLOBAL_SETTING.BETA_LOSS)
+        weights = torch.ones(self.num_rel_cls)
+        if self.beta_loss:
+            weights = class_balanced_weights(getattr(config.GLOBAL_SETTING, "REL_COUNTS", None), self.num_rel_cls)
+        self.criterion_loss_rel = nn.CrossEntropyLoss(weight=weights)
+        self.criterion_loss = nn.CrossEntropyLoss()
+        self._native_init(config, self, self.num_obj_cls, [self.rel_out])
+
+    def forward(self, proposals, rel_pair_idxs, rel_labels, logger, roi_features=None,
+                roi_depth_features=None, rel_binarys=None):
+        if self.training:
+            raise NotImplementedError(_TRAIN_MSG)
+        if self.mode == "predcls":
+            labels = _cat_field(proposals, "labels").long()
+            logits = None
+            obj_label_for_dist = labels
+        else:
+            logits = _cat_field(proposals, "predict_logits").detach()
+            obj_label_for_dist = _cat_field(proposals, "pred_labels").detach().long()
+            labels = None
+        rel, n_objs, n_pairs = self._run_native(proposals, rel_pair_idxs, roi_features, roi_depth_features,
+                                                labels, logits, debug=getattr(self, "debug_outputs", False))
+        obj_dists = nn.functional.one_hot(obj_label_for_dist.to(rel.device), self.num_obj_cls).float()
+        return obj_dists.split(n_objs, dim=0), rel.split(n_pairs, dim=0), {}, None, None, None
+
+
+def class_balanced_weights(counts, num_cls, beta=0.999):
+    """BETA_LOSS class weights (roi_relation_predictors.py:4058-4066). The reference reads a
+    hard-coded absolute pickle path; here the 51 counts come from GLOBAL_SETTING.REL_COUNTS."""
+    if counts is None:
+        raise ValueError("GLOBAL_SETTING.BETA_LOSS needs GLOBAL_SETTING.REL_COUNTS (the predicate counts of "
+                         "the reference's pred_counts.pkl)")
+    c = torch.as_tensor(counts, dtype=torch.float64)
+    if c.numel() != num_cls:
+        raise ValueError("REL_COUNTS must have %d entries" % num_cls)
+    c = torch.sort(c, descending=True)[0]
+    w = (1.0 - beta) / (1.0 - beta ** c)
+    return (w * (num_cls / w.sum())).float()
+
+
+class _EnsembleParams(_Holder):
+    """Parameter tree of the reference's `Ensemble` (roi_relation_predictors.py:3661-3744)."""
+
+    def __init__(self, config, num_obj_cls, sizes, obj_classes):
+        super().__init__()
+        _build_trunk(self, config, num_obj_cls, with_embed2=False)
+        vecs = _embedding_vectors(obj_classes, getattr(config, "GLOVE_DIR", ""), 200)
+        with torch.no_grad():
+            self.obj_embed.weight.copy_(vecs)
+        dim = config.MODEL.ROI_RELATION_HEAD.VETOTRANSFORMER.T_INPUT_DIM
+        self.rel_out = nn.ModuleList(_xavier_linear(dim, g + 2) for g in sizes)
+        self.rel_out_group = nn.ModuleList([])
+        self.CE_loss = nn.CrossEntropyLoss()
+        self.criterion_loss = nn.CrossEntropyLoss()
+
+
+@ROI_RELATION_PREDICTOR.register("VETOPredictor_MEET")
+class VETOPredictor_MEET(nn.Module, _NativeForward):
+    def __init__(self, config, in_channels):
+        super().__init__()
+        self.mode = _mode(config)
+        statistics = _dataset_statistics(config)
+        self.params = {"statistics": statistics, "obj_classes": statistics["obj_classes"],
+                       "rel_classes": statistics["rel_classes"]}
+        if bool(config.ENSEMBLE_LEARNING.EXPERT_GROUP):
+            raise NotImplementedError("veto_amd: ENSEMBLE_LEARNING.EXPERT_GROUP=True (3 experts per group) is not "
+                                      "supported; configs/VETO_final.yaml:154 ships False")
+        dataset = config.GLOBAL_SETTING.DATASET_CHOICE
+        self.group_split_mode = config.GCL_SETTING.GROUP_SPLIT_MODE
+        self.max_group_element_number_list = meet_tables.group_sizes(dataset, self.group_split_mode)
+        self.incre_idx_list = meet_tables.incre_idx_list(self.max_group_element_number_list)
+        self.num_groups = len(self.max_group_element_number_list)
+        self.experts_per_group = 1
+        self.num_obj_cls = len(self.params["obj_classes"])
+        self.model = _EnsembleParams(config, self.num_obj_cls, self.max_group_element_number_list,
+                                     self.params["obj_classes"])
+        self._native_init(config, self.model, self.num_obj_cls, list(self.model.rel_out))
+
+    def forward(self, proposals, rel_pair_idxs, rel_labels, logger, roi_features=None,
+                roi_depth_features=None, rel_binarys=None):
+        if self.training:
+            raise NotImplementedError(_TRAIN_MSG)
+        if self.mode == "predcls":
+            labels = _cat_field(proposals, "labels").long()
+            dist_labels = labels
+        else:
+            if self.mode == "sgdet":
+                raise NotImplementedError("veto_amd: MEET sgdet decoding (per-class NMS, "
+                                          "roi_relation_predictors.py:3855-3874) is outside the hot path")
+            dist_labels = _cat_field(proposals, "pred_labels").detach().long()
+            # obj_dists[:, 1:].max(1)[1] + 1 over a one-hot (:3776-3784): the label itself, or 1 for label 0
+            labels = torch.where(dist_labels > 0, dist_labels, torch.ones_like(dist_labels))
+        rel, n_objs, n_pairs = self._run_native(proposals, rel_pair_idxs, roi_features, roi_depth_features,
+                                                labels, None, debug=getattr(self, "debug_outputs", False))
+        rel_dists, col = {}, 0
+        for k, g in enumerate(self.max_group_element_number_list):
+            rel_dists["group_%d" % k] = rel[:, col:col + g + 2]
+            col += g + 2
+        obj_dists = nn.functional.one_hot(dist_labels.to(rel.device), self.num_obj_cls).float().split(n_objs, dim=0)
+        return obj_dists, rel_dists, {}, self.incre_idx_list, None, {}
