@@ -106,7 +106,7 @@ hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
   }
   const long waves = (long)a.n_pair * a.heads;
   const unsigned blocks = (unsigned)((waves + kWavesPerBlock - 1) / kWavesPerBlock);
-  hipLaunchKernelGGL(attention_kernel, dim3(blocks), dim3(256), lds, s, a, dh, ldh);
+  VETO_LAUNCH(attention_kernel, dim3(blocks), dim3(256), lds, s, a, dh, ldh);
   return hipGetLastError();
 }
 

@@ -3,6 +3,14 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// hipGetLastError() is per host thread and shared with every other user of the HIP runtime in the
+// process (PyTorch): clear a stale value before the launch so the check after it is about THIS launch.
+#define VETO_LAUNCH(...)            \
+  do {                              \
+    (void)hipGetLastError();        \
+    hipLaunchKernelGGL(__VA_ARGS__); \
+  } while (0)
+
 namespace veto {
 
 constexpr int kDim = 576;        // T_INPUT_DIM; forced by proj_d(512)+proj_v(64), model_veto.py:105-113

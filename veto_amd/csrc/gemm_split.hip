@@ -158,9 +158,9 @@ template <int NTERMS>
 hipError_t launch_terms(const GemmArgs& g, int epi, hipStream_t s) {
   dim3 grid(g.tiles_m * g.tiles_n), block(512);
   switch (epi) {
-    case EPI_F32: hipLaunchKernelGGL((gemm_split_kernel<NTERMS, EPI_F32>), grid, block, 0, s, g); break;
-    case EPI_RESID: hipLaunchKernelGGL((gemm_split_kernel<NTERMS, EPI_RESID>), grid, block, 0, s, g); break;
-    case EPI_GELU_SPLIT: hipLaunchKernelGGL((gemm_split_kernel<NTERMS, EPI_GELU_SPLIT>), grid, block, 0, s, g); break;
+    case EPI_F32: VETO_LAUNCH((gemm_split_kernel<NTERMS, EPI_F32>), grid, block, 0, s, g); break;
+    case EPI_RESID: VETO_LAUNCH((gemm_split_kernel<NTERMS, EPI_RESID>), grid, block, 0, s, g); break;
+    case EPI_GELU_SPLIT: VETO_LAUNCH((gemm_split_kernel<NTERMS, EPI_GELU_SPLIT>), grid, block, 0, s, g); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();

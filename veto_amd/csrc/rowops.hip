@@ -321,66 +321,66 @@ __global__ __launch_bounds__(128) void head_kernel(const float* __restrict__ cls
 
 hipError_t launch_split_planes(const float* src, __bf16* hi, __bf16* lo, size_t n, hipStream_t s) {
   const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
-  hipLaunchKernelGGL(split_planes_kernel, dim3(blocks), dim3(256), 0, s, src, hi, lo, n);
+  VETO_LAUNCH(split_planes_kernel, dim3(blocks), dim3(256), 0, s, src, hi, lo, n);
   return hipGetLastError();
 }
 
 hipError_t launch_build_patch_weight(const float* wd, const float* bd, const float* wv, const float* bv,
                                      __bf16* hi, __bf16* lo, float* bias_cat, hipStream_t s) {
-  hipLaunchKernelGGL(build_patch_weight_kernel, dim3(2 * kDim), dim3(256), 0, s, wd, bd, wv, bv, hi, lo, bias_cat);
+  VETO_LAUNCH(build_patch_weight_kernel, dim3(2 * kDim), dim3(256), 0, s, wd, bd, wv, bv, hi, lo, bias_cat);
   return hipGetLastError();
 }
 
 hipError_t launch_transpose_pair_proj(const float* src, float* dst, int kin, hipStream_t s) {
-  hipLaunchKernelGGL(transpose_pair_proj_kernel, dim3(kin), dim3(256), 0, s, src, dst, kin);
+  VETO_LAUNCH(transpose_pair_proj_kernel, dim3(kin), dim3(256), 0, s, src, dst, kin);
   return hipGetLastError();
 }
 
 hipError_t launch_transpose_head(const float* src, float* dst, int n_out, hipStream_t s) {
-  hipLaunchKernelGGL(transpose_head_kernel, dim3(kDim), dim3(128), 0, s, src, dst, n_out);
+  VETO_LAUNCH(transpose_head_kernel, dim3(kDim), dim3(128), 0, s, src, dst, n_out);
   return hipGetLastError();
 }
 
 hipError_t launch_obj_prep(const ObjPrepArgs& a, hipStream_t s) {
   if (a.num_obj_cls > 256 || a.embed_dim > 256) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(obj_prep_kernel, dim3(a.n_obj), dim3(256), 0, s, a);
+  VETO_LAUNCH(obj_prep_kernel, dim3(a.n_obj), dim3(256), 0, s, a);
   return hipGetLastError();
 }
 
 hipError_t launch_patchify(const float* depth, const float* rgb, __bf16* hi, __bf16* lo, int n_obj,
                            hipStream_t s) {
-  hipLaunchKernelGGL(patchify_kernel, dim3(n_obj, 2), dim3(256), 0, s, depth, rgb, hi, lo);
+  VETO_LAUNCH(patchify_kernel, dim3(n_obj, 2), dim3(256), 0, s, depth, rgb, hi, lo);
   return hipGetLastError();
 }
 
 hipError_t launch_pair_indices(const int64_t* rel_pairs, const int32_t* img_obj_off,
                                const int32_t* img_pair_off, int n_img, int n_pair, int32_t* subj,
                                int32_t* obj, int64_t* subj64, int64_t* obj64, hipStream_t s) {
-  hipLaunchKernelGGL(pair_indices_kernel, dim3((n_pair + 255) / 256), dim3(256), 0, s, rel_pairs,
+  VETO_LAUNCH(pair_indices_kernel, dim3((n_pair + 255) / 256), dim3(256), 0, s, rel_pairs,
                      img_obj_off, img_pair_off, n_img, n_pair, subj, obj, subj64, obj64);
   return hipGetLastError();
 }
 
 hipError_t launch_enumerate_pairs(int n, int64_t* out, hipStream_t s) {
   const long total = n > 1 ? (long)n * (n - 1) : 1;
-  hipLaunchKernelGGL(enumerate_pairs_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, n, out);
+  VETO_LAUNCH(enumerate_pairs_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, n, out);
   return hipGetLastError();
 }
 
 hipError_t launch_assemble(const AssembleArgs& a, hipStream_t s) {
-  hipLaunchKernelGGL(assemble_kernel, dim3(a.n_pair), dim3(256), 0, s, a);
+  VETO_LAUNCH(assemble_kernel, dim3(a.n_pair), dim3(256), 0, s, a);
   return hipGetLastError();
 }
 
 hipError_t launch_layernorm(const float* x, long ldx, const float* w, const float* b, __bf16* hi,
                             __bf16* lo, int rows, hipStream_t s) {
-  hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, ldx, w, b, hi, lo, rows);
+  VETO_LAUNCH(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, ldx, w, b, hi, lo, rows);
   return hipGetLastError();
 }
 
 hipError_t launch_head(const float* cls, const float* wt, const float* bias, float* out, int n_pair,
                        int n_out, hipStream_t s) {
-  hipLaunchKernelGGL(head_kernel, dim3((n_pair + 3) / 4), dim3(128), 0, s, cls, wt, bias, out, n_pair, n_out);
+  VETO_LAUNCH(head_kernel, dim3((n_pair + 3) / 4), dim3(128), 0, s, cls, wt, bias, out, n_pair, n_out);
   return hipGetLastError();
 }
 

@@ -1,0 +1,48 @@
+"""Data-parallel evaluation over the GPUs of one node: images are sharded across ranks (one process
+per GPU, as the reference's DistributedSampler does -- data/samplers/distributed.py:10-65) and the
+per-rank predicate logits are combined with ONE tensor all-gather over RCCL/xGMI, replacing the
+reference's pickled-BoxList double all_gather (utils/comm.py:48-96, engine/inference.py:49-54).
+
+The same code runs on the `gloo` backend with CPU tensors (tests/test_distributed_gloo.py)."""
+import torch
+import torch.distributed as dist
+
+
+def shard_images(num_images, rank=None, world=None):
+    """Contiguous shard of image indices for this rank; every image goes to exactly one rank and
+    shard sizes differ by at most one (IMS_PER_BATCH % num_gpus == 0 in the reference, data/build.py:189-191)."""
+    world = dist.get_world_size() if world is None else world
+    rank = dist.get_rank() if rank is None else rank
+    base, rem = divmod(num_images, world)
+    start = rank * base + min(rank, rem)
+    return list(range(start, start + base + (1 if rank < rem else 0)))
+
+
+def all_gather_logits(logits, equal_counts=False, group=None):
+    """logits: [P_r, C] on this rank -> [sum_r P_r, C], rank-major, on every rank.
+
+    P_r may differ between ranks (images have different object counts): the row counts are gathered
+    first and the payload is padded to the maximum, so the data exchange is a single
+    all_gather_into_tensor (direct, one hop per peer on the fully connected xGMI mesh)."""
+    if not dist.is_available() or not dist.is_initialized():
+        return logits
+    world = dist.get_world_size(group)
+    if world == 1:
+        return logits
+    logits = logits.contiguous()
+    p, c = logits.shape
+    if equal_counts:
+        out = torch.empty((world * p, c), dtype=logits.dtype, device=logits.device)
+        dist.all_gather_into_tensor(out, logits, group=group)
+        return out
+    counts = torch.empty(world, dtype=torch.int64, device=logits.device)
+    dist.all_gather_into_tensor(counts, torch.tensor([p], dtype=torch.int64, device=logits.device), group=group)
+    counts = counts.tolist()
+    pmax = max(counts)
+    padded = logits
+    if p < pmax:
+        padded = torch.zeros((pmax, c), dtype=logits.dtype, device=logits.device)
+        padded[:p] = logits
+    out = torch.empty((world * pmax, c), dtype=logits.dtype, device=logits.device)
+    dist.all_gather_into_tensor(out, padded, group=group)
+    return torch.cat([out[r * pmax: r * pmax + counts[r]] for r in range(world)], 0)

@@ -4,6 +4,11 @@ There is no fallback: if the library is missing or a call fails, this raises.
 """
 import ctypes
 import os
+
+# PyTorch bundles its own HIP runtime (torch/lib/libamdhip64.so, SONAME libamdhip64.so.7).  It must be
+# mapped BEFORE libveto_amd.so so that the library's NEEDED libamdhip64.so.7 resolves to that same copy;
+# the other order maps two runtimes into the process and the second one finds no device.
+import torch  # noqa: F401
 from ctypes import (POINTER, Structure, byref, c_char_p, c_double, c_float, c_int, c_int32, c_int64,
                     c_size_t, c_void_p)
 

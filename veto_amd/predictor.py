@@ -193,7 +193,7 @@ class _NativeForward:
         out["rel_out.bias"] = torch.cat([h.bias for h in heads], 0) if len(heads) > 1 else heads[0].bias
         return out
 
-    def _version(self):
+    def _weights_version(self):
         return tuple((p.data_ptr(), p._version) for p in list(self._trunk.parameters()) + list(self._trunk.buffers()))
 
     def _ensure_engine(self, device):
@@ -207,7 +207,7 @@ class _NativeForward:
                                          precision=self._precision, device=idx, max_chunk_pairs=self._max_chunk)
             self._engine_device = idx
             self._uploaded = None
-        ver = self._version()
+        ver = self._weights_version()
         if self._uploaded != ver:
             tensors = self._weight_tensors()
             stream = torch.cuda.current_stream(device).cuda_stream
