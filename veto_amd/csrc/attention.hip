@@ -1,12 +1,20 @@
 // Per-pair multi-head self-attention over the 19 relation tokens (model_veto.py:85-96):
 //   dots = q k^T * dh^-0.5 ; attn = softmax(dots, -1) ; out = attn v ; heads merged 'b h n d -> b n (h d)'.
-// One wave per (pair, head).  q/k/v of the head are staged in LDS in fp32; the 19x19 scores, the
-// softmax and the PV product are computed in fp32 on the vector ALU (QK^T + AV are 0.8 % of the
-// path's FLOPs).  The result is written as the hi/lo bf16 planes the
-// out-projection GEMM consumes.  cls_only = last layer: only token 0's query is needed
-// (model_veto.py:23 consumes x[:, 0] only), k/v still cover all 19 tokens.
+// One wave per (pair, head).  The result is written as the hi/lo bf16 planes the out-projection
+// GEMM consumes.  cls_only = last layer: only token 0's query is needed (model_veto.py:23 consumes
+// x[:, 0] only), k/v still cover all 19 tokens.
+//
+// attention_mfma_kernel<DH> (head dims 72 and 96 = the 8-head and 6-head configurations): QK^T and
+// PV on v_mfma_f32_32x32x16_bf16 in the same 3-term split-bf16 scheme as the GEMMs.  The scores are
+// computed TRANSPOSED (S^T = K Q^T) so that one query's 19 scores sit in the 16 accumulator
+// registers of lanes l and l+32: the softmax is in-register plus one cross-half shuffle, and the
+// probabilities are already the A operand of the PV product (accumulator-as-operand, no LDS trip).
+// V is transposed on its way into LDS so the PV B operand is two 8-byte reads.
+// attention_kernel (generic head dim): fp32 on the vector ALU, LDS staged.
 #include "common.h"
 #include "kernels.h"
+
+#include <cstdlib>
 
 namespace veto {
 
@@ -88,11 +96,212 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a, int dh, int 
   }
 }
 
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+template <int DH>
+__global__ __launch_bounds__(128) void attention_mfma_kernel(AttnArgs a) {
+  constexpr int DHP = (DH + 15) / 16 * 16;  // contraction extent of QK^T (zero padded)
+  constexpr int RB = DHP * 2;               // bytes per row of the Q / K images (bf16)
+  constexpr int NT = (DH + 31) / 32;        // 32-wide output tiles of PV
+  constexpr int VROW = 40;                  // bytes per row of the transposed V image: 20 keys (19 + one zero)
+  constexpr int QK_PLANE = kTokens * RB;
+  constexpr int VT_PLANE = NT * 32 * VROW;
+  constexpr int WAVE_LDS = 4 * QK_PLANE + 2 * VT_PLANE;
+  constexpr int CH = DH / 8;                // 8-element chunks per row
+  constexpr int PER_MAT = kTokens * CH;
+  constexpr int ROUNDS = (3 * PER_MAT + 63) / 64;
+  static_assert(DH % 8 == 0 && QK_PLANE % 16 == 0 && kTokens * DH * 4 <= 4 * QK_PLANE, "layout");
+  __shared__ __attribute__((aligned(16))) char smem[2 * WAVE_LDS];
+
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const long gw = (long)blockIdx.x * 2 + w;
+  const long total = (long)a.n_pair * a.heads;
+  const bool active = gw < total;
+  const long item = active ? gw : total - 1;
+  const int pair = (int)(item / a.heads), head = (int)(item % a.heads);
+  char* base = smem + w * WAVE_LDS;
+  char* q_hi = base;
+  char* q_lo = base + QK_PLANE;
+  char* k_hi = base + 2 * QK_PLANE;
+  char* k_lo = base + 3 * QK_PLANE;
+  char* vt_hi = base + 4 * QK_PLANE;
+  char* vt_lo = vt_hi + VT_PLANE;
+  const float* src0 = a.qkv + (size_t)pair * kTokens * (3 * kDim) + head * DH;
+
+  // ---- global -> registers (all loads in flight), then -> bf16 hi/lo LDS images ----------------
+  f32x4 ld[ROUNDS][2];
+#pragma unroll
+  for (int r = 0; r < ROUNDS; ++r) {
+    const int e = lane + 64 * r;
+    const int mat = e / PER_MAT, rem = e % PER_MAT, i = rem / CH, c = rem % CH;
+    const bool need = e < 3 * PER_MAT && !(a.cls_only && mat == 0 && i > 0);
+    if (need) {
+      const float* src = src0 + (size_t)i * (3 * kDim) + mat * kDim + c * 8;
+      ld[r][0] = *(const f32x4*)src;
+      ld[r][1] = *(const f32x4*)(src + 4);
+    } else {
+      ld[r][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+      ld[r][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < ROUNDS; ++r) {
+    const int e = lane + 64 * r;
+    if (e >= 3 * PER_MAT) continue;
+    const int mat = e / PER_MAT, rem = e % PER_MAT, i = rem / CH, c = rem % CH;
+    bf16x8 hi, lo;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      __bf16 hh, ll;
+      split_bf16(ld[r][t >> 2][t & 3], hh, ll);
+      hi[t] = hh;
+      lo[t] = ll;
+    }
+    if (mat < 2) {
+      char* dst = (mat == 0 ? q_hi : k_hi) + i * RB + c * 16;
+      *(bf16x8*)dst = hi;
+      *(bf16x8*)(dst + QK_PLANE) = lo;
+    } else {
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        *(__bf16*)(vt_hi + (c * 8 + t) * VROW + i * 2) = hi[t];
+        *(__bf16*)(vt_lo + (c * 8 + t) * VROW + i * 2) = lo[t];
+      }
+    }
+  }
+  if (DHP > DH) {  // zero the contraction padding of the Q / K rows
+    for (int idx = lane; idx < 4 * kTokens; idx += 64) {
+      char* dst = base + (idx / kTokens) * QK_PLANE + (idx % kTokens) * RB + DH * 2;
+#pragma unroll
+      for (int t = 0; t < (DHP - DH) / 2; ++t) *(uint32_t*)(dst + 4 * t) = 0u;
+    }
+  }
+  for (int d = lane; d < NT * 32; d += 64) {  // key 19 of every V^T row is a finite zero
+    *(uint16_t*)(vt_hi + d * VROW + 38) = 0;
+    *(uint16_t*)(vt_lo + d * VROW + 38) = 0;
+  }
+  __syncthreads();
+
+  // ---- S^T = K Q^T: row = key j, column = query i ----------------------------------------------
+  const int r = lane & 31, h = lane >> 5;
+  const int rr = r < kTokens ? r : 0;  // lanes beyond the 19 tokens re-read row 0; their outputs are masked
+  f32x16 st;
+#pragma unroll
+  for (int t = 0; t < 16; ++t) st[t] = 0.f;
+#pragma unroll
+  for (int s = 0; s < DHP / 16; ++s) {
+    const int off = rr * RB + (16 * s + 8 * h) * 2;
+    const bf16x8 kh = *(const bf16x8*)(k_hi + off), kl = *(const bf16x8*)(k_lo + off);
+    const bf16x8 qh = *(const bf16x8*)(q_hi + off), ql = *(const bf16x8*)(q_lo + off);
+    st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl, qh, st, 0, 0, 0);
+    st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, ql, st, 0, 0, 0);
+    st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qh, st, 0, 0, 0);
+  }
+
+  // ---- softmax over the keys of query (lane & 31): 16 registers here + 16 in lane ^ 32 ---------
+  const float scale = 1.0f / sqrtf((float)DH);
+  float p[16];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int t = 0; t < 16; ++t) {
+    const int j = (t & 3) + 8 * (t >> 2) + 4 * h;
+    p[t] = j < kTokens ? st[t] * scale : -INFINITY;
+    mx = fmaxf(mx, p[t]);
+  }
+  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+  float sum = 0.f;
+#pragma unroll
+  for (int t = 0; t < 16; ++t) {
+    p[t] = expf(p[t] - mx);
+    sum += p[t];
+  }
+  sum += __shfl_xor(sum, 32, 64);
+  const float inv = 1.f / sum;
+  bf16x8 ph[2], pl[2];
+#pragma unroll
+  for (int t = 0; t < 16; ++t) {
+    __bf16 hh, ll;
+    split_bf16(p[t] * inv, hh, ll);
+    ph[t >> 3][t & 7] = hh;
+    pl[t >> 3][t & 7] = ll;
+  }
+
+  // ---- O = P V: A operand = P^T accumulators; element e of k-step s is key 16s + 8(e>>2) + 4h + (e&3)
+  float* o_lds = (float*)base;  // [19][DH] fp32, re-uses the (now dead) Q / K images
+  const bf16x4 z4 = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+#pragma unroll
+  for (int n = 0; n < NT; ++n) {
+    const int d = 32 * n + r;
+    f32x16 o;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) o[t] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      bf16x4 h0, h1, l0, l1;
+      if (s == 0) {
+        h0 = *(const bf16x4*)(vt_hi + d * VROW + 8 * h);
+        h1 = *(const bf16x4*)(vt_hi + d * VROW + 16 + 8 * h);
+        l0 = *(const bf16x4*)(vt_lo + d * VROW + 8 * h);
+        l1 = *(const bf16x4*)(vt_lo + d * VROW + 16 + 8 * h);
+      } else {  // keys 16..19 live in lane half 0; everything else of this k-step is padding
+        h0 = *(const bf16x4*)(vt_hi + d * VROW + 32);
+        l0 = *(const bf16x4*)(vt_lo + d * VROW + 32);
+        if (h) { h0 = z4; l0 = z4; }
+        h1 = z4;
+        l1 = z4;
+      }
+      const bf16x8 vh = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+      const bf16x8 vl = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+      o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pl[s], vh, o, 0, 0, 0);
+      o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ph[s], vl, o, 0, 0, 0);
+      o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ph[s], vh, o, 0, 0, 0);
+    }
+    if (d < DH) {
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        const int i = (t & 3) + 8 * (t >> 2) + 4 * h;
+        if (i < kTokens) o_lds[i * DH + d] = o[t];
+      }
+    }
+  }
+  __syncthreads();
+  if (!active) return;
+  const int nq = a.cls_only ? 1 : kTokens;
+  for (int e = lane; e < nq * CH; e += 64) {
+    const int i = e / CH, c = e % CH;
+    const f32x4 v0 = *(const f32x4*)(o_lds + i * DH + c * 8);
+    const f32x4 v1 = *(const f32x4*)(o_lds + i * DH + c * 8 + 4);
+    bf16x8 hi, lo;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      __bf16 hh, ll;
+      split_bf16(v0[t], hh, ll);
+      hi[t] = hh;
+      lo[t] = ll;
+      split_bf16(v1[t], hh, ll);
+      hi[4 + t] = hh;
+      lo[4 + t] = ll;
+    }
+    const size_t row = a.cls_only ? (size_t)pair : (size_t)pair * kTokens + i;
+    const size_t off = row * kDim + head * DH + c * 8;
+    *(bf16x8*)(a.o_hi + off) = hi;
+    *(bf16x8*)(a.o_lo + off) = lo;
+  }
+}
+
 }  // namespace
 
 hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
   if (kDim % a.heads != 0) return hipErrorInvalidValue;
   const int dh = kDim / a.heads;
+  static const bool force_valu = getenv("VETO_ATTN_VALU") != nullptr;  // A/B knob for the parity tests
+  if (!force_valu && (dh == 72 || dh == 96)) {
+    const long items = (long)a.n_pair * a.heads;
+    const unsigned blocks = (unsigned)((items + 1) / 2);
+    if (dh == 72) VETO_LAUNCH(attention_mfma_kernel<72>, dim3(blocks), dim3(128), 0, s, a);
+    else VETO_LAUNCH(attention_mfma_kernel<96>, dim3(blocks), dim3(128), 0, s, a);
+    return hipGetLastError();
+  }
   if (dh % 4 != 0) return hipErrorInvalidValue;
   const int ldh = dh + 4;
   const size_t lds = (size_t)kWavesPerBlock * (3 * kTokens * ldh + kTokens * 20) * sizeof(float);

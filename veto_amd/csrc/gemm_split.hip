@@ -19,26 +19,38 @@
 #include "common.h"
 #include "kernels.h"
 
+#include <cstdlib>
+#include <type_traits>
+
 namespace veto {
 
 namespace {
 
-constexpr int BM = 256, BN = 192, BK = 32;
-constexpr int kStageBytes = (2 * BM + 2 * BN) * BK * 2;  // 57344
-constexpr int kAHi = 0, kALo = BM * 64, kWHi = 2 * BM * 64, kWLo = 2 * BM * 64 + BN * 64;
+constexpr int BN = 192, BK = 32;
 
 __device__ __forceinline__ void glds16(const char* src, char* lds_dst) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                    (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
 }
 
-template <int NTERMS, int EPI>
-__global__ __launch_bounds__(512, 2) void gemm_split_kernel(GemmArgs g) {
+// WM = waves along M.  WM=4: 256x192 tile, 8 waves, 112 KiB LDS, one workgroup per CU.
+// WM=2: 128x192 tile, 4 waves, 80 KiB LDS, TWO workgroups per CU whose barriers/epilogues are
+// independent, so one workgroup's epilogue and stage waits hide under the other's MFMA stream.
+template <int NTERMS, int EPI, int WM>
+__global__ __launch_bounds__(128 * WM, 2) void gemm_split_kernel(GemmArgs g) {
+  constexpr int BM = 64 * WM;
+  constexpr int NWAVES = 2 * WM;
+  constexpr int kStageBytes = (2 * BM + 2 * BN) * BK * 2;
+  constexpr int kAHi = 0, kALo = BM * 64, kWHi = 2 * BM * 64, kWLo = 2 * BM * 64 + BN * 64;
+  constexpr int CA = BM / 16, CW = BN / 16;          // 16-row chunks per plane
+  constexpr int NCHUNK = 2 * CA + 2 * CW;
+  constexpr int CPW = NCHUNK / NWAVES;  // chunks per wave
+  static_assert(CPW * NWAVES == NCHUNK, "every wave moves the same number of chunks");
   __shared__ __attribute__((aligned(16))) char smem[2 * kStageBytes];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6) & (NWAVES - 1);
   const int wm = w >> 1, wn = w & 1;
 
   // XCD-aware tile order: blocks b and b+8 share an XCD (round-robin dispatch), so give each XCD a
@@ -52,28 +64,35 @@ __global__ __launch_bounds__(512, 2) void gemm_split_kernel(GemmArgs g) {
 
   const int K = g.K;
   // ---- per-lane source pointers of this wave's 16-row chunks (7 per stage) -------------------
+#ifdef VETO_EXPERIMENT_FULL_LINES  // timing experiment only (wrong results): 8 rows x 128 B per chunk
+  const int rr = lane >> 3;
+  const int qs = lane & 7;
+#else
   const int rr = lane >> 2;                       // row inside the 16-row chunk
   const int fs = (4 - (rr >> 2)) & 3;             // swizzle key of that row
   const int qs = (lane & 3) ^ fs;                 // source k-chunk that lands in LDS slot lane&3
-  const char* src[7];
+#endif
+  const char* src[CPW];
 #pragma unroll
-  for (int i = 0; i < 7; ++i) {
-    const int c = w + 8 * i;                      // chunk id, wave-uniform
-    const __bf16* base;
-    int row;
-    if (c < 16) { base = g.a_hi; row = tile_m * BM + c * 16; }
-    else if (c < 32) { base = g.a_lo; row = tile_m * BM + (c - 16) * 16; }
-    else if (c < 44) { base = g.w_hi; row = tile_n * BN + (c - 32) * 16; }
-    else { base = g.w_lo; row = tile_n * BN + (c - 44) * 16; }
+  for (int i = 0; i < CPW; ++i) {
+    const int c = w + NWAVES * i;                 // chunk id, wave-uniform
+    const __bf16* base = g.a_hi;
+    int row = 0;
+    if (c < CA) { base = g.a_hi; row = tile_m * BM + c * 16; }
+    else if (c < 2 * CA) { base = g.a_lo; row = tile_m * BM + (c - CA) * 16; }
+    else if (c < 2 * CA + CW) { base = g.w_hi; row = tile_n * BN + (c - 2 * CA) * 16; }
+    else if (c < NCHUNK) { base = g.w_lo; row = tile_n * BN + (c - 2 * CA - CW) * 16; }
     src[i] = (const char*)(base + (size_t)(row + rr) * K + qs * 8);
   }
 
+  // FAST mode never reads the lo planes; their chunks are still moved (the mode exists to report
+  // the single-pass error, not to be tuned).
+  auto lo_only_chunk = [&](int) { return false; };
   auto load_stage = [&](int stage, int kt) {
 #pragma unroll
-    for (int i = 0; i < 7; ++i) {
-      const int c = w + 8 * i;
-      if (NTERMS == 1 && ((c >= 16 && c < 32) || c >= 44)) continue;  // lo planes unused
-      glds16(src[i] + (size_t)kt * (BK * 2), smem + stage * kStageBytes + c * 1024);
+    for (int i = 0; i < CPW; ++i) {
+      if (lo_only_chunk(i)) continue;
+      glds16(src[i] + (size_t)kt * (BK * 2), smem + stage * kStageBytes + (w + NWAVES * i) * 1024);
     }
   };
 
@@ -90,25 +109,39 @@ __global__ __launch_bounds__(512, 2) void gemm_split_kernel(GemmArgs g) {
     for (int m = 0; m < 4; ++m) acc[n][m] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nk = K / BK;
-  load_stage(0, 0);
-  for (int kt = 0; kt < nk; ++kt) {
+  bf16x8 ah[4], al[4], wh[6], wl[6];
+
+  // One k-step.  Software pipeline inside the step: while the 12 MFMAs of weight tile n run, the
+  // fragments of tile n+1 are read from LDS and (in the first GL groups) two LDS-DMA chunks of the
+  // NEXT stage are issued, so the vector-memory issue cost hides under the matrix pipe instead of
+  // preceding it.  sched_group_barrier pins that interleave in the emitted code.
+  auto k_step = [&](int kt, auto load_next) {
+    constexpr bool LOAD = decltype(load_next)::value;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (kt + 1 < nk) load_stage((kt + 1) & 1, kt + 1);
     const char* st = smem + (kt & 1) * kStageBytes;
-    bf16x8 ah[4], al[4], wh[6], wl[6];
+    char* nst = smem + ((kt + 1) & 1) * kStageBytes;
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
       ah[m] = *(const bf16x8*)(st + kAHi + a_off + m * 1024);
       if (NTERMS == 3) al[m] = *(const bf16x8*)(st + kALo + a_off + m * 1024);
     }
+    wh[0] = *(const bf16x8*)(st + kWHi + w_off);
+    if (NTERMS == 3) wl[0] = *(const bf16x8*)(st + kWLo + w_off);
+    constexpr int GL = (CPW + 1) / 2;  // groups that carry global loads (2 chunks each)
 #pragma unroll
     for (int n = 0; n < 6; ++n) {
-      wh[n] = *(const bf16x8*)(st + kWHi + w_off + n * 1024);
-      if (NTERMS == 3) wl[n] = *(const bf16x8*)(st + kWLo + w_off + n * 1024);
-    }
+      if (n < 5) {
+        wh[n + 1] = *(const bf16x8*)(st + kWHi + w_off + (n + 1) * 1024);
+        if (NTERMS == 3) wl[n + 1] = *(const bf16x8*)(st + kWLo + w_off + (n + 1) * 1024);
+      }
+      if (LOAD && n < GL) {
 #pragma unroll
-    for (int n = 0; n < 6; ++n)
+        for (int j = 0; j < 2; ++j) {
+          const int i = 2 * n + j;
+          if (i < CPW && !lo_only_chunk(i)) glds16(src[i] + (size_t)(kt + 1) * (BK * 2), nst + (w + NWAVES * i) * 1024);
+        }
+      }
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
         if (NTERMS == 3) {
@@ -117,7 +150,21 @@ __global__ __launch_bounds__(512, 2) void gemm_split_kernel(GemmArgs g) {
         }
         acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[n], ah[m], acc[n][m], 0, 0, 0);
       }
-  }
+    }
+    if (NTERMS == 3) {  // DS_READ 0x100, VMEM 0x10, MFMA 0x8
+      __builtin_amdgcn_sched_group_barrier(0x100, 10, 0);
+#pragma unroll
+      for (int n = 0; n < 6; ++n) {
+        if (n < 5) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        if (LOAD && n < GL) __builtin_amdgcn_sched_group_barrier(0x10, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x8, 12, 0);
+      }
+    }
+  };
+
+  load_stage(0, 0);
+  for (int kt = 0; kt < nk - 1; ++kt) k_step(kt, std::true_type{});
+  k_step(nk - 1, std::false_type{});
 
   // ---- epilogue: lane holds C[row = m-tile row lane&15][4 consecutive cols (lane>>4)*4..+3] ----
 #pragma unroll
@@ -154,27 +201,40 @@ __global__ __launch_bounds__(512, 2) void gemm_split_kernel(GemmArgs g) {
   }
 }
 
-template <int NTERMS>
-hipError_t launch_terms(const GemmArgs& g, int epi, hipStream_t s) {
-  dim3 grid(g.tiles_m * g.tiles_n), block(512);
+template <int NTERMS, int WM>
+hipError_t launch_terms(GemmArgs g, int epi, hipStream_t s) {
+  constexpr int BM = 64 * WM;
+  g.tiles_m = (g.M + BM - 1) / BM;
+  g.tiles_n = g.N / BN;
+  dim3 grid(g.tiles_m * g.tiles_n), block(128 * WM);
   switch (epi) {
-    case EPI_F32: VETO_LAUNCH((gemm_split_kernel<NTERMS, EPI_F32>), grid, block, 0, s, g); break;
-    case EPI_RESID: VETO_LAUNCH((gemm_split_kernel<NTERMS, EPI_RESID>), grid, block, 0, s, g); break;
-    case EPI_GELU_SPLIT: VETO_LAUNCH((gemm_split_kernel<NTERMS, EPI_GELU_SPLIT>), grid, block, 0, s, g); break;
+    case EPI_F32: VETO_LAUNCH((gemm_split_kernel<NTERMS, EPI_F32, WM>), grid, block, 0, s, g); break;
+    case EPI_RESID: VETO_LAUNCH((gemm_split_kernel<NTERMS, EPI_RESID, WM>), grid, block, 0, s, g); break;
+    case EPI_GELU_SPLIT: VETO_LAUNCH((gemm_split_kernel<NTERMS, EPI_GELU_SPLIT, WM>), grid, block, 0, s, g); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
 }
 
+int g_tile_wm = 0;  // 0 = not yet read from the environment
+
+int tile_wm() {
+  if (g_tile_wm == 0) {
+    const char* e = getenv("VETO_GEMM_BM");  // tuning knob: 256 or 128 (default)
+    g_tile_wm = (e && atoi(e) == 256) ? 4 : 2;
+  }
+  return g_tile_wm;
+}
+
 }  // namespace
 
-int gemm_rows_padded(int m) { return (m + BM - 1) / BM * BM; }
+// Row padding every A-operand buffer must have (the larger tile; valid for both).
+int gemm_rows_padded(int m) { return (m + 255) / 256 * 256; }
 
 hipError_t launch_gemm_split(GemmArgs g, int epi, int precision, hipStream_t s) {
   if (g.N % BN != 0 || g.K % BK != 0 || g.M <= 0) return hipErrorInvalidValue;
-  g.tiles_m = (g.M + BM - 1) / BM;
-  g.tiles_n = g.N / BN;
-  return precision == 0 ? launch_terms<3>(g, epi, s) : launch_terms<1>(g, epi, s);
+  if (tile_wm() == 4) return precision == 0 ? launch_terms<3, 4>(g, epi, s) : launch_terms<1, 4>(g, epi, s);
+  return precision == 0 ? launch_terms<3, 2>(g, epi, s) : launch_terms<1, 2>(g, epi, s);
 }
 
 }  // namespace veto

@@ -52,7 +52,9 @@ class VetoError(RuntimeError):
 
 
 def library_path():
-    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libveto_amd.so")
+    # VETO_AMD_LIB: A/B a differently built copy of the same library (tools/ only; never a fallback)
+    return os.environ.get("VETO_AMD_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc",
+                                                          "libveto_amd.so")
 
 
 def load_library():
