@@ -159,12 +159,24 @@ def main():
         dist.destroy_process_group()
 
 
+def usable_cores():
+    """CPUs this process may actually use: the cgroup quota when there is one, else the affinity mask."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(sd, args, batch, gpu_logits, pairs):
     """Times the CPU oracle (a port of the reference formulation: materialised gathers, per-pair patch
     embedding, all layers on all 19 tokens, fp32 torch-CPU) image by image on the host cores until
     ~cpu-seconds have elapsed; also returns the max-abs logit difference GPU vs oracle on those images."""
     from oracle import veto_oracle as vo
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     torch.set_num_threads(cores)
     cfg = vo.OracleConfig(layers=args.layers, heads=args.heads)
     n = args.objs

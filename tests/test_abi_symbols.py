@@ -1,0 +1,54 @@
+"""CPU-side checks of the C-ABI library: it builds/loads, exports every entry point that
+include/veto_amd.h declares, and rejects bad configurations before touching the GPU."""
+import ctypes
+import os
+import re
+
+from veto_amd import native
+
+HEADER = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "veto_amd.h")
+
+
+def _declared():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(veto_[a-z_]+)\s*\(", text)))
+
+
+def test_header_and_binding_list_the_same_entry_points():
+    assert _declared() == sorted(native.EXPORTS)
+
+
+def test_library_exports_every_declared_symbol():
+    lib = native.load_library()
+    for name in _declared():
+        assert hasattr(lib, name), name
+    assert b"gfx950" in lib.veto_version()
+
+
+def test_struct_sizes_match_the_header_layout():
+    # 13 int32 fields; 4 ints + 3 ptrs + 2 ints + 5 ptrs; 2 ints + 4 ptrs
+    assert ctypes.sizeof(native.VetoConfig) == 52
+    assert ctypes.sizeof(native.VetoInputs) == 16 + 3 * 8 + 8 + 5 * 8
+    assert ctypes.sizeof(native.VetoDebugOutputs) == 8 + 4 * 8
+
+
+def test_create_rejects_bad_configs_without_a_gpu():
+    lib = native.load_library()
+    h = ctypes.c_void_p()
+
+    def cfg(**kw):
+        base = dict(struct_size=ctypes.sizeof(native.VetoConfig), dim=576, layers=4, heads=8, patch=2, channels=256,
+                    resolution=8, num_obj_cls=151, embed_dim=200, num_out=51, precision=0, device=0,
+                    max_chunk_pairs=0)
+        base.update(kw)
+        return native.VetoConfig(**base)
+
+    for bad, needle in ((dict(dim=512), b"576"), (dict(heads=7), b"NHEADS"), (dict(patch=4), b"PATCH_SIZE"),
+                        (dict(struct_size=8), b"size mismatch"), (dict(layers=0), b"ENC_LAYERS"),
+                        (dict(precision=5), b"precision")):
+        rc = lib.veto_create(ctypes.byref(cfg(**bad)), ctypes.byref(h))
+        assert rc == -1, bad
+        assert needle in lib.veto_last_error(), (bad, lib.veto_last_error())
+    assert lib.veto_workspace_bytes(None, 10, 90) == 0
+    assert lib.veto_debug_gemm_workspace_bytes(256, 192, 32) == 2 * 256 * 32 * 2 + 2 * 192 * 32 * 2

@@ -1,0 +1,136 @@
+"""Host-side logic that needs no GPU: registry protocol, config slice, BoxList, MEET tables,
+state-dict key compatibility, error behaviour, synthetic-data determinism."""
+import hashlib
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from veto_amd import meet_tables, predictor, registry, synth, testing
+from veto_amd.config import default_config
+from veto_amd.structures import BoxList
+
+
+def test_registry_protocol_matches_reference():
+    r = registry.Registry()
+
+    @r.register("a")
+    def a():
+        return 1
+
+    r.register("b", a)
+    assert r["a"] is a and r["b"] is a
+    with pytest.raises(AssertionError):       # utils/registry.py:4-6
+        r.register("a", a)
+    assert set(registry.ROI_RELATION_PREDICTOR) >= {"VETOPredictor", "VETOPredictor_MEET"}
+
+
+def test_install_overwrites_reference_entries():
+    target = registry.Registry({"VETOPredictor": object(), "VETOPredictor_MEET": object(), "MotifPredictor": 7})
+    registry.install(target)
+    assert target["VETOPredictor"] is predictor.VETOPredictor
+    assert target["VETOPredictor_MEET"] is predictor.VETOPredictor_MEET
+    assert target["MotifPredictor"] == 7
+    cfg = testing.make_config(2, 8)
+    predictor.set_statistics_provider(None)
+    predictor.set_embedding_provider(lambda names, d, k: torch.zeros(len(names), k))
+    m = registry.make_roi_relation_predictor(cfg, 512)
+    assert isinstance(m, predictor.VETOPredictor) and m.mode == "predcls"
+
+
+def test_state_dict_keys_equal_the_reference_names():
+    # synth.*_state_dict key lists were checked against the real reference's load_state_dict
+    # (tests/golden/make_golden.py: no unexpected keys, only criterion buffers missing)
+    predictor.set_embedding_provider(lambda names, d, k: torch.zeros(len(names), k))
+    m = predictor.VETOPredictor(testing.make_config(6, 6), 512)
+    assert set(m.state_dict()) == set(synth.predictor_state_dict(0, layers=6))
+    mm = predictor.VETOPredictor_MEET(testing.make_config(6, 6, meet=True), 512)
+    assert set(mm.state_dict()) == set(synth.meet_state_dict(0, [4, 6, 9, 19, 12], layers=6))
+    assert mm.max_group_element_number_list == [4, 6, 9, 19, 12]
+    g, _, _ = load_golden("meet_n10_l6h6")
+    assert mm.incre_idx_list == [int(x) for x in g["incre_idx_list"]]
+    gq = predictor.VETOPredictor_MEET(testing.make_config(4, 8, meet=True, dataset="GQA"), 512)
+    g, _, _ = load_golden("meet_gqa_n6_l4h8")
+    assert gq.incre_idx_list == [int(x) for x in g["incre_idx_list"]]
+    assert [h.out_features for h in gq.model.rel_out] == [int(x) + 2 for x in g["group_sizes"]]
+
+
+def test_modes_and_constructor_errors():
+    cfg = default_config()
+    cfg.MODEL.ROI_RELATION_HEAD.USE_GT_OBJECT_LABEL = False
+    predictor.set_embedding_provider(lambda names, d, k: torch.zeros(len(names), k))
+    assert predictor.VETOPredictor(cfg, 512).mode == "sgcls"
+    cfg.MODEL.ROI_RELATION_HEAD.USE_GT_BOX = False
+    assert predictor.VETOPredictor(cfg, 512).mode == "sgdet"
+    cfg.MODEL.ROI_RELATION_HEAD.VETOTRANSFORMER.T_INPUT_DIM = 512
+    with pytest.raises(ValueError):
+        predictor.VETOPredictor(cfg, 512)
+    cfg = testing.make_config(2, 8, meet=True)
+    cfg.ENSEMBLE_LEARNING.EXPERT_GROUP = True
+    with pytest.raises(NotImplementedError):
+        predictor.VETOPredictor_MEET(cfg, 512)
+    cfg = testing.make_config(2, 8)
+    cfg.VETO_AMD.PRECISION = "int4"
+    with pytest.raises(ValueError):
+        predictor.VETOPredictor(cfg, 512)
+
+
+def test_no_cpu_path_and_no_training_path():
+    predictor.set_embedding_provider(lambda names, d, k: torch.zeros(len(names), k))
+    m = predictor.VETOPredictor(testing.make_config(1, 8), 512).eval()
+    batch = synth.synthetic_batch(7, 1, 3)
+    props = testing.make_proposals(batch, "predcls", "cpu")
+    pairs = [torch.tensor([[0, 1], [1, 0]])]
+    with pytest.raises(RuntimeError, match="HIP device"):
+        m(props, pairs, None, None, roi_features=torch.from_numpy(batch["roi_features"]),
+          roi_depth_features=torch.from_numpy(batch["roi_depth_features"]))
+    with pytest.raises(NotImplementedError):
+        m.train()(props, pairs, None, None)
+
+
+def test_beta_loss_weights_from_reference_counts():
+    import os
+    from conftest import GOLDEN_DIR
+    counts = np.loadtxt(os.path.join(GOLDEN_DIR, "pred_counts.txt"))
+    w = predictor.class_balanced_weights(counts, 51)
+    assert abs(float(w.sum()) - 51) < 1e-3 and abs(float(w[0]) - 0.14453256) < 1e-6 and abs(float(w[50]) - 28.964382) < 1e-3
+    cfg = testing.make_config(1, 8)
+    cfg.GLOBAL_SETTING.BETA_LOSS = True
+    with pytest.raises(ValueError):
+        predictor.VETOPredictor(cfg, 512)
+    cfg.GLOBAL_SETTING.REL_COUNTS = counts.tolist()
+    m = predictor.VETOPredictor(cfg, 512)
+    assert torch.allclose(m.criterion_loss_rel.weight, w)
+
+
+def test_boxlist_convert_uses_the_plus_one_convention():
+    b = BoxList(torch.tensor([[10.0, 20.0, 29.0, 59.0]]), (800, 600), "xyxy")
+    b.add_field("labels", torch.tensor([3]))
+    w = b.convert("xywh")
+    assert w.bbox.tolist() == [[10.0, 20.0, 20.0, 40.0]] and w.get_field("labels").item() == 3
+    assert w.convert("xyxy").bbox.tolist() == b.bbox.tolist() and len(b) == 1
+    with pytest.raises(ValueError):
+        b.convert("cxcywh")
+
+
+def test_meet_tables():
+    for (ds, split), sizes in meet_tables.GROUP_SIZES.items():
+        assert sum(sizes) == meet_tables.NUM_CLASSES[ds][1] - 1
+        idx = meet_tables.incre_idx_list(sizes)
+        assert len(idx) == meet_tables.NUM_CLASSES[ds][1] and idx[0] == 0 and idx[-1] == len(sizes)
+    with pytest.raises(ValueError):
+        meet_tables.group_sizes("VG", "nope")
+
+
+def test_synthetic_generators_are_bit_stable():
+    # the golden fixtures depend on these streams: a changed digest means every golden must be regenerated
+    sd = synth.predictor_state_dict(0, layers=1)
+    h = hashlib.sha256()
+    for k in sorted(sd):
+        h.update(k.encode())
+        h.update(np.ascontiguousarray(sd[k]).tobytes())
+    b = synth.synthetic_batch(7, 1, 4)
+    for k in ("boxes", "labels", "roi_features", "predict_logits"):
+        h.update(np.ascontiguousarray(b[k]).tobytes())
+    assert h.hexdigest() == "5fffec42c9ef2181a42859be88e635aa1c1ff2db4c7890dd2ddc2d1cba19197e"

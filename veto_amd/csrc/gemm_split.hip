@@ -78,11 +78,14 @@ __global__ __launch_bounds__(128 * WM, 2) void gemm_split_kernel(GemmArgs g) {
     const int c = w + NWAVES * i;                 // chunk id, wave-uniform
     const __bf16* base = g.a_hi;
     int row = 0;
-    if (c < CA) { base = g.a_hi; row = tile_m * BM + c * 16; }
-    else if (c < 2 * CA) { base = g.a_lo; row = tile_m * BM + (c - CA) * 16; }
-    else if (c < 2 * CA + CW) { base = g.w_hi; row = tile_n * BN + (c - 2 * CA) * 16; }
-    else if (c < NCHUNK) { base = g.w_lo; row = tile_n * BN + (c - 2 * CA - CW) * 16; }
-    src[i] = (const char*)(base + (size_t)(row + rr) * K + qs * 8);
+    long ld = K;
+    if (c < CA) { base = g.a_hi; row = tile_m * BM + c * 16 + rr; ld = g.lda; }
+    else if (c < 2 * CA) { base = g.a_lo; row = tile_m * BM + (c - CA) * 16 + rr; ld = g.lda; }
+    else if (c < 2 * CA + CW) { base = g.w_hi; row = tile_n * BN + (c - 2 * CA) * 16 + rr; }
+    else if (c < NCHUNK) { base = g.w_lo; row = tile_n * BN + (c - 2 * CA - CW) * 16 + rr; }
+    // strided A rows (lda != K: the CLS rows of the token matrix) are not padded: clamp to the last row
+    if (c < 2 * CA && g.lda != K && row >= g.M) row = g.M - 1;
+    src[i] = (const char*)(base + (size_t)row * ld + qs * 8);
   }
 
   // FAST mode never reads the lo planes; their chunks are still moved (the mode exists to report
@@ -233,6 +236,7 @@ int gemm_rows_padded(int m) { return (m + 255) / 256 * 256; }
 
 hipError_t launch_gemm_split(GemmArgs g, int epi, int precision, hipStream_t s) {
   if (g.N % BN != 0 || g.K % BK != 0 || g.M <= 0) return hipErrorInvalidValue;
+  if (g.lda == 0) g.lda = g.K;
   if (tile_wm() == 4) return precision == 0 ? launch_terms<3, 4>(g, epi, s) : launch_terms<1, 4>(g, epi, s);
   return precision == 0 ? launch_terms<3, 2>(g, epi, s) : launch_terms<1, 2>(g, epi, s);
 }

@@ -17,8 +17,9 @@ struct GemmArgs {
   __bf16* c_hi;        // EPI_GELU_SPLIT
   __bf16* c_lo;
   int M, N, K;
+  long lda;            // A row stride in elements (0 = K; rows must then be padded to 256)
   long ldr;
-  int ldc;
+  long ldc;
   int tiles_m, tiles_n;  // filled by launch_gemm_split
 };
 

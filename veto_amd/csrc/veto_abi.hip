@@ -203,9 +203,10 @@ Workspace carve(char* base, int n_obj, int n_pair, int chunk) {
 
 int run_gemm(veto_handle_t h, hipStream_t s, const char* name, const __bf16* a_hi, const __bf16* a_lo,
              const SplitW& w, const float* bias, const float* resid, long ldr, float* c, __bf16* c_hi,
-             __bf16* c_lo, int ldc, int M, int N, int K, int epi) {
+             __bf16* c_lo, long ldc, int M, int N, int K, int epi, long lda = 0, int w_row0 = 0) {
   GemmArgs g{};
-  g.a_hi = a_hi; g.a_lo = a_lo; g.w_hi = w.hi; g.w_lo = w.lo;
+  g.a_hi = a_hi; g.a_lo = a_lo; g.lda = lda;
+  g.w_hi = w.hi + (size_t)w_row0 * K; g.w_lo = w.lo + (size_t)w_row0 * K;
   g.bias = bias; g.resid = resid; g.c = c; g.c_hi = c_hi; g.c_lo = c_lo;
   g.M = M; g.N = N; g.K = K; g.ldr = ldr; g.ldc = ldc;
   const double flops = 2.0 * M * (double)N * K;
@@ -435,9 +436,20 @@ int veto_forward(veto_handle_t h, void* stream, const veto_inputs_t* in, void* w
     for (int l = 0; l < L; ++l) {
       const LayerW& w = h->layers[l];
       const bool last = (l == L - 1);
-      int rc = run_gemm(h, s, "gemm_qkv", ws.a_hi, ws.a_lo, w.qkv, nullptr, nullptr, 0, qkv, nullptr, nullptr, 3 * kDim,
-                        M, 3 * kDim, kDim, EPI_F32);
-      if (rc) return rc;
+      int rc;
+      if (!last) {
+        rc = run_gemm(h, s, "gemm_qkv", ws.a_hi, ws.a_lo, w.qkv, nullptr, nullptr, 0, qkv, nullptr, nullptr, 3 * kDim,
+                      M, 3 * kDim, kDim, EPI_F32);
+        if (rc) return rc;
+      } else {
+        // last layer: keys/values for all 19 tokens, the query for the CLS row of each pair only
+        rc = run_gemm(h, s, "gemm_kv_last", ws.a_hi, ws.a_lo, w.qkv, nullptr, nullptr, 0, qkv + kDim, nullptr, nullptr,
+                      3 * kDim, M, 2 * kDim, kDim, EPI_F32, 0, kDim);
+        if (rc) return rc;
+        rc = run_gemm(h, s, "gemm_q_cls", ws.a_hi, ws.a_lo, w.qkv, nullptr, nullptr, 0, qkv, nullptr, nullptr,
+                      (long)kTokens * 3 * kDim, np, kDim, kDim, EPI_F32, (long)kTokens * kDim, 0);
+        if (rc) return rc;
+      }
       {
         AttnArgs a{};
         a.qkv = qkv; a.n_pair = np; a.heads = H; a.cls_only = last ? 1 : 0;
