@@ -82,7 +82,6 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a, int dh, int 
       acc += pj * vv;
     }
     const size_t row = a.cls_only ? (size_t)pair : (size_t)pair * kTokens + i;
-    const size_t off = row * kDim + head * dh + d4 * 4;
     bf16x4 hi, lo;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -91,8 +90,9 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a, int dh, int 
       hi[c] = h;
       lo[c] = l;
     }
-    *(bf16x4*)(a.o_hi + off) = hi;
-    *(bf16x4*)(a.o_lo + off) = lo;
+    __bf16* dst = a.o + row * (2 * kDim) + split_index(head * dh + d4 * 4);
+    *(bf16x4*)dst = hi;
+    *(bf16x4*)(dst + 32) = lo;
   }
 }
 
@@ -283,9 +283,9 @@ __global__ __launch_bounds__(128) void attention_mfma_kernel(AttnArgs a) {
       lo[4 + t] = ll;
     }
     const size_t row = a.cls_only ? (size_t)pair : (size_t)pair * kTokens + i;
-    const size_t off = row * kDim + head * DH + c * 8;
-    *(bf16x8*)(a.o_hi + off) = hi;
-    *(bf16x8*)(a.o_lo + off) = lo;
+    __bf16* dst = a.o + row * (2 * kDim) + split_index(head * DH + c * 8);
+    *(bf16x8*)dst = hi;
+    *(bf16x8*)(dst + 32) = lo;
   }
 }
 

@@ -24,6 +24,14 @@ typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
+// "Split row" operand format of every GEMM operand (activations and weights): a logical row of K
+// fp32 values is stored as 2K bf16, in blocks of 32 k's: [hi(k0..k0+31) | lo(k0..k0+31)], i.e. 64 B of
+// hi followed by 64 B of lo.  One k-step (BK = 32) of one row is therefore ONE full 128-byte line,
+// and a row is contiguous (2304 B for K = 576).  Measured on MI355X (tools/micro/ldsdma_bench.hip):
+// 8 waves/CU pulling L2-resident data through global_load_lds sustain 64 GB/s per CU with 128-byte
+// row pieces vs 49 GB/s with the 64-byte pieces of separate hi/lo planes.
+__host__ __device__ __forceinline__ int split_index(int k) { return ((k >> 5) << 6) + (k & 31); }  // hi; lo = +32
+
 // x ~= hi + lo with hi = bf16(x), lo = bf16(x - hi): 16 significand bits in two bf16.
 __device__ __forceinline__ void split_bf16(float x, __bf16& hi, __bf16& lo) {
   hi = (__bf16)x;

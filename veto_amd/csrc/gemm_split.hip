@@ -4,48 +4,49 @@
 //
 //   C[M,N] = A[M,K] . W[N,K]^T        (nn.Linear layout: both operands K-contiguous)
 //
-// A and W are each held as two bf16 planes (hi, lo) with x ~= hi + lo (16 significand bits).
+// A and W are stored as split rows (common.h): per row and per 32 k's, 64 B of bf16 hi then 64 B of
+// bf16 lo, x ~= hi + lo (16 significand bits).
 // PRECISE (NTERMS=3): A_hi.W_hi + A_lo.W_hi + A_hi.W_lo, fp32 accumulate  -> ~2^-16 relative,
 // which is what the 1e-3 logit bar needs (plain bf16 misses it by 14x).
 // FAST (NTERMS=1): A_hi.W_hi only.
 //
+// This file: the homogeneous kernel (every wave loads and computes) and the dispatcher.
+// gemm_split_ps.hip: persistent + loader-wave variant of the same tile.  Both give bit-identical C.
+//
 // Tile 256(M) x 192(N) x 32(K), 8 waves (4 along M x 2 along N), v_mfma_f32_16x16x32_bf16.
 // The MFMA is issued "swapped" (weights as the A operand, activations as the B operand) so that
 // each lane ends up with 4 CONSECUTIVE output columns of one row -> 16-byte epilogue accesses.
-// LDS: two stages of {A_hi, A_lo, W_hi, W_lo} = 2 x 56 KiB, filled by global_load_lds_dwordx4
-// (no VGPR staging).  Each 16-row x 64-byte chunk is one wave-instruction; the XOR swizzle of the
-// 16-byte k-chunks is applied on the per-lane SOURCE address and again on the ds_read_b128 address
-// (the LDS destination of an LDS-DMA is lane-linear), which makes the fragment reads conflict-free.
+// LDS: two stages of {A rows, W rows} x 128 B = 2 x 56 KiB, filled by global_load_lds_dwordx4 (no
+// VGPR staging): one wave-instruction moves 8 rows x 128 B (8 full cache lines).  Inside a row the
+// eight 16-byte slots (4 hi k-chunks, 4 lo k-chunks) are XOR-swizzled with (row>>1)&7 -- on the
+// per-lane SOURCE address for the DMA (its LDS destination is lane-linear) and again on the
+// ds_read_b128 address -- which makes every fragment read bank-conflict free.
 #include "common.h"
 #include "kernels.h"
 
 #include <cstdlib>
+#include <cstring>
 #include <type_traits>
 
 namespace veto {
 
 namespace {
 
-constexpr int BN = 192, BK = 32;
+constexpr int BM = 256, BN = 192, BK = 32;
+constexpr int NWAVES = 8;
+constexpr int kStageBytes = (BM + BN) * 128;     // 57344
+constexpr int kWOff = BM * 128;                  // W rows follow the A rows inside a stage
+constexpr int NCHUNK = (BM + BN) / 8;            // 56 chunks of 8 rows x 128 B
+constexpr int CA = BM / 8;
+constexpr int CPW = NCHUNK / NWAVES;             // 7 per wave and stage
 
 __device__ __forceinline__ void glds16(const char* src, char* lds_dst) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                    (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
 }
 
-// WM = waves along M.  WM=4: 256x192 tile, 8 waves, 112 KiB LDS, one workgroup per CU.
-// WM=2: 128x192 tile, 4 waves, 80 KiB LDS, TWO workgroups per CU whose barriers/epilogues are
-// independent, so one workgroup's epilogue and stage waits hide under the other's MFMA stream.
-template <int NTERMS, int EPI, int WM>
-__global__ __launch_bounds__(128 * WM, 2) void gemm_split_kernel(GemmArgs g) {
-  constexpr int BM = 64 * WM;
-  constexpr int NWAVES = 2 * WM;
-  constexpr int kStageBytes = (2 * BM + 2 * BN) * BK * 2;
-  constexpr int kAHi = 0, kALo = BM * 64, kWHi = 2 * BM * 64, kWLo = 2 * BM * 64 + BN * 64;
-  constexpr int CA = BM / 16, CW = BN / 16;          // 16-row chunks per plane
-  constexpr int NCHUNK = 2 * CA + 2 * CW;
-  constexpr int CPW = NCHUNK / NWAVES;  // chunks per wave
-  static_assert(CPW * NWAVES == NCHUNK, "every wave moves the same number of chunks");
+template <int NTERMS, int EPI>
+__global__ __launch_bounds__(64 * NWAVES, 2) void gemm_split_kernel(GemmArgs g) {
   __shared__ __attribute__((aligned(16))) char smem[2 * kStageBytes];
 
   const int tid = threadIdx.x;
@@ -63,47 +64,36 @@ __global__ __launch_bounds__(128 * WM, 2) void gemm_split_kernel(GemmArgs g) {
   const int tile_m = logical / g.tiles_n;
 
   const int K = g.K;
-  // ---- per-lane source pointers of this wave's 16-row chunks (7 per stage) -------------------
-#ifdef VETO_EXPERIMENT_FULL_LINES  // timing experiment only (wrong results): 8 rows x 128 B per chunk
-  const int rr = lane >> 3;
-  const int qs = lane & 7;
-#else
-  const int rr = lane >> 2;                       // row inside the 16-row chunk
-  const int fs = (4 - (rr >> 2)) & 3;             // swizzle key of that row
-  const int qs = (lane & 3) ^ fs;                 // source k-chunk that lands in LDS slot lane&3
-#endif
+  // ---- per-lane source pointers of this wave's 8-row chunks (7 per stage) ----------------------
+  const int rr = lane >> 3;                       // row inside the chunk
   const char* src[CPW];
 #pragma unroll
   for (int i = 0; i < CPW; ++i) {
-    const int c = w + NWAVES * i;                 // chunk id, wave-uniform
-    const __bf16* base = g.a_hi;
-    int row = 0;
-    long ld = K;
-    if (c < CA) { base = g.a_hi; row = tile_m * BM + c * 16 + rr; ld = g.lda; }
-    else if (c < 2 * CA) { base = g.a_lo; row = tile_m * BM + (c - CA) * 16 + rr; ld = g.lda; }
-    else if (c < 2 * CA + CW) { base = g.w_hi; row = tile_n * BN + (c - 2 * CA) * 16 + rr; }
-    else if (c < NCHUNK) { base = g.w_lo; row = tile_n * BN + (c - 2 * CA - CW) * 16 + rr; }
-    // strided A rows (lda != K: the CLS rows of the token matrix) are not padded: clamp to the last row
-    if (c < 2 * CA && g.lda != K && row >= g.M) row = g.M - 1;
-    src[i] = (const char*)(base + (size_t)row * ld + qs * 8);
+    const int c = w + NWAVES * i;                 // chunk id, wave-uniform; CA is a multiple of NWAVES
+    const int r16 = ((c & 1) << 3) + rr;          // row inside its 16-row MFMA tile
+    const int slot = (lane & 7) ^ ((r16 >> 1) & 7);  // source 16-byte slot that lands in LDS slot lane&7
+    const __bf16* base;
+    long ld;
+    int row;
+    if (c < CA) {
+      base = g.a; ld = g.lda; row = tile_m * BM + c * 8 + rr;
+      if (g.lda != 2 * K && row >= g.M) row = g.M - 1;  // strided (unpadded) A rows: clamp
+    } else {
+      base = g.w; ld = 2 * K; row = tile_n * BN + (c - CA) * 8 + rr;
+    }
+    src[i] = (const char*)(base + (size_t)row * ld) + slot * 16;
   }
-
-  // FAST mode never reads the lo planes; their chunks are still moved (the mode exists to report
-  // the single-pass error, not to be tuned).
-  auto lo_only_chunk = [&](int) { return false; };
   auto load_stage = [&](int stage, int kt) {
 #pragma unroll
-    for (int i = 0; i < CPW; ++i) {
-      if (lo_only_chunk(i)) continue;
-      glds16(src[i] + (size_t)kt * (BK * 2), smem + stage * kStageBytes + (w + NWAVES * i) * 1024);
-    }
+    for (int i = 0; i < CPW; ++i)
+      glds16(src[i] + (size_t)kt * 128, smem + stage * kStageBytes + (w + NWAVES * i) * 1024);
   };
 
-  // ---- fragment read offsets ------------------------------------------------------------------
+  // ---- fragment read offsets: row fr of a 16-row tile, hi k-chunk fq; lo = same ^ 64 -------------
   const int fr = lane & 15, fq = lane >> 4;
-  const int frag_off = fr * 64 + ((fq ^ ((4 - (fr >> 2)) & 3)) << 4);
-  const int a_off = (wm * 64) * 64 + frag_off;    // activation rows of this wave (4 tiles of 16)
-  const int w_off = (wn * 96) * 64 + frag_off;    // weight rows of this wave (6 tiles of 16)
+  const int frag_off = fr * 128 + ((fq ^ ((fr >> 1) & 7)) << 4);
+  const int a_off = (wm * 64) * 128 + frag_off;           // activation rows of this wave (4 tiles of 16)
+  const int w_off = kWOff + (wn * 96) * 128 + frag_off;   // weight rows of this wave (6 tiles of 16)
 
   f32x4 acc[6][4];
 #pragma unroll
@@ -115,7 +105,7 @@ __global__ __launch_bounds__(128 * WM, 2) void gemm_split_kernel(GemmArgs g) {
   bf16x8 ah[4], al[4], wh[6], wl[6];
 
   // One k-step.  Software pipeline inside the step: while the 12 MFMAs of weight tile n run, the
-  // fragments of tile n+1 are read from LDS and (in the first GL groups) two LDS-DMA chunks of the
+  // fragments of tile n+1 are read from LDS and (in the first 4 groups) two LDS-DMA chunks of the
   // NEXT stage are issued, so the vector-memory issue cost hides under the matrix pipe instead of
   // preceding it.  sched_group_barrier pins that interleave in the emitted code.
   auto k_step = [&](int kt, auto load_next) {
@@ -126,23 +116,23 @@ __global__ __launch_bounds__(128 * WM, 2) void gemm_split_kernel(GemmArgs g) {
     char* nst = smem + ((kt + 1) & 1) * kStageBytes;
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
-      ah[m] = *(const bf16x8*)(st + kAHi + a_off + m * 1024);
-      if (NTERMS == 3) al[m] = *(const bf16x8*)(st + kALo + a_off + m * 1024);
+      ah[m] = *(const bf16x8*)(st + a_off + m * 2048);
+      if (NTERMS == 3) al[m] = *(const bf16x8*)(st + ((a_off + m * 2048) ^ 64));
     }
-    wh[0] = *(const bf16x8*)(st + kWHi + w_off);
-    if (NTERMS == 3) wl[0] = *(const bf16x8*)(st + kWLo + w_off);
+    wh[0] = *(const bf16x8*)(st + w_off);
+    if (NTERMS == 3) wl[0] = *(const bf16x8*)(st + (w_off ^ 64));
     constexpr int GL = (CPW + 1) / 2;  // groups that carry global loads (2 chunks each)
 #pragma unroll
     for (int n = 0; n < 6; ++n) {
       if (n < 5) {
-        wh[n + 1] = *(const bf16x8*)(st + kWHi + w_off + (n + 1) * 1024);
-        if (NTERMS == 3) wl[n + 1] = *(const bf16x8*)(st + kWLo + w_off + (n + 1) * 1024);
+        wh[n + 1] = *(const bf16x8*)(st + w_off + (n + 1) * 2048);
+        if (NTERMS == 3) wl[n + 1] = *(const bf16x8*)(st + ((w_off + (n + 1) * 2048) ^ 64));
       }
       if (LOAD && n < GL) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           const int i = 2 * n + j;
-          if (i < CPW && !lo_only_chunk(i)) glds16(src[i] + (size_t)(kt + 1) * (BK * 2), nst + (w + NWAVES * i) * 1024);
+          if (i < CPW) glds16(src[i] + (size_t)(kt + 1) * 128, nst + (w + NWAVES * i) * 1024);
         }
       }
 #pragma unroll
@@ -159,7 +149,8 @@ __global__ __launch_bounds__(128 * WM, 2) void gemm_split_kernel(GemmArgs g) {
 #pragma unroll
       for (int n = 0; n < 6; ++n) {
         if (n < 5) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-        if (LOAD && n < GL) __builtin_amdgcn_sched_group_barrier(0x10, 2, 0);
+        if (LOAD && n < GL - 1) __builtin_amdgcn_sched_group_barrier(0x10, 2, 0);
+        if (LOAD && n == GL - 1) __builtin_amdgcn_sched_group_barrier(0x10, 1, 0);  // CPW = 7: last group has one
         __builtin_amdgcn_sched_group_barrier(0x8, 12, 0);
       }
     }
@@ -178,14 +169,8 @@ __global__ __launch_bounds__(128 * WM, 2) void gemm_split_kernel(GemmArgs g) {
     for (int n = 0; n < 6; ++n) {
       const int col = tile_n * BN + wn * 96 + n * 16 + (lane >> 4) * 4;
       f32x4 v = acc[n][m];
-      if (g.bias) {
-        const f32x4 b = *(const f32x4*)(g.bias + col);
-        v += b;
-      }
-      if (EPI == EPI_RESID) {
-        const f32x4 r = *(const f32x4*)(g.resid + (size_t)row * g.ldr + col);
-        v += r;
-      }
+      if (g.bias) v += *(const f32x4*)(g.bias + col);
+      if (EPI == EPI_RESID) v += *(const f32x4*)(g.resid + (size_t)row * g.ldr + col);
       if (EPI == EPI_GELU_SPLIT) {
         bf16x4 hi, lo;
 #pragma unroll
@@ -195,8 +180,9 @@ __global__ __launch_bounds__(128 * WM, 2) void gemm_split_kernel(GemmArgs g) {
           hi[e] = h;
           lo[e] = l;
         }
-        *(bf16x4*)(g.c_hi + (size_t)row * g.ldc + col) = hi;
-        *(bf16x4*)(g.c_lo + (size_t)row * g.ldc + col) = lo;
+        __bf16* dst = g.c_split + (size_t)row * g.ldc + split_index(col);
+        *(bf16x4*)dst = hi;
+        *(bf16x4*)(dst + 32) = lo;
       } else {
         *(f32x4*)(g.c + (size_t)row * g.ldc + col) = v;
       }
@@ -204,41 +190,35 @@ __global__ __launch_bounds__(128 * WM, 2) void gemm_split_kernel(GemmArgs g) {
   }
 }
 
-template <int NTERMS, int WM>
+template <int NTERMS>
 hipError_t launch_terms(GemmArgs g, int epi, hipStream_t s) {
-  constexpr int BM = 64 * WM;
-  g.tiles_m = (g.M + BM - 1) / BM;
-  g.tiles_n = g.N / BN;
-  dim3 grid(g.tiles_m * g.tiles_n), block(128 * WM);
+  dim3 grid(g.tiles_m * g.tiles_n), block(64 * NWAVES);
   switch (epi) {
-    case EPI_F32: VETO_LAUNCH((gemm_split_kernel<NTERMS, EPI_F32, WM>), grid, block, 0, s, g); break;
-    case EPI_RESID: VETO_LAUNCH((gemm_split_kernel<NTERMS, EPI_RESID, WM>), grid, block, 0, s, g); break;
-    case EPI_GELU_SPLIT: VETO_LAUNCH((gemm_split_kernel<NTERMS, EPI_GELU_SPLIT, WM>), grid, block, 0, s, g); break;
+    case EPI_F32: VETO_LAUNCH((gemm_split_kernel<NTERMS, EPI_F32>), grid, block, 0, s, g); break;
+    case EPI_RESID: VETO_LAUNCH((gemm_split_kernel<NTERMS, EPI_RESID>), grid, block, 0, s, g); break;
+    case EPI_GELU_SPLIT: VETO_LAUNCH((gemm_split_kernel<NTERMS, EPI_GELU_SPLIT>), grid, block, 0, s, g); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
 }
 
-int g_tile_wm = 0;  // 0 = not yet read from the environment
-
-int tile_wm() {
-  if (g_tile_wm == 0) {
-    const char* e = getenv("VETO_GEMM_BM");  // tuning knob: 256 or 128 (default)
-    g_tile_wm = (e && atoi(e) == 256) ? 4 : 2;
-  }
-  return g_tile_wm;
-}
-
 }  // namespace
 
-// Row padding every A-operand buffer must have (the larger tile; valid for both).
-int gemm_rows_padded(int m) { return (m + 255) / 256 * 256; }
+// Row padding every contiguous A-operand buffer must have.
+int gemm_rows_padded(int m) { return (m + BM - 1) / BM * BM; }
 
 hipError_t launch_gemm_split(GemmArgs g, int epi, int precision, hipStream_t s) {
   if (g.N % BN != 0 || g.K % BK != 0 || g.M <= 0) return hipErrorInvalidValue;
-  if (g.lda == 0) g.lda = g.K;
-  if (tile_wm() == 4) return precision == 0 ? launch_terms<3, 4>(g, epi, s) : launch_terms<1, 4>(g, epi, s);
-  return precision == 0 ? launch_terms<3, 2>(g, epi, s) : launch_terms<1, 2>(g, epi, s);
+  if (g.lda == 0) g.lda = 2 * (long)g.K;
+  g.tiles_m = (g.M + BM - 1) / BM;
+  g.tiles_n = g.N / BN;
+  // VETO_GEMM_VARIANT (A/B knob): "ps" persistent + loader waves (default), "plain" homogeneous waves.
+  static const bool plain = [] {
+    const char* e = getenv("VETO_GEMM_VARIANT");
+    return e && !strcmp(e, "plain");
+  }();
+  if (!plain) return launch_gemm_split_ps(g, epi, precision, s);
+  return precision == 0 ? launch_terms<3>(g, epi, s) : launch_terms<1>(g, epi, s);
 }
 
 }  // namespace veto

@@ -6,31 +6,32 @@ namespace veto {
 
 enum Epi { EPI_F32 = 0, EPI_RESID = 1, EPI_GELU_SPLIT = 2 };
 
+// C[M,N] = A[M,K] . W[N,K]^T with A and W in the split-row format (common.h): rows of 2K bf16.
 struct GemmArgs {
-  const __bf16* a_hi;  // [rows padded to 256, K]
-  const __bf16* a_lo;
-  const __bf16* w_hi;  // [N, K]
-  const __bf16* w_lo;
+  const __bf16* a;     // row r at a + r*lda; rows padded to a multiple of 256 when lda == 2K
+  const __bf16* w;     // [N, 2K]
   const float* bias;   // [N] or nullptr
   const float* resid;  // EPI_RESID: row r at resid + r*ldr
   float* c;            // EPI_F32 / EPI_RESID: row r at c + r*ldc
-  __bf16* c_hi;        // EPI_GELU_SPLIT
-  __bf16* c_lo;
+  __bf16* c_split;     // EPI_GELU_SPLIT: split-row output, row r at c_split + r*ldc (ldc = 2N)
   int M, N, K;
-  long lda;            // A row stride in elements (0 = K; rows must then be padded to 256)
+  long lda;            // A row stride in bf16 elements (0 = 2K)
   long ldr;
   long ldc;
-  int tiles_m, tiles_n;  // filled by launch_gemm_split
+  int tiles_m, tiles_n;  // filled by the launcher
 };
 
 int gemm_rows_padded(int m);
+// VETO_GEMM_VARIANT: "ps" (persistent + loader waves) or "plain" (homogeneous waves); same results.
 hipError_t launch_gemm_split(GemmArgs g, int epi, int precision, hipStream_t s);
+hipError_t launch_gemm_split_ps(GemmArgs g, int epi, int precision, hipStream_t s);
 
 // ---- weight preparation (once per weight upload) ---------------------------------------------
-hipError_t launch_split_planes(const float* src, __bf16* hi, __bf16* lo, size_t n, hipStream_t s);
-// W_cat [1152, 2048] hi/lo + bias_cat [1152] from proj_d [512,2048], proj_v [64,2048]
+// src [rows, K] fp32 -> dst [rows, 2K] split rows
+hipError_t launch_split_rows(const float* src, __bf16* dst, size_t rows, int K, hipStream_t s);
+// W_cat [1152, 2*2048] split rows + bias_cat [1152] from proj_d [512,2048], proj_v [64,2048]
 hipError_t launch_build_patch_weight(const float* wd, const float* bd, const float* wv, const float* bv,
-                                     __bf16* hi, __bf16* lo, float* bias_cat, hipStream_t s);
+                                     __bf16* dst, float* bias_cat, hipStream_t s);
 // dst[k][half*576 + j] = src[j][half*kin + k]   (src is [576, 2*kin])
 hipError_t launch_transpose_pair_proj(const float* src, float* dst, int kin, hipStream_t s);
 // dst[k][c] = src[c][k]  (src [n_out, 576])
@@ -53,9 +54,8 @@ struct ObjPrepArgs {
   int n_obj;
 };
 hipError_t launch_obj_prep(const ObjPrepArgs& a, hipStream_t s);
-// rgb/depth [n_obj, 256, 8, 8] -> patch rows [n_obj*16, 2048] hi/lo (depth features first)
-hipError_t launch_patchify(const float* depth, const float* rgb, __bf16* hi, __bf16* lo, int n_obj,
-                           hipStream_t s);
+// rgb/depth [n_obj, 256, 8, 8] -> patch rows [n_obj*16, 2*2048] split rows (depth features first)
+hipError_t launch_patchify(const float* depth, const float* rgb, __bf16* dst, int n_obj, hipStream_t s);
 
 // ---- pair stage --------------------------------------------------------------------------------
 hipError_t launch_pair_indices(const int64_t* rel_pairs, const int32_t* img_obj_off,
@@ -71,18 +71,18 @@ struct AssembleArgs {
   const float* ln_w; const float* ln_b;  // layer-0 attention PreNorm
   const int32_t* subj; const int32_t* obj;  // this chunk's pairs
   float* x;                 // [n_pair*19, 576]
-  __bf16* a_hi; __bf16* a_lo;  // LN(x) planes
+  __bf16* a;                // LN(x), split rows [n_pair*19, 2*576]
   int n_pair;
 };
 hipError_t launch_assemble(const AssembleArgs& a, hipStream_t s);
 
-// LayerNorm(eps 1e-5) of `rows` rows (row r at x + r*ldx) -> hi/lo planes [rows, 576]
-hipError_t launch_layernorm(const float* x, long ldx, const float* w, const float* b, __bf16* hi,
-                            __bf16* lo, int rows, hipStream_t s);
+// LayerNorm(eps 1e-5) of `rows` rows (row r at x + r*ldx) -> split rows [rows, 2*576]
+hipError_t launch_layernorm(const float* x, long ldx, const float* w, const float* b, __bf16* dst, int rows,
+                            hipStream_t s);
 
 struct AttnArgs {
   const float* qkv;        // [n_pair*19, 1728]
-  __bf16* o_hi; __bf16* o_lo;  // [rows, 576]; rows = n_pair*19, or n_pair when cls_only
+  __bf16* o;               // split rows [rows, 2*576]; rows = n_pair*19, or n_pair when cls_only
   int n_pair, heads, cls_only;
 };
 hipError_t launch_attention(const AttnArgs& a, hipStream_t s);

@@ -22,15 +22,18 @@ namespace {
 // ------------------------------------------------------------------------------------------------
 // weight preparation
 // ------------------------------------------------------------------------------------------------
-__global__ void split_planes_kernel(const float* __restrict__ src, __bf16* __restrict__ hi,
-                                    __bf16* __restrict__ lo, size_t n) {
+// fp32 [rows, K] -> split rows [rows, 2K] (common.h)
+__global__ void split_rows_kernel(const float* __restrict__ src, __bf16* __restrict__ dst, size_t n, int K) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   for (; i < n; i += stride) {
+    const size_t row = i / K;
+    const int k = (int)(i % K);
     __bf16 h, l;
     split_bf16(src[i], h, l);
-    hi[i] = h;
-    lo[i] = l;
+    __bf16* d = dst + row * (2 * (size_t)K) + split_index(k);
+    d[0] = h;
+    d[32] = l;
   }
 }
 
@@ -41,8 +44,7 @@ __global__ void split_planes_kernel(const float* __restrict__ src, __bf16* __res
 // NB the crossed naming of the reference: proj_d (512 wide) acts on DEPTH, proj_v (64 wide) on RGB.
 __global__ void build_patch_weight_kernel(const float* __restrict__ wd, const float* __restrict__ bd,
                                           const float* __restrict__ wv, const float* __restrict__ bv,
-                                          __bf16* __restrict__ hi, __bf16* __restrict__ lo,
-                                          float* __restrict__ bias_cat) {
+                                          __bf16* __restrict__ dst, float* __restrict__ bias_cat) {
   const int j = blockIdx.x;  // 0..1151
   const int half = j / kDim, jj = j % kDim;
   for (int kk = threadIdx.x; kk < 2048; kk += blockDim.x) {
@@ -52,8 +54,9 @@ __global__ void build_patch_weight_kernel(const float* __restrict__ wd, const fl
     if (jj >= 512 && mod == 1) v = wv[(size_t)(jj - 512) * 2048 + pp * 512 + half * 256 + c];
     __bf16 h, l;
     split_bf16(v, h, l);
-    hi[(size_t)j * 2048 + kk] = h;
-    lo[(size_t)j * 2048 + kk] = l;
+    __bf16* d = dst + (size_t)j * 4096 + split_index(kk);
+    d[0] = h;
+    d[32] = l;
   }
   if (threadIdx.x == 0) bias_cat[j] = half == 0 ? (jj < 512 ? bd[jj] : bv[jj - 512]) : 0.f;
 }
@@ -141,7 +144,7 @@ __global__ __launch_bounds__(256) void obj_prep_kernel(ObjPrepArgs a) {
 // 'b c (h p1) (w p2) -> b (h w) (p1 p2 c)', p = 2, 8x8 maps, one thread per channel.
 __global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ depth,
                                                        const float* __restrict__ rgb,
-                                                       __bf16* __restrict__ hi, __bf16* __restrict__ lo) {
+                                                       __bf16* __restrict__ dst) {
   const int n = blockIdx.x, mod = blockIdx.y, c = threadIdx.x;
   const float* in = (mod == 0 ? depth : rgb) + ((size_t)n * 256 + c) * 64;
   float v[64];
@@ -158,8 +161,9 @@ __global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__
       const int col = mod * 1024 + ((y & 1) * 2 + (x & 1)) * 256 + c;
       __bf16 h, l;
       split_bf16(v[y * 8 + x], h, l);
-      hi[(size_t)row * 2048 + col] = h;
-      lo[(size_t)row * 2048 + col] = l;
+      __bf16* d = dst + (size_t)row * 4096 + split_index(col);
+      d[0] = h;
+      d[32] = l;
     }
 }
 
@@ -204,8 +208,7 @@ struct RowRegs { float v[10]; };
 __device__ __forceinline__ int row_col(int lane, int i) { return i < 4 ? 2 * (lane + 64 * i) : 512 + 2 * lane; }
 
 __device__ __forceinline__ void row_layernorm_store(const RowRegs& r, int lane, const float* __restrict__ w,
-                                                    const float* __restrict__ b, __bf16* __restrict__ hi,
-                                                    __bf16* __restrict__ lo) {
+                                                    const float* __restrict__ b, __bf16* __restrict__ dst) {
   const bool tail = lane < 32;
   float s = 0.f;
 #pragma unroll
@@ -226,8 +229,9 @@ __device__ __forceinline__ void row_layernorm_store(const RowRegs& r, int lane, 
     __bf16 h0, l0, h1, l1;
     split_bf16(y0, h0, l0);
     split_bf16(y1, h1, l1);
-    *(bf16x2*)(hi + c) = bf16x2{h0, h1};
-    *(bf16x2*)(lo + c) = bf16x2{l0, l1};
+    __bf16* d = dst + split_index(c);  // c is even: the pair stays inside one 32-k block
+    *(bf16x2*)d = bf16x2{h0, h1};
+    *(bf16x2*)(d + 32) = bf16x2{l0, l1};
   }
 }
 
@@ -267,15 +271,14 @@ __global__ __launch_bounds__(256) void assemble_kernel(AssembleArgs a) {
       *(float2*)(a.x + ((size_t)p * kTokens + t) * kDim + c) = v;
     }
     const size_t row = (size_t)p * kTokens + t;
-    row_layernorm_store(r, lane, a.ln_w, a.ln_b, a.a_hi + row * kDim, a.a_lo + row * kDim);
+    row_layernorm_store(r, lane, a.ln_w, a.ln_b, a.a + row * (2 * kDim));
   }
 }
 
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, long ldx,
                                                         const float* __restrict__ w,
                                                         const float* __restrict__ b,
-                                                        __bf16* __restrict__ hi, __bf16* __restrict__ lo,
-                                                        int rows) {
+                                                        __bf16* __restrict__ dst, int rows) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
   const int lane = threadIdx.x & 63;
@@ -288,7 +291,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     r.v[2 * i] = v.x;
     r.v[2 * i + 1] = v.y;
   }
-  row_layernorm_store(r, lane, w, b, hi + (size_t)row * kDim, lo + (size_t)row * kDim);
+  row_layernorm_store(r, lane, w, b, dst + (size_t)row * (2 * kDim));
 }
 
 // logits[p][c] = cls[p] . W[c] + b[c]; weights pre-transposed to [576][n_out]; 4 pairs per block.
@@ -319,15 +322,17 @@ __global__ __launch_bounds__(128) void head_kernel(const float* __restrict__ cls
 
 }  // namespace
 
-hipError_t launch_split_planes(const float* src, __bf16* hi, __bf16* lo, size_t n, hipStream_t s) {
+hipError_t launch_split_rows(const float* src, __bf16* dst, size_t rows, int K, hipStream_t s) {
+  if (K % 32 != 0) return hipErrorInvalidValue;
+  const size_t n = rows * (size_t)K;
   const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
-  VETO_LAUNCH(split_planes_kernel, dim3(blocks), dim3(256), 0, s, src, hi, lo, n);
+  VETO_LAUNCH(split_rows_kernel, dim3(blocks), dim3(256), 0, s, src, dst, n, K);
   return hipGetLastError();
 }
 
 hipError_t launch_build_patch_weight(const float* wd, const float* bd, const float* wv, const float* bv,
-                                     __bf16* hi, __bf16* lo, float* bias_cat, hipStream_t s) {
-  VETO_LAUNCH(build_patch_weight_kernel, dim3(2 * kDim), dim3(256), 0, s, wd, bd, wv, bv, hi, lo, bias_cat);
+                                     __bf16* dst, float* bias_cat, hipStream_t s) {
+  VETO_LAUNCH(build_patch_weight_kernel, dim3(2 * kDim), dim3(256), 0, s, wd, bd, wv, bv, dst, bias_cat);
   return hipGetLastError();
 }
 
@@ -347,9 +352,8 @@ hipError_t launch_obj_prep(const ObjPrepArgs& a, hipStream_t s) {
   return hipGetLastError();
 }
 
-hipError_t launch_patchify(const float* depth, const float* rgb, __bf16* hi, __bf16* lo, int n_obj,
-                           hipStream_t s) {
-  VETO_LAUNCH(patchify_kernel, dim3(n_obj, 2), dim3(256), 0, s, depth, rgb, hi, lo);
+hipError_t launch_patchify(const float* depth, const float* rgb, __bf16* dst, int n_obj, hipStream_t s) {
+  VETO_LAUNCH(patchify_kernel, dim3(n_obj, 2), dim3(256), 0, s, depth, rgb, dst);
   return hipGetLastError();
 }
 
@@ -372,9 +376,9 @@ hipError_t launch_assemble(const AssembleArgs& a, hipStream_t s) {
   return hipGetLastError();
 }
 
-hipError_t launch_layernorm(const float* x, long ldx, const float* w, const float* b, __bf16* hi,
-                            __bf16* lo, int rows, hipStream_t s) {
-  VETO_LAUNCH(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, ldx, w, b, hi, lo, rows);
+hipError_t launch_layernorm(const float* x, long ldx, const float* w, const float* b, __bf16* dst, int rows,
+                            hipStream_t s) {
+  VETO_LAUNCH(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, ldx, w, b, dst, rows);
   return hipGetLastError();
 }
 

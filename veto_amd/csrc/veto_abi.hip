@@ -42,14 +42,11 @@ struct Param {
   bool loaded = false;
 };
 
-struct SplitW {
-  __bf16* hi = nullptr;
-  __bf16* lo = nullptr;
-};
+typedef __bf16* SplitW;  // [N, 2K] split rows (common.h)
 
 struct LayerW {
   const float *ln1_w, *ln1_b, *ln2_w, *ln2_b, *out_b, *fc1_b, *fc2_b;
-  SplitW qkv, out, fc1, fc2;
+  SplitW qkv = nullptr, out = nullptr, fc1 = nullptr, fc2 = nullptr;
 };
 
 struct ProfRec {
@@ -72,7 +69,7 @@ struct veto_handle_s {
   char* derived = nullptr;   // split planes, transposes, folded tables
   bool dirty = true;
   std::vector<LayerW> layers;
-  SplitW patch_w;
+  SplitW patch_w = nullptr;
   float* patch_bias = nullptr;
   float* loc_wt = nullptr;
   float* cls_wt = nullptr;
@@ -142,14 +139,14 @@ int finalize_weights(veto_handle_t h, hipStream_t s) {
   const int L = h->cfg.layers;
   for (int l = 0; l < L; ++l) {
     LayerW& w = h->layers[l];
-    HIP_TRY(launch_split_planes(h->p(lname(l, "0.fn.to_qkv.weight")), w.qkv.hi, w.qkv.lo, (size_t)3 * kDim * kDim, s));
-    HIP_TRY(launch_split_planes(h->p(lname(l, "0.fn.to_out.0.weight")), w.out.hi, w.out.lo, (size_t)kDim * kDim, s));
-    HIP_TRY(launch_split_planes(h->p(lname(l, "1.fn.net.0.weight")), w.fc1.hi, w.fc1.lo, (size_t)2 * kDim * kDim, s));
-    HIP_TRY(launch_split_planes(h->p(lname(l, "1.fn.net.3.weight")), w.fc2.hi, w.fc2.lo, (size_t)2 * kDim * kDim, s));
+    HIP_TRY(launch_split_rows(h->p(lname(l, "0.fn.to_qkv.weight")), w.qkv, 3 * kDim, kDim, s));
+    HIP_TRY(launch_split_rows(h->p(lname(l, "0.fn.to_out.0.weight")), w.out, kDim, kDim, s));
+    HIP_TRY(launch_split_rows(h->p(lname(l, "1.fn.net.0.weight")), w.fc1, 2 * kDim, kDim, s));
+    HIP_TRY(launch_split_rows(h->p(lname(l, "1.fn.net.3.weight")), w.fc2, kDim, 2 * kDim, s));
   }
   const std::string pe = std::string(kT) + "patch_embed.";
   HIP_TRY(launch_build_patch_weight(h->p(pe + "proj_d.weight"), h->p(pe + "proj_d.bias"), h->p(pe + "proj_v.weight"),
-                                    h->p(pe + "proj_v.bias"), h->patch_w.hi, h->patch_w.lo, h->patch_bias, s));
+                                    h->p(pe + "proj_v.bias"), h->patch_w, h->patch_bias, s));
   HIP_TRY(launch_transpose_pair_proj(h->p("location_projection.0.weight"), h->loc_wt, kPosDim, s));
   HIP_TRY(launch_transpose_pair_proj(h->p("class_projection.0.weight"), h->cls_wt, h->cfg.embed_dim, s));
   HIP_TRY(launch_transpose_head(h->p("rel_out.weight"), h->head_wt, h->cfg.num_out, s));
@@ -160,13 +157,13 @@ int finalize_weights(veto_handle_t h, hipStream_t s) {
 struct Workspace {
   int32_t *subj, *obj;
   float* lc;
-  __bf16 *pa_hi, *pa_lo;
+  __bf16* pa;       // patch rows, split [prow, 2*2048]
   float* patch_tab;
   float* x;
-  __bf16 *a_hi, *a_lo;
-  char* big;
+  __bf16* a;        // LN(x) / attention output, split [mpad, 2*576]
+  char* big;        // qkv fp32 [mpad,1728]; later the MLP hidden, split [mpad, 2*1152]
   float* xc;
-  __bf16 *ac_hi, *ac_lo, *hc_hi, *hc_lo;
+  __bf16 *ac, *hc;  // CLS-compact operands, split [cpad, 2*576] / [cpad, 2*1152]
   size_t total;
 };
 
@@ -185,29 +182,26 @@ Workspace carve(char* base, int n_obj, int n_pair, int chunk) {
   w.subj = (int32_t*)take((size_t)n_pair * 4);
   w.obj = (int32_t*)take((size_t)n_pair * 4);
   w.lc = (float*)take((size_t)n_obj * 2 * 2 * kDim * 4);
-  w.pa_hi = (__bf16*)take(prow * 2048 * 2);
-  w.pa_lo = (__bf16*)take(prow * 2048 * 2);
+  w.pa = (__bf16*)take(prow * 2 * 2048 * 2);
   w.patch_tab = (float*)take((size_t)n_obj * 16 * 2 * kDim * 4);
   w.x = (float*)take(mpad * kDim * 4);
-  w.a_hi = (__bf16*)take(mpad * kDim * 2);
-  w.a_lo = (__bf16*)take(mpad * kDim * 2);
-  w.big = take(mpad * 3 * kDim * 4);  // qkv fp32 [mpad,1728]; later the MLP hidden hi/lo [mpad,1152] x2
+  w.a = (__bf16*)take(mpad * 2 * kDim * 2);
+  w.big = take(mpad * 3 * kDim * 4);
   w.xc = (float*)take(cpad * kDim * 4);
-  w.ac_hi = (__bf16*)take(cpad * kDim * 2);
-  w.ac_lo = (__bf16*)take(cpad * kDim * 2);
-  w.hc_hi = (__bf16*)take(cpad * 2 * kDim * 2);
-  w.hc_lo = (__bf16*)take(cpad * 2 * kDim * 2);
+  w.ac = (__bf16*)take(cpad * 2 * kDim * 2);
+  w.hc = (__bf16*)take(cpad * 4 * kDim * 2);
   w.total = off;
   return w;
 }
 
-int run_gemm(veto_handle_t h, hipStream_t s, const char* name, const __bf16* a_hi, const __bf16* a_lo,
-             const SplitW& w, const float* bias, const float* resid, long ldr, float* c, __bf16* c_hi,
-             __bf16* c_lo, long ldc, int M, int N, int K, int epi, long lda = 0, int w_row0 = 0) {
+// lda / ldc of split operands are in bf16 elements (2K / 2N for contiguous rows).
+int run_gemm(veto_handle_t h, hipStream_t s, const char* name, const __bf16* a, SplitW w, const float* bias,
+             const float* resid, long ldr, float* c, __bf16* c_split, long ldc, int M, int N, int K, int epi,
+             long lda = 0, int w_row0 = 0) {
   GemmArgs g{};
-  g.a_hi = a_hi; g.a_lo = a_lo; g.lda = lda;
-  g.w_hi = w.hi + (size_t)w_row0 * K; g.w_lo = w.lo + (size_t)w_row0 * K;
-  g.bias = bias; g.resid = resid; g.c = c; g.c_hi = c_hi; g.c_lo = c_lo;
+  g.a = a; g.lda = lda;
+  g.w = w + (size_t)w_row0 * 2 * K;
+  g.bias = bias; g.resid = resid; g.c = c; g.c_split = c_split;
   g.M = M; g.N = N; g.K = K; g.ldr = ldr; g.ldc = ldc;
   const double flops = 2.0 * M * (double)N * K;
   const double bytes = 4.0 * ((double)M * K + (double)N * K) + (double)M * N * (epi == EPI_RESID ? 8.0 : 4.0);
@@ -288,12 +282,12 @@ int veto_create(const veto_config_t* cfg, veto_handle_t* out) {
   auto dtake = [&](size_t bytes) { size_t o = doff; doff += align_up(bytes, 256); return o; };
   std::vector<size_t> lo_(L * 8);
   for (int l = 0; l < L; ++l) {
-    lo_[l * 8 + 0] = dtake((size_t)3 * kDim * kDim * 2); lo_[l * 8 + 1] = dtake((size_t)3 * kDim * kDim * 2);
-    lo_[l * 8 + 2] = dtake((size_t)kDim * kDim * 2);     lo_[l * 8 + 3] = dtake((size_t)kDim * kDim * 2);
-    lo_[l * 8 + 4] = dtake((size_t)2 * kDim * kDim * 2); lo_[l * 8 + 5] = dtake((size_t)2 * kDim * kDim * 2);
-    lo_[l * 8 + 6] = dtake((size_t)2 * kDim * kDim * 2); lo_[l * 8 + 7] = dtake((size_t)2 * kDim * kDim * 2);
+    lo_[l * 8 + 0] = dtake((size_t)3 * kDim * kDim * 4);
+    lo_[l * 8 + 2] = dtake((size_t)kDim * kDim * 4);
+    lo_[l * 8 + 4] = dtake((size_t)2 * kDim * kDim * 4);
+    lo_[l * 8 + 6] = dtake((size_t)2 * kDim * kDim * 4);
   }
-  const size_t o_pw_hi = dtake((size_t)2 * kDim * 2048 * 2), o_pw_lo = dtake((size_t)2 * kDim * 2048 * 2);
+  const size_t o_pw = dtake((size_t)2 * kDim * 2048 * 4);
   const size_t o_pb = dtake((size_t)2 * kDim * 4);
   const size_t o_loc = dtake((size_t)kPosDim * 2 * kDim * 4);
   const size_t o_cls = dtake((size_t)E * 2 * kDim * 4);
@@ -304,17 +298,17 @@ int veto_create(const veto_config_t* cfg, veto_handle_t* out) {
   for (int l = 0; l < L; ++l) {
     LayerW& w = h->layers[l];
     char* d = h->derived;
-    w.qkv = {(__bf16*)(d + lo_[l * 8 + 0]), (__bf16*)(d + lo_[l * 8 + 1])};
-    w.out = {(__bf16*)(d + lo_[l * 8 + 2]), (__bf16*)(d + lo_[l * 8 + 3])};
-    w.fc1 = {(__bf16*)(d + lo_[l * 8 + 4]), (__bf16*)(d + lo_[l * 8 + 5])};
-    w.fc2 = {(__bf16*)(d + lo_[l * 8 + 6]), (__bf16*)(d + lo_[l * 8 + 7])};
+    w.qkv = (__bf16*)(d + lo_[l * 8 + 0]);
+    w.out = (__bf16*)(d + lo_[l * 8 + 2]);
+    w.fc1 = (__bf16*)(d + lo_[l * 8 + 4]);
+    w.fc2 = (__bf16*)(d + lo_[l * 8 + 6]);
     w.ln1_w = h->p(lname(l, "0.norm.weight")); w.ln1_b = h->p(lname(l, "0.norm.bias"));
     w.ln2_w = h->p(lname(l, "1.norm.weight")); w.ln2_b = h->p(lname(l, "1.norm.bias"));
     w.out_b = h->p(lname(l, "0.fn.to_out.0.bias"));
     w.fc1_b = h->p(lname(l, "1.fn.net.0.bias"));
     w.fc2_b = h->p(lname(l, "1.fn.net.3.bias"));
   }
-  h->patch_w = {(__bf16*)(h->derived + o_pw_hi), (__bf16*)(h->derived + o_pw_lo)};
+  h->patch_w = (__bf16*)(h->derived + o_pw);
   h->patch_bias = (float*)(h->derived + o_pb);
   h->loc_wt = (float*)(h->derived + o_loc);
   h->cls_wt = (float*)(h->derived + o_cls);
@@ -407,11 +401,11 @@ int veto_forward(veto_handle_t h, void* stream, const veto_inputs_t* in, void* w
   }
   {
     ProfScope ps(h, s, "patchify", 0, (double)n_obj * 2 * 256 * 64 * (4 + 4));
-    HIP_TRY(launch_patchify(in->roi_depth, in->roi_rgb, ws.pa_hi, ws.pa_lo, n_obj, s));
+    HIP_TRY(launch_patchify(in->roi_depth, in->roi_rgb, ws.pa, n_obj, s));
   }
   {
-    int rc = run_gemm(h, s, "gemm_patch", ws.pa_hi, ws.pa_lo, h->patch_w, h->patch_bias, nullptr, 0, ws.patch_tab,
-                      nullptr, nullptr, 2 * kDim, n_obj * 16, 2 * kDim, 2048, EPI_F32);
+    int rc = run_gemm(h, s, "gemm_patch", ws.pa, h->patch_w, h->patch_bias, nullptr, 0, ws.patch_tab, nullptr, 2 * kDim,
+                      n_obj * 16, 2 * kDim, 2048, EPI_F32);
     if (rc) return rc;
   }
 
@@ -420,14 +414,13 @@ int veto_forward(veto_handle_t h, void* stream, const veto_inputs_t* in, void* w
     const int np = (n_pair - c0 < chunk) ? n_pair - c0 : chunk;
     const int M = np * kTokens;
     float* qkv = (float*)ws.big;
-    __bf16* h_hi = (__bf16*)ws.big;
-    __bf16* h_lo = h_hi + (size_t)gemm_rows_padded(chunk * kTokens) * 2 * kDim;
+    __bf16* hid = (__bf16*)ws.big;  // MLP hidden, split rows [M, 2*1152] (qkv is dead by then)
     {
       AssembleArgs a{};
       a.patch_tab = ws.patch_tab; a.lc = ws.lc; a.cls_token = h->p(T + "cls_token");
       a.pos_embedding = h->p(T + "pos_embedding");
       a.ln_w = h->layers[0].ln1_w; a.ln_b = h->layers[0].ln1_b;
-      a.subj = ws.subj + c0; a.obj = ws.obj + c0; a.x = ws.x; a.a_hi = ws.a_hi; a.a_lo = ws.a_lo; a.n_pair = np;
+      a.subj = ws.subj + c0; a.obj = ws.obj + c0; a.x = ws.x; a.a = ws.a; a.n_pair = np;
       ProfScope ps(h, s, "assemble_tokens", 0, (double)M * kDim * (4 + 4) + (double)np * 18 * 2 * kDim * 4);
       HIP_TRY(launch_assemble(a, s));
     }
@@ -438,62 +431,58 @@ int veto_forward(veto_handle_t h, void* stream, const veto_inputs_t* in, void* w
       const bool last = (l == L - 1);
       int rc;
       if (!last) {
-        rc = run_gemm(h, s, "gemm_qkv", ws.a_hi, ws.a_lo, w.qkv, nullptr, nullptr, 0, qkv, nullptr, nullptr, 3 * kDim,
-                      M, 3 * kDim, kDim, EPI_F32);
+        rc = run_gemm(h, s, "gemm_qkv", ws.a, w.qkv, nullptr, nullptr, 0, qkv, nullptr, 3 * kDim, M, 3 * kDim, kDim, EPI_F32);
         if (rc) return rc;
       } else {
         // last layer: keys/values for all 19 tokens, the query for the CLS row of each pair only
-        rc = run_gemm(h, s, "gemm_kv_last", ws.a_hi, ws.a_lo, w.qkv, nullptr, nullptr, 0, qkv + kDim, nullptr, nullptr,
-                      3 * kDim, M, 2 * kDim, kDim, EPI_F32, 0, kDim);
+        rc = run_gemm(h, s, "gemm_kv_last", ws.a, w.qkv, nullptr, nullptr, 0, qkv + kDim, nullptr, 3 * kDim, M, 2 * kDim,
+                      kDim, EPI_F32, 0, kDim);
         if (rc) return rc;
-        rc = run_gemm(h, s, "gemm_q_cls", ws.a_hi, ws.a_lo, w.qkv, nullptr, nullptr, 0, qkv, nullptr, nullptr,
-                      (long)kTokens * 3 * kDim, np, kDim, kDim, EPI_F32, (long)kTokens * kDim, 0);
+        rc = run_gemm(h, s, "gemm_q_cls", ws.a, w.qkv, nullptr, nullptr, 0, qkv, nullptr, (long)kTokens * 3 * kDim, np, kDim,
+                      kDim, EPI_F32, (long)kTokens * 2 * kDim, 0);
         if (rc) return rc;
       }
       {
         AttnArgs a{};
         a.qkv = qkv; a.n_pair = np; a.heads = H; a.cls_only = last ? 1 : 0;
-        a.o_hi = last ? ws.ac_hi : ws.a_hi;
-        a.o_lo = last ? ws.ac_lo : ws.a_lo;
+        a.o = last ? ws.ac : ws.a;
         const double nq = last ? 1 : kTokens;
         ProfScope ps(h, s, last ? "attention_cls" : "attention", 4.0 * np * nq * kTokens * kDim,
                      (double)M * 3 * kDim * 4 + (double)np * nq * kDim * 4);
         HIP_TRY(launch_attention(a, s));
       }
       if (!last) {
-        rc = run_gemm(h, s, "gemm_out", ws.a_hi, ws.a_lo, w.out, w.out_b, ws.x, kDim, ws.x, nullptr, nullptr, kDim, M,
-                      kDim, kDim, EPI_RESID);
+        rc = run_gemm(h, s, "gemm_out", ws.a, w.out, w.out_b, ws.x, kDim, ws.x, nullptr, kDim, M, kDim, kDim, EPI_RESID);
         if (rc) return rc;
         {
           ProfScope ps(h, s, "layernorm", 0, (double)M * kDim * 8);
-          HIP_TRY(launch_layernorm(ws.x, kDim, w.ln2_w, w.ln2_b, ws.a_hi, ws.a_lo, M, s));
+          HIP_TRY(launch_layernorm(ws.x, kDim, w.ln2_w, w.ln2_b, ws.a, M, s));
         }
-        rc = run_gemm(h, s, "gemm_fc1", ws.a_hi, ws.a_lo, w.fc1, w.fc1_b, nullptr, 0, nullptr, h_hi, h_lo, 2 * kDim, M,
-                      2 * kDim, kDim, EPI_GELU_SPLIT);
+        rc = run_gemm(h, s, "gemm_fc1", ws.a, w.fc1, w.fc1_b, nullptr, 0, nullptr, hid, 4 * kDim, M, 2 * kDim, kDim,
+                      EPI_GELU_SPLIT);
         if (rc) return rc;
-        rc = run_gemm(h, s, "gemm_fc2", h_hi, h_lo, w.fc2, w.fc2_b, ws.x, kDim, ws.x, nullptr, nullptr, kDim, M, kDim,
-                      2 * kDim, EPI_RESID);
+        rc = run_gemm(h, s, "gemm_fc2", hid, w.fc2, w.fc2_b, ws.x, kDim, ws.x, nullptr, kDim, M, kDim, 2 * kDim, EPI_RESID);
         if (rc) return rc;
         {
           const LayerW& nx = h->layers[l + 1];
           ProfScope ps(h, s, "layernorm", 0, (double)M * kDim * 8);
-          HIP_TRY(launch_layernorm(ws.x, kDim, nx.ln1_w, nx.ln1_b, ws.a_hi, ws.a_lo, M, s));
+          HIP_TRY(launch_layernorm(ws.x, kDim, nx.ln1_w, nx.ln1_b, ws.a, M, s));
         }
       } else {
         // Only x[:, 0] of the last layer is consumed (model_veto.py:23): out-proj, FeedForward and
         // both residuals run on the CLS row of each pair (row p*19 of x -> compact row p).
-        rc = run_gemm(h, s, "gemm_out_cls", ws.ac_hi, ws.ac_lo, w.out, w.out_b, ws.x, (long)kTokens * kDim, ws.xc,
-                      nullptr, nullptr, kDim, np, kDim, kDim, EPI_RESID);
+        rc = run_gemm(h, s, "gemm_out_cls", ws.ac, w.out, w.out_b, ws.x, (long)kTokens * kDim, ws.xc, nullptr, kDim, np,
+                      kDim, kDim, EPI_RESID);
         if (rc) return rc;
         {
           ProfScope ps(h, s, "layernorm_cls", 0, (double)np * kDim * 8);
-          HIP_TRY(launch_layernorm(ws.xc, kDim, w.ln2_w, w.ln2_b, ws.ac_hi, ws.ac_lo, np, s));
+          HIP_TRY(launch_layernorm(ws.xc, kDim, w.ln2_w, w.ln2_b, ws.ac, np, s));
         }
-        rc = run_gemm(h, s, "gemm_fc1_cls", ws.ac_hi, ws.ac_lo, w.fc1, w.fc1_b, nullptr, 0, nullptr, ws.hc_hi, ws.hc_lo,
-                      2 * kDim, np, 2 * kDim, kDim, EPI_GELU_SPLIT);
+        rc = run_gemm(h, s, "gemm_fc1_cls", ws.ac, w.fc1, w.fc1_b, nullptr, 0, nullptr, ws.hc, 4 * kDim, np, 2 * kDim, kDim,
+                      EPI_GELU_SPLIT);
         if (rc) return rc;
-        rc = run_gemm(h, s, "gemm_fc2_cls", ws.hc_hi, ws.hc_lo, w.fc2, w.fc2_b, ws.xc, kDim, ws.xc, nullptr, nullptr, kDim,
-                      np, kDim, 2 * kDim, EPI_RESID);
+        rc = run_gemm(h, s, "gemm_fc2_cls", ws.hc, w.fc2, w.fc2_b, ws.xc, kDim, ws.xc, nullptr, kDim, np, kDim, 2 * kDim,
+                      EPI_RESID);
         if (rc) return rc;
       }
     }
@@ -559,7 +548,7 @@ int veto_profile_reset(veto_handle_t h) {
 size_t veto_debug_gemm_workspace_bytes(int32_t m, int32_t n, int32_t k) {
   if (m <= 0 || n <= 0 || k <= 0) return 0;
   const size_t mp = (size_t)gemm_rows_padded(m);
-  return align_up(mp * k * 2, 256) * 2 + align_up((size_t)n * k * 2, 256) * 2;
+  return align_up(mp * k * 4, 256) + align_up((size_t)n * k * 4, 256);
 }
 
 int veto_debug_gemm(void* stream, const float* a, const float* w, const float* bias, float* c, int32_t m, int32_t n,
@@ -569,15 +558,13 @@ int veto_debug_gemm(void* stream, const float* a, const float* w, const float* b
   hipStream_t s = (hipStream_t)stream;
   const size_t mp = (size_t)gemm_rows_padded(m);
   char* base = (char*)workspace;
-  __bf16* a_hi = (__bf16*)base;
-  __bf16* a_lo = (__bf16*)(base + align_up(mp * k * 2, 256));
-  __bf16* w_hi = (__bf16*)(base + 2 * align_up(mp * k * 2, 256));
-  __bf16* w_lo = (__bf16*)((char*)w_hi + align_up((size_t)n * k * 2, 256));
-  HIP_TRY(hipMemsetAsync(base, 0, 2 * align_up(mp * k * 2, 256), s));
-  HIP_TRY(launch_split_planes(a, a_hi, a_lo, (size_t)m * k, s));
-  HIP_TRY(launch_split_planes(w, w_hi, w_lo, (size_t)n * k, s));
+  __bf16* a_s = (__bf16*)base;
+  __bf16* w_s = (__bf16*)(base + align_up(mp * k * 4, 256));
+  HIP_TRY(hipMemsetAsync(base, 0, align_up(mp * k * 4, 256), s));
+  HIP_TRY(launch_split_rows(a, a_s, (size_t)m, k, s));
+  HIP_TRY(launch_split_rows(w, w_s, (size_t)n, k, s));
   GemmArgs g{};
-  g.a_hi = a_hi; g.a_lo = a_lo; g.w_hi = w_hi; g.w_lo = w_lo; g.bias = bias; g.c = c;
+  g.a = a_s; g.w = w_s; g.bias = bias; g.c = c;
   g.M = m; g.N = n; g.K = k; g.ldc = n;
   hipError_t e = launch_gemm_split(g, EPI_F32, precision, s);
   if (e != hipSuccess) return fail(e == hipErrorInvalidValue ? VETO_ERR_INVALID : VETO_ERR_HIP,
