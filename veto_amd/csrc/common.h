@@ -44,8 +44,15 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+// Exact-erf GELU (nn.GELU default, model_veto.py:140).  erf through Abramowitz-Stegun 7.1.26
+// (|error| <= 1.5e-7, i.e. below the 2^-17 noise of the split-bf16 products around it) instead of
+// the ~30-instruction libm erff: the FeedForward epilogue applies it to 96 values per lane.
 __device__ __forceinline__ float gelu_erf(float x) {
-  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float t = __frcp_rn(1.0f + 0.3275911f * z);
+  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  const float erf_abs = 1.0f - poly * __expf(-z * z);
+  return 0.5f * x * (1.0f + copysignf(erf_abs, x));
 }
 
 }  // namespace veto

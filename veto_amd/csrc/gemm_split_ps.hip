@@ -9,10 +9,14 @@
 //    (tile, k-step) as ONE stream of stages: the loaders run into the next tile while the consumers
 //    are still in the epilogue, and the epilogue stores are fire-and-forget.
 //
-// Protocol (2 LDS stages, one s_barrier per stage s, all 12 waves take part):
-//   loader:   issue(0); for s: { vmcnt(0); barrier B_s; issue(s+1) }
-//   consumer:           for s: {           barrier B_s; compute(s); [epilogue at the end of a tile] }
-// B_s = "stage s has landed" (every loader waited for its own DMAs) + "buffer (s+1)&1 is free" (every
+// Protocol (one s_barrier per stage s, all 12 waves take part).  LDS holds THREE activation stages
+// and TWO weight stages (3 x 32 KiB + 2 x 24 KiB = 144 KiB): the activation panel streams from
+// HBM / Infinity Cache and gets two k-steps of flight time, the weights come from L2 and get one.
+//   loader:   A(0) W(0) A(1); for s: { vmcnt(8): all but A(s+1) landed; barrier B_s; W(s+1); A(s+2) }
+//   consumer:                 for s: {                                   barrier B_s; compute(s) }
+// (vmcnt counts in issue order: A(s) and W(s) are older than A(s+1), whose 8 chunks stay in flight
+// ACROSS the barrier -- the loader's issue time overlaps the flight of the previous stage instead of
+// adding to it.)  B_s = "A(s), W(s) have landed" + "the buffers stage s-1 used are free" (every
 // consumer finished stage s-1; its fragment reads were consumed by its own MFMAs before it arrived).
 //
 // Tile order: workgroup b lives on XCD b%8 (round-robin dispatch; speed only) and in round i takes
@@ -33,11 +37,13 @@ namespace {
 
 constexpr int BM = 256, BN = 192, BK = 32;
 constexpr int NCONS = 8, NLOAD = 4;
-constexpr int kStageBytes = (BM + BN) * 128;  // 57344
-constexpr int kWOff = BM * 128;
-constexpr int NCHUNK = (BM + BN) / 8;         // 56 chunks of 8 rows x 128 B per stage
-constexpr int CA = BM / 8;
-constexpr int CPL = NCHUNK / NLOAD;           // 14 per loader wave
+constexpr int kABytes = BM * 128;             // one A stage: 256 rows x 128 B = 32 KiB (3 of them)
+constexpr int kWBytes = BN * 128;             // one W stage: 192 rows x 128 B = 24 KiB (2 of them)
+constexpr int kLdsBytes = 3 * kABytes + 2 * kWBytes + 1024;  // 144 KiB + a dump area for prefetches
+constexpr int kDumpOff = 3 * kABytes + 2 * kWBytes;
+constexpr int kPrefSteps = BN * 4 / 128;      // 6: 128-byte lines per residual row of a tile
+constexpr int CPA = BM / 8 / NLOAD;           // 8 A chunks (8 rows x 128 B) per loader wave and stage
+constexpr int CPWL = BN / 8 / NLOAD;          // 6 W chunks
 
 __device__ __forceinline__ void glds16(const char* src, char* lds_dst) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
@@ -68,7 +74,7 @@ __device__ __forceinline__ void wg_barrier() {
 
 template <int NTERMS, int EPI>
 __global__ __launch_bounds__(64 * (NCONS + NLOAD), 3) void gemm_split_ps_kernel(GemmArgs g) {
-  __shared__ __attribute__((aligned(16))) char smem[2 * kStageBytes];
+  __shared__ __attribute__((aligned(16))) char smem[kLdsBytes];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -84,54 +90,104 @@ __global__ __launch_bounds__(64 * (NCONS + NLOAD), 3) void gemm_split_ps_kernel(
   while (tile_of(my_tiles) < ntiles) ++my_tiles;  // tile_of is increasing in `it`
   if (my_tiles == 0) return;
   const int nstages = my_tiles * nk;
+  // Phase stagger (speed only): equal tiles keep the persistent workgroups in lockstep, so all 256 CUs
+  // would reach their epilogue -- a chip-wide HBM burst of 50-100 MB with no MFMA work beside it -- at
+  // the same moment.  Starting the workgroups of an XCD in 4 phases spreads the bursts under the
+  // other phases' matrix work.
+  for (int i = g.stagger * ((b >> 3) & 3); i > 0; --i) __builtin_amdgcn_s_sleep(127);
 
   if (w >= NCONS) {
     // ------------------------------- loader wave ------------------------------------------------
     const int lw = (w - NCONS) & (NLOAD - 1);
     const int rr = lane >> 3;
-    const char* src[CPL];
-    auto setup = [&](int tile) {
-      const int tile_n = tile % g.tiles_n, tile_m = tile / g.tiles_n;
+    const char* srcA[CPA];
+    const char* srcW[CPWL];
+    auto src_of = [&](const __bf16* base, long ld, int row, int c) {
+      const int r16 = ((c & 1) << 3) + rr;
+      const int slot = (lane & 7) ^ ((r16 >> 1) & 7);
+      return (const char*)(base + (size_t)row * ld) + slot * 16;
+    };
+    auto setupA = [&](int tile) {
+      const int tile_m = tile / g.tiles_n;
 #pragma unroll
-      for (int i = 0; i < CPL; ++i) {
-        const int c = lw + NLOAD * i;  // CA is a multiple of NLOAD
-        const int r16 = ((c & 1) << 3) + rr;
-        const int slot = (lane & 7) ^ ((r16 >> 1) & 7);
-        const __bf16* base;
-        long ld;
-        int row;
-        if (c < CA) {
-          base = g.a; ld = g.lda; row = tile_m * BM + c * 8 + rr;
-          if (g.lda != 2 * K && row >= g.M) row = g.M - 1;  // strided (unpadded) A rows
-        } else {
-          base = g.w; ld = 2 * K; row = tile_n * BN + (c - CA) * 8 + rr;
-        }
-        src[i] = (const char*)(base + (size_t)row * ld) + slot * 16;
+      for (int i = 0; i < CPA; ++i) {
+        const int c = lw + NLOAD * i;
+        int row = tile_m * BM + c * 8 + rr;
+        if (g.lda != 2 * K && row >= g.M) row = g.M - 1;  // strided (unpadded) A rows
+        srcA[i] = src_of(g.a, g.lda, row, c);
       }
     };
-    auto issue = [&](int s, int kt) {
-      char* dst = smem + (s & 1) * kStageBytes + lw * 1024;
+    auto setupW = [&](int tile) {
+      const int tile_n = tile % g.tiles_n;
 #pragma unroll
-      for (int i = 0; i < CPL; ++i) glds16(src[i] + (size_t)kt * 128, dst + NLOAD * i * 1024);
+      for (int i = 0; i < CPWL; ++i) {
+        const int c = lw + NLOAD * i;
+        srcW[i] = src_of(g.w, 2 * K, tile_n * BN + c * 8 + rr, c);
+      }
+    };
+    // cursors of the next A stage / W stage to issue (the stream of stages crosses tile boundaries)
+    int itA = 0, ktA = 0, bufA = 0, itW = 0, ktW = 0, bufW = 0;
+    auto issueA = [&]() {
+      char* dst = smem + bufA * kABytes + lw * 1024;
+#pragma unroll
+      for (int i = 0; i < CPA; ++i) glds16(srcA[i] + (size_t)ktA * 128, dst + NLOAD * i * 1024);
+      bufA = bufA == 2 ? 0 : bufA + 1;
+      if (++ktA == nk) {
+        ktA = 0;
+        if (++itA < my_tiles) setupA(tile_of(itA));
+      }
+    };
+    auto issueW = [&]() {
+      char* dst = smem + 3 * kABytes + bufW * kWBytes + lw * 1024;
+#pragma unroll
+      for (int i = 0; i < CPWL; ++i) glds16(srcW[i] + (size_t)ktW * 128, dst + NLOAD * i * 1024);
+      bufW ^= 1;
+      if (++ktW == nk) {
+        ktW = 0;
+        if (++itW < my_tiles) setupW(tile_of(itW));
+      }
+    };
+    // EPI_RESID: the epilogue reads a 256 x 192 fp32 residual tile that nobody has touched since the
+    // previous kernel, i.e. from HBM, synchronously, on all CUs at once (46k cycles per tile against 7k
+    // for a store-only epilogue).  During the last 6 k-steps of a tile the loader waves touch one
+    // 128-byte line per lane of that tile (4-byte LDS-DMA into a dump area) so that it is L2 / MALL
+    // resident when the consumers ask for it.  Pure prefetch: results do not depend on it.
+    auto prefetch_resid = [&](int tile, int j) {
+      const int tile_n = tile % g.tiles_n, tile_m = tile / g.tiles_n;
+      int row = tile_m * BM + lw * 64 + lane;
+      if (row >= g.M) row = g.M - 1;
+      const float* p = g.resid + (size_t)row * g.ldr + tile_n * BN + j * 32;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)p,
+                                       (__attribute__((address_space(3))) void*)(smem + kDumpOff + lw * 256), 4, 0, 0);
     };
     unsigned long long tA = 0, tB = 0, tC = 0, tD = 0, t_begin = 0, a_vm = 0, a_bar = 0, a_iss = 0;
     (void)tA; (void)tB; (void)tC; (void)tD; (void)t_begin; (void)a_vm; (void)a_bar; (void)a_iss;
     STAMP(t_begin);
-    setup(tile_of(0));
-    issue(0, 0);
-    int it = 0, kt = 0;
+    setupA(tile_of(0));
+    setupW(tile_of(0));
+    issueA();                   // A(0)
+    issueW();                   // W(0)
+    if (nstages > 1) issueA();  // A(1)
+    bool pref_in_flight = false;  // a residual prefetch was the youngest request of the last iteration
+    int itC = 0, ktC = 0;         // (tile, k-step) the consumers work on after barrier B_s
     for (int s = 0; s < nstages; ++s) {
       STAMP(tA);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      // outstanding, oldest first: ..., A(s), W(s), A(s+1) [, prefetch]: everything but A(s+1)'s CPA
+      // chunks (and the prefetch, which gets another k-step) must be done
+      if (s + 1 >= nstages) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else if (pref_in_flight) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CPA + 1) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CPA) : "memory");
       STAMP(tB);
       wg_barrier();
       STAMP(tC);
-      if (++kt == nk) {
-        kt = 0;
-        ++it;
-        if (it < my_tiles) setup(tile_of(it));
+      if (s + 1 < nstages) issueW();  // W(s+1) -> the W buffer stage s-1 used
+      if (s + 2 < nstages) issueA();  // A(s+2) -> the A buffer stage s-1 used
+      pref_in_flight = false;
+      if (EPI == EPI_RESID && s + 2 < nstages && ktC >= nk - kPrefSteps) {
+        prefetch_resid(tile_of(itC), ktC - (nk - kPrefSteps));
+        pref_in_flight = true;
       }
-      if (s + 1 < nstages) issue(s + 1, kt);
+      if (++ktC == nk) { ktC = 0; ++itC; }
       STAMP(tD);
       ACC(a_vm, tB, tA); ACC(a_bar, tC, tB); ACC(a_iss, tD, tC);
     }
@@ -148,12 +204,12 @@ __global__ __launch_bounds__(64 * (NCONS + NLOAD), 3) void gemm_split_ps_kernel(
   const int fr = lane & 15, fq = lane >> 4;
   const int frag_off = fr * 128 + ((fq ^ ((fr >> 1) & 7)) << 4);
   const int a_off = (wm * 64) * 128 + frag_off;
-  const int w_off = kWOff + (wn * 96) * 128 + frag_off;
+  const int w_off = 3 * kABytes + (wn * 96) * 128 + frag_off;
 
   unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t_begin = 0, a_bar = 0, a_cmp = 0, a_epi = 0;
   (void)t0; (void)t1; (void)t2; (void)t3; (void)t_begin; (void)a_bar; (void)a_cmp; (void)a_epi;
   STAMP(t_begin);
-  int s = 0;
+  int s = 0, s3 = 0;  // stage counter and s % 3
   for (int it = 0; it < my_tiles; ++it) {
     const int tile = tile_of(it);
     const int tile_n = tile % g.tiles_n, tile_m = tile / g.tiles_n;
@@ -164,37 +220,53 @@ __global__ __launch_bounds__(64 * (NCONS + NLOAD), 3) void gemm_split_ps_kernel(
       for (int m = 0; m < 4; ++m) acc[n][m] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     bf16x8 ah[4], al[4], wh[6], wl[6];
-    for (int kt = 0; kt < nk; ++kt, ++s) {
+    for (int kt = 0; kt < nk; ++kt, ++s, s3 = s3 == 2 ? 0 : s3 + 1) {
       STAMP(t0);
       wg_barrier();
       STAMP(t1);
-      const char* st = smem + (s & 1) * kStageBytes;
+      const char* sa = smem + s3 * kABytes;
+      const char* sw = smem + (s & 1) * kWBytes;
+      // Fragment reads are issued in the order the MFMAs need them, two at a time, one group ahead of
+      // their use: the first MFMA waits for two LDS reads (not twelve), and all 12 waves of the
+      // workgroup hitting the LDS right after the barrier overlap with matrix work instead of
+      // preceding it.  NTERMS == 1 skips the lo fragments.
+      auto rdA = [&](int m) {
+        ah[m] = *(const bf16x8*)(sa + a_off + m * 2048);
+        if (NTERMS == 3) al[m] = *(const bf16x8*)(sa + ((a_off + m * 2048) ^ 64));
+      };
+      auto rdW = [&](int n) {
+        wh[n] = *(const bf16x8*)(sw + w_off + n * 2048);
+        if (NTERMS == 3) wl[n] = *(const bf16x8*)(sw + ((w_off + n * 2048) ^ 64));
+      };
+      auto mma = [&](int n, int m) {
+        if (NTERMS == 3) {
+          acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[n], ah[m], acc[n][m], 0, 0, 0);
+          acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[n], al[m], acc[n][m], 0, 0, 0);
+        }
+        acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[n], ah[m], acc[n][m], 0, 0, 0);
+      };
+      rdW(0);
+      rdA(0);
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
-        ah[m] = *(const bf16x8*)(st + a_off + m * 2048);
-        if (NTERMS == 3) al[m] = *(const bf16x8*)(st + ((a_off + m * 2048) ^ 64));
+        if (m < 3) rdA(m + 1); else rdW(1);
+        mma(0, m);
       }
-      wh[0] = *(const bf16x8*)(st + w_off);
-      if (NTERMS == 3) wl[0] = *(const bf16x8*)(st + (w_off ^ 64));
 #pragma unroll
-      for (int n = 0; n < 6; ++n) {
-        if (n < 5) {
-          wh[n + 1] = *(const bf16x8*)(st + w_off + (n + 1) * 2048);
-          if (NTERMS == 3) wl[n + 1] = *(const bf16x8*)(st + ((w_off + (n + 1) * 2048) ^ 64));
-        }
+      for (int n = 1; n < 6; ++n) {
+        if (n < 5) rdW(n + 1);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) mma(n, m);
+      }
+      if (NTERMS == 3) {  // pin the interleave: DS_READ 0x100, MFMA 0x8
+        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);   // W0 (hi, lo), A0 (hi, lo)
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
-          if (NTERMS == 3) {
-            acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[n], ah[m], acc[n][m], 0, 0, 0);
-            acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[n], al[m], acc[n][m], 0, 0, 0);
-          }
-          acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[n], ah[m], acc[n][m], 0, 0, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 2, 0); // A(m+1) or W1
+          __builtin_amdgcn_sched_group_barrier(0x8, 3, 0);   // tile (0, m)
         }
-      }
-      if (NTERMS == 3) {  // DS_READ 0x100, MFMA 0x8: fragments of tile n+1 under the MFMAs of tile n
-        __builtin_amdgcn_sched_group_barrier(0x100, 10, 0);
 #pragma unroll
-        for (int n = 0; n < 6; ++n) {
+        for (int n = 1; n < 6; ++n) {
           if (n < 5) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
           __builtin_amdgcn_sched_group_barrier(0x8, 12, 0);
         }
@@ -203,31 +275,50 @@ __global__ __launch_bounds__(64 * (NCONS + NLOAD), 3) void gemm_split_ps_kernel(
       ACC(a_bar, t1, t0); ACC(a_cmp, t2, t1);
     }
 
-    // epilogue: lane holds C[row lane&15 of m-tile][4 consecutive columns]; stores are not waited for
+    // epilogue: lane holds C[row lane&15 of m-tile][4 consecutive columns]; stores are not waited for.
+    // EPI_RESID: the residual reads of row group m+1 are issued BEFORE the stores of group m (vmcnt
+    // counts loads and stores in issue order, so a load issued after a store would have to wait for
+    // it; and c may alias resid, which stops the compiler from hoisting the loads by itself).
+    f32x4 bias_v[6];
+#pragma unroll
+    for (int n = 0; n < 6; ++n)
+      bias_v[n] = g.bias ? *(const f32x4*)(g.bias + tile_n * BN + wn * 96 + n * 16 + (lane >> 4) * 4)
+                         : f32x4{0.f, 0.f, 0.f, 0.f};
+    const int row0 = tile_m * BM + wm * 64 + (lane & 15);
+    const int col0 = tile_n * BN + wn * 96 + (lane >> 4) * 4;
+    f32x4 res[2][6];
+    auto load_res = [&](int m, f32x4 (&r)[6]) {
+      int row = row0 + m * 16;
+      if (row >= g.M) row = g.M - 1;  // clamp: the value is never stored
+#pragma unroll
+      for (int n = 0; n < 6; ++n) r[n] = *(const f32x4*)(g.resid + (size_t)row * g.ldr + col0 + n * 16);
+    };
+    if (EPI == EPI_RESID) load_res(0, res[0]);
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
-      const int row = tile_m * BM + wm * 64 + m * 16 + (lane & 15);
-      if (row >= g.M) continue;
+      if (EPI == EPI_RESID && m < 3) load_res(m + 1, res[(m + 1) & 1]);
+      const int row = row0 + m * 16;
+      if (row < g.M) {
 #pragma unroll
-      for (int n = 0; n < 6; ++n) {
-        const int col = tile_n * BN + wn * 96 + n * 16 + (lane >> 4) * 4;
-        f32x4 v = acc[n][m];
-        if (g.bias) v += *(const f32x4*)(g.bias + col);
-        if (EPI == EPI_RESID) v += *(const f32x4*)(g.resid + (size_t)row * g.ldr + col);
-        if (EPI == EPI_GELU_SPLIT) {
-          bf16x4 hi, lo;
+        for (int n = 0; n < 6; ++n) {
+          const int col = col0 + n * 16;
+          f32x4 v = acc[n][m] + bias_v[n];
+          if (EPI == EPI_RESID) v += res[m & 1][n];
+          if (EPI == EPI_GELU_SPLIT) {
+            bf16x4 hi, lo;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            __bf16 h, l;
-            split_bf16(gelu_erf(v[e]), h, l);
-            hi[e] = h;
-            lo[e] = l;
+            for (int e = 0; e < 4; ++e) {
+              __bf16 h, l;
+              split_bf16(gelu_erf(v[e]), h, l);
+              hi[e] = h;
+              lo[e] = l;
+            }
+            __bf16* dst = g.c_split + (size_t)row * g.ldc + split_index(col);
+            *(bf16x4*)dst = hi;
+            *(bf16x4*)(dst + 32) = lo;
+          } else {
+            *(f32x4*)(g.c + (size_t)row * g.ldc + col) = v;
           }
-          __bf16* dst = g.c_split + (size_t)row * g.ldc + split_index(col);
-          *(bf16x4*)dst = hi;
-          *(bf16x4*)(dst + 32) = lo;
-        } else {
-          *(f32x4*)(g.c + (size_t)row * g.ldc + col) = v;
         }
       }
     }
@@ -257,6 +348,8 @@ hipError_t launch_ps_terms(GemmArgs g, int epi, int nblocks, hipStream_t s) {
 
 // g.tiles_m / g.tiles_n / g.lda are already filled by launch_gemm_split.
 hipError_t launch_gemm_split_ps(GemmArgs g, int epi, int precision, hipStream_t s) {
+  static const int stagger = getenv("VETO_GEMM_STAGGER") ? atoi(getenv("VETO_GEMM_STAGGER")) : 0;
+  g.stagger = stagger;
   static int num_cu = 0;
   if (num_cu == 0) {
     int dev = 0;

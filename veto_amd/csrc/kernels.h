@@ -19,6 +19,7 @@ struct GemmArgs {
   long ldr;
   long ldc;
   int tiles_m, tiles_n;  // filled by the launcher
+  int stagger;           // persistent kernel: start-phase stagger in units of s_sleep(127) (speed only)
 };
 
 int gemm_rows_padded(int m);
