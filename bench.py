@@ -131,6 +131,13 @@ def main():
         dom = max(gemms, key=lambda k: gemms[k]["ms_per_step"])
         achieved = gemms[dom]["tflops"]
         f_ref = flops_per_pair(args.layers, args.heads)
+        traffic = None
+        try:  # PMC-derived HBM bytes per launch of the dominant kernel at THIS workload (profiles/r01_traffic.json)
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+            if dom in tj and (args.images, args.objs, args.layers, args.heads, args.precision) == (12, 36, 4, 8, "precise"):
+                traffic = tj[dom]["hbm_bytes_per_launch"]
+        except (OSError, ValueError, KeyError):
+            pass
         res = {
             "metric": "relation-pairs/sec (PredCls, 36 obj/img)", "value": value, "unit": "pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
@@ -143,7 +150,7 @@ def main():
                        "layers": args.layers, "heads": args.heads, "precision": args.precision,
                        "parallelism": "image-sharded x%d, RCCL all-gather of logits" % world if world > 1 else "single GPU"},
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": PEAK_BF16_TFLOPS,
-                         "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS, "traffic": None,
+                         "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic,
                          "note": "achieved = algorithmic 2*M*N*K of one launch / its mean hipEvent duration; the "
                                  "precise mode issues 3 bf16 MFMA passes per algorithmic FLOP"},
             "whole_path": {"ref_flops_per_pair": f_ref, "tflops_ref_equivalent": value * f_ref / 1e12,
