@@ -111,6 +111,33 @@ int veto_forward(veto_handle_t h, void* stream, const veto_inputs_t* in, void* w
 /* out: device [max(n*(n-1), 1), 2] int64, row-major (i, j), i != j; [[0,0]] when n <= 1. */
 int veto_enumerate_pairs(void* stream, int32_t n, int64_t* out);
 
+/* ---- relation post-processing ---------------------------------------
+ * The vanilla GT-box branch of PostProcessor.forward, pysgg/modeling/roi_heads/relation_head/
+ * inference.py:398-453: softmax of object and predicate logits, max over the foreground classes,
+ * triple score rel*obj_s*obj_o, descending sort per image (ties: lower original index first), and the
+ * pair indices / probabilities / labels emitted in that order. */
+typedef struct veto_post_args {
+  int32_t struct_size;            /* sizeof(veto_post_args_t) */
+  int32_t n_img, n_obj, n_pair;
+  int32_t n_rel_cls, n_obj_cls;   /* 51 / 151 (VG) */
+  int32_t max_pairs_per_image;    /* host-side maximum of the per-image pair counts; must be <= 4096 */
+  int32_t reserved0;
+  const float* rel_logits;        /* device [n_pair, n_rel_cls] */
+  const float* obj_logits;        /* device [n_obj, n_obj_cls]  (refine logits / predict_logits) */
+  const int64_t* rel_pairs;       /* device [n_pair, 2] image-local */
+  const int32_t* img_obj_offset;  /* device [n_img + 1] */
+  const int32_t* img_pair_offset; /* device [n_img + 1] */
+  float* obj_scores;              /* out device [n_obj]   -> BoxList field pred_scores */
+  int64_t* obj_pred;              /* out device [n_obj]   -> pred_labels */
+  float* rel_prob_sorted;         /* out device [n_pair, n_rel_cls] -> pred_rel_scores */
+  int64_t* rel_pairs_sorted;      /* out device [n_pair, 2]         -> rel_pair_idxs */
+  int64_t* rel_labels_sorted;     /* out device [n_pair]            -> pred_rel_labels */
+  float* triple_sorted;           /* optional out device [n_pair] (the sort keys) */
+} veto_post_args_t;
+
+size_t veto_postprocess_workspace_bytes(int32_t n_pair, int32_t n_rel_cls);
+int veto_postprocess(void* stream, const veto_post_args_t* args, void* workspace, size_t workspace_bytes);
+
 /* ---- measurement hooks (bench.py): per-kernel device time from hipEvents on `stream` ---------- */
 int veto_profile_enable(veto_handle_t h, int32_t on);
 /* Synchronises the recorded events; returns the number of distinct kernels. */

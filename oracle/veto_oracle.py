@@ -213,6 +213,33 @@ def forward(sd, cfg, batch, rel_pair_idxs=None, dtype=torch.float32, return_inte
     return logits, subj, obj
 
 
+def postprocess(rel_logits, obj_logits, rel_pair_idxs, num_objs, dtype=torch.float32):
+    """Vanilla GT-box branch of PostProcessor.forward, inference.py:398-453.
+    rel_logits [sum P, C], obj_logits [sum N, Co], rel_pair_idxs list of [P_i, 2] (image-local).
+    Returns one dict per image: pred_scores, pred_labels, rel_pair_idxs, pred_rel_scores,
+    pred_rel_labels, triple_scores (sorted, descending; exact ties keep the lower index first)."""
+    rel_logits, obj_logits = _t(rel_logits, dtype), _t(obj_logits, dtype)
+    out, o0, p0 = [], 0, 0
+    for pairs, n in zip(rel_pair_idxs, num_objs):
+        pairs = torch.as_tensor(np.asarray(pairs)).long()
+        P = pairs.shape[0]
+        obj_prob = torch.softmax(obj_logits[o0:o0 + n], -1)           # :405
+        obj_prob[:, 0] = 0                                            # :406
+        obj_scores, obj_pred = obj_prob[:, 1:].max(dim=1)             # :411
+        obj_pred = obj_pred + 1                                       # :412
+        rel_prob = torch.softmax(rel_logits[p0:p0 + P], -1)           # :440
+        rel_scores, rel_class = rel_prob[:, 1:].max(dim=1)            # :441
+        rel_class = rel_class + 1                                     # :442
+        triple = rel_scores * obj_scores[pairs[:, 0]] * obj_scores[pairs[:, 1]]   # :444
+        order = torch.sort(triple, descending=True, stable=True)[1]  # :445 (stable: defined tie order)
+        out.append({"pred_scores": obj_scores, "pred_labels": obj_pred, "rel_pair_idxs": pairs[order],
+                    "pred_rel_scores": rel_prob[order], "pred_rel_labels": rel_class[order],
+                    "triple_scores": triple[order]})
+        o0 += n
+        p0 += P
+    return out
+
+
 def meet_incre_idx_list(group_sizes):
     """SHA_GCL_extra/extra_function_utils.py:39-77 (first return value) for the contiguous
     splits of group_chosen_function.py:6-94: class c (1-based, frequency order) belongs to

@@ -18,7 +18,31 @@ def pytest_configure(config):
 
 
 def golden_names():
-    return sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith(".npz"))
+    """Predictor fixtures (the post_* files are PostProcessor fixtures, see post_golden_names)."""
+    return sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith(".npz") and not f.startswith("post_"))
+
+
+def post_golden_names():
+    return sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith(".npz") and f.startswith("post_"))
+
+
+def load_post_golden(name):
+    """Returns (fixture, rel_logits, obj_logits, pair list, num_objs) with the inputs regenerated."""
+    import torch
+    from oracle import veto_oracle as vo
+    from veto_amd import synth
+    g = dict(np.load(os.path.join(GOLDEN_DIR, name + ".npz")))
+    num_objs = [int(x) for x in g["num_objs"]]
+    pairs = [vo.enumerate_test_pairs(n) for n in num_objs]
+    n_obj, n_pair = sum(num_objs), sum(len(p) for p in pairs)
+    rel_logits = synth.normal(21, "post.rel_logits", (n_pair, 51), 0.0, 2.0)
+    if int(g["onehot"]):
+        lab = synth.integers(21, "post.labels", (n_obj,), 1, 151)
+        obj_logits = np.full((n_obj, 151), -1000.0, dtype=np.float32)
+        obj_logits[np.arange(n_obj), lab] = 1000.0
+    else:
+        obj_logits = synth.normal(21, "post.obj_logits", (n_obj, 151), 0.0, 3.0)
+    return g, rel_logits, obj_logits, pairs, num_objs
 
 
 def load_golden(name):

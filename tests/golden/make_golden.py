@@ -218,9 +218,39 @@ def run_case(P, cfg, BoxList, name, mode, layers, heads, num_objs, meet=False, d
     print("%-24s %s %s  |max|=%.3f  %d bytes" % (name, mode, out[key].shape, np.abs(out[key]).max(), sz))
 
 
+def run_postprocessor(cfg, BoxList, name, num_objs, onehot):
+    """The reference's own PostProcessor (inference.py:9-92,398-453) on portable-RNG logits."""
+    from pysgg.modeling.roi_heads.relation_head.inference import make_roi_relation_post_processor
+    cfg.MODEL.ROI_RELATION_HEAD.USE_GT_BOX = True
+    cfg.ENSEMBLE_LEARNING.ENABLED = False
+    cfg.ENSEMBLE_LEARNING.EXPERT_GROUP = False   # configs/VETO_final.yaml:154; inference.py:93 tests this flag alone
+    cfg.MODEL.ATTRIBUTE_ON = False
+    post = make_roi_relation_post_processor(cfg).eval()
+    n_obj, P_list = sum(num_objs), [max(n * (n - 1), 1) for n in num_objs]
+    rel_logits = torch.from_numpy(synth.normal(21, "post.rel_logits", (sum(P_list), 51), 0.0, 2.0))
+    if onehot:   # predcls: relation_head.py:109 overloads predict_logits with +-1000 one-hots
+        lab = torch.from_numpy(synth.integers(21, "post.labels", (n_obj,), 1, 151))
+        obj_logits = torch.full((n_obj, 151), -1000.0)
+        obj_logits[torch.arange(n_obj), lab] = 1000.0
+    else:
+        obj_logits = torch.from_numpy(synth.normal(21, "post.obj_logits", (n_obj, 151), 0.0, 3.0))
+    pairs = test_pairs(num_objs)
+    boxes = [BoxList(torch.zeros(n, 4), (800, 600), mode="xyxy") for n in num_objs]
+    with torch.no_grad():
+        res = post((list(rel_logits.split(P_list)), list(obj_logits.split(list(num_objs)))), pairs, boxes)
+    out = {"num_objs": np.array(num_objs), "onehot": int(onehot)}
+    for i, r in enumerate(res):
+        for f in ("pred_labels", "pred_scores", "rel_pair_idxs", "pred_rel_scores", "pred_rel_labels"):
+            out["%s_%d" % (f, i)] = r.get_field(f).numpy()
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print("%-24s postprocessor %s images, %d pairs" % (name, len(res), sum(P_list)))
+
+
 def main():
     torch.set_num_threads(8)
     P, cfg, BoxList = import_reference()
+    run_postprocessor(cfg, BoxList, "post_sgcls_ragged", [5, 1, 9], onehot=False)
+    run_postprocessor(cfg, BoxList, "post_predcls_n36", [36], onehot=True)
     run_case(P, cfg, BoxList, "predcls_n10_l6h6", "predcls", 6, 6, [10], train=True)
     run_case(P, cfg, BoxList, "predcls_n10_l4h8", "predcls", 4, 8, [10])
     run_case(P, cfg, BoxList, "predcls_n36_l6h6", "predcls", 6, 6, [36])

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import golden_names, load_golden
+from conftest import golden_names, load_golden, load_post_golden, post_golden_names
 
 pytestmark = pytest.mark.gpu
 
@@ -204,3 +204,73 @@ def test_cpu_tensors_fail_loudly():
     model.train()
     with pytest.raises(NotImplementedError):
         model(props, pairs, None, None)
+
+
+def _check_sorted_output(res, ref_scores_sorted, ref_pairs, ref_labels, ref_prob, tol=2e-6):
+    """Scores must match; the order may differ only where the reference's keys are within rounding."""
+    got_pairs, got_prob = res.get_field("rel_pair_idxs").cpu().numpy(), res.get_field("pred_rel_scores").cpu().numpy()
+    got_labels = res.get_field("pred_rel_labels").cpu().numpy()
+    assert got_pairs.shape == ref_pairs.shape
+    same = (got_pairs == ref_pairs).all(1)
+    if not same.all():   # a swap is legitimate only between (near-)equal sort keys
+        bad = np.nonzero(~same)[0]
+        assert np.abs(ref_scores_sorted[bad][:, None] - ref_scores_sorted[bad][None, :]).min(1).max() <= tol
+        key = lambda p: p[:, 0] * 4096 + p[:, 1]
+        assert np.array_equal(np.sort(key(got_pairs)), np.sort(key(ref_pairs)))
+    assert np.abs(got_prob[same] - ref_prob[same]).max() <= tol
+    assert np.array_equal(got_labels[same], ref_labels[same])
+
+
+@pytest.mark.parametrize("name", post_golden_names())
+def test_postprocessor_golden_parity(name):
+    """HIP PostProcessor (veto_postprocess) vs the committed outputs of the real reference PostProcessor."""
+    from oracle import veto_oracle as vo
+    from veto_amd.postprocess import PostProcessor
+    from veto_amd.structures import BoxList
+    dev = _dev()
+    g, rel_logits, obj_logits, pairs, num_objs = load_post_golden(name)
+    boxes = [BoxList(torch.zeros(n, 4), (800, 600)).to(dev) for n in num_objs]
+    post = PostProcessor(False, use_gt_box=True)
+    P = [len(p) for p in pairs]
+    res = post((list(torch.from_numpy(rel_logits).to(dev).split(P)), list(torch.from_numpy(obj_logits).to(dev).split(num_objs))),
+               [torch.from_numpy(p).to(dev) for p in pairs], boxes)
+    torch.cuda.synchronize()
+    ref = vo.postprocess(rel_logits, obj_logits, pairs, num_objs)
+    for i, r in enumerate(res):
+        assert np.array_equal(r.get_field("pred_labels").cpu().numpy(), g["pred_labels_%d" % i])
+        assert np.abs(r.get_field("pred_scores").cpu().numpy() - g["pred_scores_%d" % i]).max() <= 1e-6
+        _check_sorted_output(r, ref[i]["triple_scores"].numpy(), g["rel_pair_idxs_%d" % i], g["pred_rel_labels_%d" % i],
+                             g["pred_rel_scores_%d" % i])
+        ts = post.last_triple_scores[i].cpu().numpy()
+        assert (np.diff(ts) <= 0).all()                       # sortedness
+
+
+def test_postprocessor_full_size_properties():
+    """12 images x 1260 pairs: sorted keys, a permutation of the input pairs, probabilities sum to 1,
+    ties broken by index (two identical logit rows keep their input order)."""
+    from veto_amd import synth
+    from veto_amd.postprocess import PostProcessor
+    from veto_amd.structures import BoxList
+    from oracle import veto_oracle as vo
+    dev = _dev()
+    num_objs = [36] * 12
+    pairs = [torch.from_numpy(vo.enumerate_test_pairs(36)).to(dev) for _ in num_objs]
+    rel = torch.from_numpy(synth.normal(5, "rel", (15120, 51), 0.0, 2.0)).to(dev)
+    rel[101] = rel[100]                                        # an exact tie inside image 0
+    obj = torch.from_numpy(synth.normal(5, "obj", (432, 151), 0.0, 3.0)).to(dev)
+    boxes = [BoxList(torch.zeros(36, 4), (800, 600)).to(dev) for _ in num_objs]
+    post = PostProcessor(False, use_gt_box=True)
+    res = post((rel, obj), pairs, boxes)
+    torch.cuda.synchronize()
+    for i, r in enumerate(res):
+        ts = post.last_triple_scores[i]
+        assert (ts[1:] <= ts[:-1]).all()
+        p = r.get_field("rel_pair_idxs")
+        assert torch.equal(torch.sort(p[:, 0] * 64 + p[:, 1])[0], torch.sort(pairs[i][:, 0] * 64 + pairs[i][:, 1])[0])
+        assert (r.get_field("pred_rel_scores").sum(1) - 1).abs().max() < 1e-5
+        assert (r.get_field("pred_rel_labels") >= 1).all() and (r.get_field("pred_labels") >= 1).all()
+    p0 = res[0].get_field("rel_pair_idxs")
+    key = (p0[:, 0] * 64 + p0[:, 1]).tolist()
+    k100, k101 = int(pairs[0][100, 0] * 64 + pairs[0][100, 1]), int(pairs[0][101, 0] * 64 + pairs[0][101, 1])
+    if (post.last_triple_scores[0][key.index(k100)] == post.last_triple_scores[0][key.index(k101)]):
+        assert key.index(k100) < key.index(k101)

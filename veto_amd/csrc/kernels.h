@@ -91,4 +91,26 @@ hipError_t launch_attention(const AttnArgs& a, hipStream_t s);
 hipError_t launch_head(const float* cls, const float* wt, const float* bias, float* out, int n_pair,
                        int n_out, hipStream_t s);
 
+// ---- post-processing (inference.py:398-453, GT-box branch) -------------------------------------
+struct PostArgs {
+  const float* rel_logits;       // [n_pair, n_rel_cls]
+  const float* obj_logits;       // [n_obj, n_obj_cls]
+  const int64_t* rel_pairs;      // [n_pair, 2] image-local
+  const int32_t* img_obj_off;    // [n_img + 1]
+  const int32_t* img_pair_off;   // [n_img + 1]
+  int n_img, n_obj, n_pair, n_rel_cls, n_obj_cls;
+  float* obj_scores;             // out [n_obj]
+  int64_t* obj_pred;             // out [n_obj]
+  float* out_prob;               // out [n_pair, n_rel_cls], sorted
+  int64_t* out_pairs;            // out [n_pair, 2], sorted
+  int64_t* out_labels;           // out [n_pair], sorted
+  float* out_triple;             // optional out [n_pair], sorted
+  float* prob_tmp;               // workspace [n_pair, n_rel_cls]
+  float* triple;                 // workspace [n_pair]
+  int32_t* label_tmp;            // workspace [n_pair]
+  int32_t* perm;                 // workspace [n_pair]
+};
+int postprocess_max_pairs_per_image();
+hipError_t launch_postprocess(const PostArgs& a, hipStream_t s);
+
 }  // namespace veto

@@ -1,0 +1,141 @@
+// Relation post-processing, the step right after the predicate logits:
+// the vanilla, GT-box branch of PostProcessor.forward, pysgg/modeling/roi_heads/relation_head/
+// inference.py:398-453.  Per image:
+//   obj_prob = softmax(obj_logit); obj_prob[:, 0] = 0; obj_score, obj_pred = max over classes 1..   (:405-412)
+//   rel_prob = softmax(rel_logit); rel_score, rel_class = max over classes 1..                       (:440-442)
+//   triple   = rel_score * obj_score[subj] * obj_score[obj]; descending sort                         (:444-445)
+//   emit rel_pair_idx, rel_prob, rel_class in that order                                              (:446-452)
+// Kernels: per-object softmax/max, per-pair softmax/max/triple score (one wave per pair), one
+// workgroup per image for the segmented sort (bitonic in LDS over (score desc, index asc) -- a total
+// order, so the result is deterministic; torch.sort leaves the order of exact ties unspecified),
+// and a row gather into sorted order.
+#include "common.h"
+#include "kernels.h"
+
+namespace veto {
+
+namespace {
+
+// one wave per row: softmax over `ncls` logits, then max over classes 1..ncls-1
+__device__ __forceinline__ void wave_softmax_fgmax(const float* __restrict__ logit, int ncls, int lane,
+                                                   float* __restrict__ prob_out, float& best, int& best_cls) {
+  float mx = -INFINITY;
+  for (int c = lane; c < ncls; c += 64) mx = fmaxf(mx, logit[c]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  float sum = 0.f;
+  for (int c = lane; c < ncls; c += 64) sum += expf(logit[c] - mx);
+  sum = wave_sum(sum);
+  const float inv = 1.f / sum;
+  best = -1.f;
+  best_cls = 0x7fffffff;
+  for (int c = lane; c < ncls; c += 64) {
+    const float p = expf(logit[c] - mx) * inv;
+    if (prob_out) prob_out[c] = p;
+    if (c >= 1 && p > best) { best = p; best_cls = c; }  // first maximum inside the lane (ascending c)
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {  // arg-max across lanes; ties -> the lower class index (torch.max)
+    const float ob = __shfl_xor(best, o, 64);
+    const int oc = __shfl_xor(best_cls, o, 64);
+    if (ob > best || (ob == best && oc < best_cls)) { best = ob; best_cls = oc; }
+  }
+}
+
+__global__ __launch_bounds__(256) void obj_score_kernel(const float* __restrict__ obj_logits, int n_obj, int ncls,
+                                                        float* __restrict__ obj_scores, int64_t* __restrict__ obj_pred) {
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (n >= n_obj) return;
+  float best;
+  int cls;
+  wave_softmax_fgmax(obj_logits + (size_t)n * ncls, ncls, lane, nullptr, best, cls);
+  if (lane == 0) { obj_scores[n] = best; obj_pred[n] = cls; }
+}
+
+__global__ __launch_bounds__(256) void rel_score_kernel(PostArgs a) {
+  const int p = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (p >= a.n_pair) return;
+  float best;
+  int cls;
+  wave_softmax_fgmax(a.rel_logits + (size_t)p * a.n_rel_cls, a.n_rel_cls, lane, a.prob_tmp + (size_t)p * a.n_rel_cls, best, cls);
+  if (lane == 0) {
+    int lo = 0, hi = a.n_img - 1;  // image of this pair: largest i with img_pair_off[i] <= p
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (a.img_pair_off[mid] <= p) lo = mid; else hi = mid - 1;
+    }
+    const int off = a.img_obj_off[lo];
+    const float s0 = a.obj_scores[off + a.rel_pairs[2 * (size_t)p]];
+    const float s1 = a.obj_scores[off + a.rel_pairs[2 * (size_t)p + 1]];
+    a.triple[p] = best * s0 * s1;  // same association as the reference: (rel * obj0) * obj1
+    a.label_tmp[p] = cls;
+  }
+}
+
+constexpr int kSortMax = 4096;
+
+// one workgroup per image: sort its pairs by (score descending, original index ascending)
+__global__ __launch_bounds__(1024) void segment_sort_kernel(PostArgs a) {
+  __shared__ float s_key[kSortMax];
+  __shared__ int s_idx[kSortMax];
+  const int img = blockIdx.x;
+  const int p0 = a.img_pair_off[img], cnt = a.img_pair_off[img + 1] - p0;
+  int n2 = 1;
+  while (n2 < cnt) n2 <<= 1;
+  for (int i = threadIdx.x; i < n2; i += blockDim.x) {
+    s_key[i] = i < cnt ? a.triple[p0 + i] : -INFINITY;
+    s_idx[i] = i < cnt ? i : 0x7fffffff;  // padding sorts last
+  }
+  __syncthreads();
+  for (int k = 2; k <= n2; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = threadIdx.x; i < n2; i += blockDim.x) {
+        const int l = i ^ j;
+        if (l > i) {
+          const float ki = s_key[i], kl = s_key[l];
+          const int ii = s_idx[i], il = s_idx[l];
+          // "i before l" in the final order: higher score first, then lower index (NaN-free inputs)
+          const bool i_first = ki > kl || (ki == kl && ii < il);
+          const bool ascending_block = (i & k) == 0;
+          if (ascending_block ? !i_first : i_first) {
+            s_key[i] = kl; s_key[l] = ki;
+            s_idx[i] = il; s_idx[l] = ii;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  for (int i = threadIdx.x; i < cnt; i += blockDim.x) a.perm[p0 + i] = p0 + s_idx[i];
+}
+
+__global__ __launch_bounds__(256) void gather_sorted_kernel(PostArgs a) {
+  const int p = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (p >= a.n_pair) return;
+  const int src = a.perm[p];
+  for (int c = lane; c < a.n_rel_cls; c += 64) a.out_prob[(size_t)p * a.n_rel_cls + c] = a.prob_tmp[(size_t)src * a.n_rel_cls + c];
+  if (lane == 0) {
+    a.out_pairs[2 * (size_t)p] = a.rel_pairs[2 * (size_t)src];
+    a.out_pairs[2 * (size_t)p + 1] = a.rel_pairs[2 * (size_t)src + 1];
+    a.out_labels[p] = a.label_tmp[src];
+    if (a.out_triple) a.out_triple[p] = a.triple[src];
+  }
+}
+
+}  // namespace
+
+int postprocess_max_pairs_per_image() { return kSortMax; }
+
+hipError_t launch_postprocess(const PostArgs& a, hipStream_t s) {
+  VETO_LAUNCH(obj_score_kernel, dim3((a.n_obj + 3) / 4), dim3(256), 0, s, a.obj_logits, a.n_obj, a.n_obj_cls, a.obj_scores, a.obj_pred);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  VETO_LAUNCH(rel_score_kernel, dim3((a.n_pair + 3) / 4), dim3(256), 0, s, a);
+  if ((e = hipGetLastError()) != hipSuccess) return e;
+  VETO_LAUNCH(segment_sort_kernel, dim3(a.n_img), dim3(1024), 0, s, a);
+  if ((e = hipGetLastError()) != hipSuccess) return e;
+  VETO_LAUNCH(gather_sorted_kernel, dim3((a.n_pair + 3) / 4), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
+}  // namespace veto

@@ -502,6 +502,39 @@ int veto_enumerate_pairs(void* stream, int32_t n, int64_t* out) {
   return VETO_OK;
 }
 
+size_t veto_postprocess_workspace_bytes(int32_t n_pair, int32_t n_rel_cls) {
+  if (n_pair <= 0 || n_rel_cls <= 0) return 0;
+  return align_up((size_t)n_pair * n_rel_cls * 4, 256) + 3 * align_up((size_t)n_pair * 4, 256);
+}
+
+int veto_postprocess(void* stream, const veto_post_args_t* a, void* workspace, size_t workspace_bytes) {
+  if (!a || !workspace) return fail(VETO_ERR_INVALID, "null argument");
+  if (a->struct_size != (int32_t)sizeof(veto_post_args_t)) return fail(VETO_ERR_INVALID, "veto_post_args_t size mismatch");
+  if (a->n_img <= 0 || a->n_obj <= 0 || a->n_pair <= 0 || a->n_rel_cls < 2 || a->n_obj_cls < 2)
+    return fail(VETO_ERR_INVALID, "bad sizes");
+  if (!a->rel_logits || !a->obj_logits || !a->rel_pairs || !a->img_obj_offset || !a->img_pair_offset || !a->obj_scores ||
+      !a->obj_pred || !a->rel_prob_sorted || !a->rel_pairs_sorted || !a->rel_labels_sorted)
+    return fail(VETO_ERR_INVALID, "missing pointer");
+  if (a->max_pairs_per_image < 1 || a->max_pairs_per_image > postprocess_max_pairs_per_image())
+    return fail(VETO_ERR_INVALID, "max_pairs_per_image %d outside 1..%d (MAX_PROPOSAL_PAIR is 2048 at test time)",
+                a->max_pairs_per_image, postprocess_max_pairs_per_image());
+  if (workspace_bytes < veto_postprocess_workspace_bytes(a->n_pair, a->n_rel_cls)) return fail(VETO_ERR_WORKSPACE, "workspace too small");
+  char* base = (char*)workspace;
+  PostArgs p{};
+  p.rel_logits = a->rel_logits; p.obj_logits = a->obj_logits; p.rel_pairs = a->rel_pairs;
+  p.img_obj_off = a->img_obj_offset; p.img_pair_off = a->img_pair_offset;
+  p.n_img = a->n_img; p.n_obj = a->n_obj; p.n_pair = a->n_pair; p.n_rel_cls = a->n_rel_cls; p.n_obj_cls = a->n_obj_cls;
+  p.obj_scores = a->obj_scores; p.obj_pred = a->obj_pred; p.out_prob = a->rel_prob_sorted;
+  p.out_pairs = a->rel_pairs_sorted; p.out_labels = a->rel_labels_sorted; p.out_triple = a->triple_sorted;
+  p.prob_tmp = (float*)base;
+  base += align_up((size_t)a->n_pair * a->n_rel_cls * 4, 256);
+  p.triple = (float*)base; base += align_up((size_t)a->n_pair * 4, 256);
+  p.label_tmp = (int32_t*)base; base += align_up((size_t)a->n_pair * 4, 256);
+  p.perm = (int32_t*)base;
+  HIP_TRY(launch_postprocess(p, (hipStream_t)stream));
+  return VETO_OK;
+}
+
 int veto_profile_enable(veto_handle_t h, int32_t on) {
   if (!h) return fail(VETO_ERR_INVALID, "null handle");
   h->prof_on = on != 0;

@@ -1,0 +1,94 @@
+"""MI355X-native relation PostProcessor.
+
+Mirrors the vanilla, GT-box branch of the reference's PostProcessor
+(pysgg/modeling/roi_heads/relation_head/inference.py:9-92,398-453): same constructor arguments, same
+`forward(x, rel_pair_idxs, boxes)` call, and the same BoxList fields on the results
+(`pred_labels`, `pred_scores`, `rel_pair_idxs`, `pred_rel_scores`, `pred_rel_labels`).  The
+arithmetic (softmax, foreground max, triple score, per-image descending sort, gather) runs in
+libveto_amd.so (veto_postprocess).  sgdet decoding (per-class NMS, inference.py:413-418), attributes
+and the MEET merge (inference.py:93-397) are not built; they raise."""
+import ctypes
+
+import torch
+from torch import nn
+
+from . import native
+
+
+class PostProcessor(nn.Module):
+    def __init__(self, attribute_on, use_gt_box=False, later_nms_pred_thres=0.3, cfg=None):
+        super().__init__()
+        self.cfg = cfg
+        self.attribute_on = attribute_on
+        self.use_gt_box = use_gt_box
+        self.later_nms_pred_thres = later_nms_pred_thres
+        self._workspace = None
+
+    def forward(self, x, rel_pair_idxs, boxes, custom_rel_labels=None, cur_chosen_matrix=None, incre_idx_list=None,
+                ensemble=False):
+        relation_logits, refine_logits = x
+        if self.attribute_on:
+            raise NotImplementedError("veto_amd.PostProcessor: attribute head is outside the VETO path")
+        if not self.use_gt_box:
+            raise NotImplementedError("veto_amd.PostProcessor: sgdet decoding (per-class NMS) is not built")
+        if isinstance(relation_logits, dict) or ensemble:
+            raise NotImplementedError("veto_amd.PostProcessor: MEET group merge (inference.py:284-397) is not built")
+        rel = torch.cat(list(relation_logits), 0) if isinstance(relation_logits, (list, tuple)) else relation_logits
+        obj = torch.cat(list(refine_logits), 0) if isinstance(refine_logits, (list, tuple)) else refine_logits
+        device = rel.device
+        if device.type != "cuda":
+            raise RuntimeError("veto_amd.PostProcessor runs only on a HIP device (got %s)" % device)
+        lib = native.load_library()
+        n_objs = [len(b) for b in boxes]
+        n_pairs = [int(p.shape[0]) for p in rel_pair_idxs]
+        n_obj, n_pair = sum(n_objs), sum(n_pairs)
+        f32 = dict(device=device, dtype=torch.float32)
+        rel = rel.detach().to(**f32).contiguous()
+        obj = obj.detach().to(**f32).contiguous()
+        if rel.shape[0] != n_pair or obj.shape[0] != n_obj:
+            raise ValueError("logit rows (%d, %d) do not match pairs/objects (%d, %d)" % (rel.shape[0], obj.shape[0], n_pair, n_obj))
+        pairs = torch.cat([p.reshape(-1, 2) for p in rel_pair_idxs], 0).to(device=device, dtype=torch.int64).contiguous()
+        cs = lambda xs: [0] + [sum(xs[:i + 1]) for i in range(len(xs))]
+        obj_off = torch.tensor(cs(n_objs), dtype=torch.int32, device=device)
+        pair_off = torch.tensor(cs(n_pairs), dtype=torch.int32, device=device)
+        out = {
+            "obj_scores": torch.empty(n_obj, **f32), "obj_pred": torch.empty(n_obj, dtype=torch.int64, device=device),
+            "prob": torch.empty((n_pair, rel.shape[1]), **f32),
+            "pairs": torch.empty((n_pair, 2), dtype=torch.int64, device=device),
+            "labels": torch.empty(n_pair, dtype=torch.int64, device=device), "triple": torch.empty(n_pair, **f32),
+        }
+        need = lib.veto_postprocess_workspace_bytes(n_pair, rel.shape[1])
+        if self._workspace is None or self._workspace.numel() < need or self._workspace.device != device:
+            self._workspace = torch.empty(need, dtype=torch.uint8, device=device)
+        a = native.VetoPostArgs()
+        a.struct_size = ctypes.sizeof(native.VetoPostArgs)
+        a.n_img, a.n_obj, a.n_pair = len(boxes), n_obj, n_pair
+        a.n_rel_cls, a.n_obj_cls, a.max_pairs_per_image = rel.shape[1], obj.shape[1], max(n_pairs)
+        a.rel_logits, a.obj_logits, a.rel_pairs = rel.data_ptr(), obj.data_ptr(), pairs.data_ptr()
+        a.img_obj_offset, a.img_pair_offset = obj_off.data_ptr(), pair_off.data_ptr()
+        a.obj_scores, a.obj_pred = out["obj_scores"].data_ptr(), out["obj_pred"].data_ptr()
+        a.rel_prob_sorted, a.rel_pairs_sorted = out["prob"].data_ptr(), out["pairs"].data_ptr()
+        a.rel_labels_sorted, a.triple_sorted = out["labels"].data_ptr(), out["triple"].data_ptr()
+        stream = torch.cuda.current_stream(device)
+        native.check(lib.veto_postprocess(ctypes.c_void_p(stream.cuda_stream), ctypes.byref(a),
+                                          ctypes.c_void_p(self._workspace.data_ptr()), self._workspace.numel()))
+        for t in (rel, obj, pairs, obj_off, pair_off):
+            t.record_stream(stream)
+        self.last_triple_scores = out["triple"].split(n_pairs)
+        results = []
+        for box, sc, pr, prob, pidx, lab in zip(boxes, out["obj_scores"].split(n_objs), out["obj_pred"].split(n_objs),
+                                                out["prob"].split(n_pairs), out["pairs"].split(n_pairs),
+                                                out["labels"].split(n_pairs)):
+            box.add_field("pred_labels", pr)       # inference.py:431-432 (the GT-box branch re-uses `box`)
+            box.add_field("pred_scores", sc)
+            box.add_field("rel_pair_idxs", pidx)   # :450-452
+            box.add_field("pred_rel_scores", prob)
+            box.add_field("pred_rel_labels", lab)
+            results.append(box)
+        return results
+
+
+def make_roi_relation_post_processor(cfg):
+    """inference.py:456-468."""
+    return PostProcessor(getattr(cfg.MODEL, "ATTRIBUTE_ON", False), cfg.MODEL.ROI_RELATION_HEAD.USE_GT_BOX,
+                         cfg.TEST.RELATION.LATER_NMS_PREDICTION_THRES, cfg)
