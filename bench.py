@@ -62,8 +62,11 @@ def main():
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
     dist = None
-    if world > 1:
+    force_dist = os.environ.get("VETO_BENCH_FORCE_DIST") == "1"  # exercise the RCCL path with one rank (testing)
+    if world > 1 or force_dist:
         import torch.distributed as dist
+        if force_dist and "RANK" not in os.environ:
+            os.environ.update(RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
         dist.init_process_group("nccl", device_id=dev)
 
     from veto_amd import distributed as vdist
@@ -83,9 +86,9 @@ def main():
     def step():
         with torch.no_grad():
             out = model(props, pairs, None, None, roi_features=rgb, roi_depth_features=dep)
-        logits = torch.cat(list(out[1]), 0) if world > 1 else out[1]
-        if world > 1:
-            logits = vdist.all_gather_logits(logits, equal_counts=True)
+        logits = torch.cat(list(out[1]), 0) if dist is not None else out[1]
+        if dist is not None:
+            logits = vdist.all_gather_logits(logits, equal_counts=True, force=force_dist)
         return logits
 
     def fence():
@@ -159,8 +162,14 @@ def main():
             "gemm_tflops": {k: round(v["tflops"], 1) for k, v in gemms.items()},
         }
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"], res["logit_max_abs_err"] = cpu_baseline(sd, args, batch, last, pairs)
-        print(json.dumps(res))
+            gl = list(last.split([int(p.shape[0]) for p in pairs])) if torch.is_tensor(last) else last
+            res["cpu_baseline"], res["logit_max_abs_err"] = cpu_baseline(sd, args, batch, gl, pairs)
+        # RCCL writes its version banner through C stdio, which (when stdout is a file or pipe) only
+        # drains at exit, i.e. AFTER a Python print: drain it first so that the JSON is the last line.
+        import ctypes
+        sys.stdout.flush()
+        ctypes.CDLL(None).fflush(None)
+        print(json.dumps(res), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -18,7 +18,7 @@ def shard_images(num_images, rank=None, world=None):
     return list(range(start, start + base + (1 if rank < rem else 0)))
 
 
-def all_gather_logits(logits, equal_counts=False, group=None):
+def all_gather_logits(logits, equal_counts=False, group=None, force=False):
     """logits: [P_r, C] on this rank -> [sum_r P_r, C], rank-major, on every rank.
 
     P_r may differ between ranks (images have different object counts): the row counts are gathered
@@ -27,7 +27,7 @@ def all_gather_logits(logits, equal_counts=False, group=None):
     if not dist.is_available() or not dist.is_initialized():
         return logits
     world = dist.get_world_size(group)
-    if world == 1:
+    if world == 1 and not force:   # force: run the collective anyway (single-rank test of the RCCL path)
         return logits
     logits = logits.contiguous()
     p, c = logits.shape

@@ -222,6 +222,19 @@ class _NativeForward:
             self._uploaded = ver
         return self._engine
 
+    def _offsets(self, n_objs, n_pairs, device):
+        """Per-image prefix sums as device tensors.  torch.tensor(list, device=...) is a synchronous
+        pageable H2D copy that stalls the host behind all queued GPU work, so batch shapes seen before
+        (the common case in an eval loop) re-use their tensors."""
+        cache = self.__dict__.setdefault("_offset_cache", {})
+        key = (n_objs, n_pairs, str(device))
+        hit = cache.get(key)
+        if hit is None:
+            if len(cache) >= 256:
+                cache.clear()
+            hit = cache[key] = _offset_tensors(n_objs, n_pairs, device)
+        return hit
+
     def _run_native(self, proposals, rel_pair_idxs, roi_features, roi_depth_features, labels, logits,
                     debug=False):
         device = roi_features.device
@@ -240,8 +253,7 @@ class _NativeForward:
         boxes = torch.cat([p.bbox for p in proposals], 0).to(**f32).contiguous()
         mode = proposals[0].mode
         pairs = torch.cat([p.reshape(-1, 2) for p in rel_pair_idxs], 0).to(device=device, dtype=torch.int64).contiguous()
-        obj_off = torch.tensor([0] + list(_cumsum(n_objs)), dtype=torch.int32, device=device)
-        pair_off = torch.tensor([0] + list(_cumsum(n_pairs)), dtype=torch.int32, device=device)
+        obj_off, pair_off = self._offsets(tuple(n_objs), tuple(n_pairs), device)
         lab = labels.to(device=device, dtype=torch.int64).contiguous() if labels is not None else None
         lg = logits.detach().to(**f32).contiguous() if logits is not None else None
 
@@ -272,11 +284,17 @@ class _NativeForward:
         stream = torch.cuda.current_stream(device).cuda_stream
         eng.forward(stream, inp, self._workspace.data_ptr(), self._workspace.numel(), out.data_ptr(), dbg)
         # the inputs above are referenced by enqueued kernels: keep them alive on this stream
-        for t in (rgb, dep, boxes, pairs, obj_off, pair_off, lab, lg):
+        for t in (rgb, dep, boxes, pairs, lab, lg):
             if t is not None:
                 t.record_stream(torch.cuda.current_stream(device))
         self.last_debug = extras
         return out, n_objs, n_pairs
+
+
+def _offset_tensors(n_objs, n_pairs, device):
+    obj_off = torch.tensor([0] + list(_cumsum(n_objs)), dtype=torch.int32, device=device)
+    pair_off = torch.tensor([0] + list(_cumsum(n_pairs)), dtype=torch.int32, device=device)
+    return obj_off, pair_off
 
 
 def _cumsum(xs):
