@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256) void obj_prep_kernel(ObjPrepArgs a) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) acc += a.pos_w[tid * 4 + k] * s_box[k];
     s_pos[tid] = fmaxf(acc, 0.f);
-    if (a.pos_out) a.pos_out[(size_t)n * kPosDim + tid] = s_pos[tid];
+    if (a.pos_out && blockIdx.y == 0) a.pos_out[(size_t)n * kPosDim + tid] = s_pos[tid];
   }
   if (a.obj_logits) {
     if (tid == 0) {
@@ -130,8 +130,11 @@ __global__ __launch_bounds__(256) void obj_prep_kernel(ObjPrepArgs a) {
     for (int e = tid; e < a.embed_dim; e += 256) s_emb[e] = a.embed[(size_t)lab * a.embed_dim + e];
   }
   __syncthreads();
+  // blockIdx.y selects which 256 of the 1152 output columns this workgroup produces (the cheap box /
+  // class embedding above is recomputed per workgroup): 5x more workgroups hide the k-loop latency.
   float* out = a.lc + (size_t)n * 2 * (2 * kDim);
-  for (int jj = tid; jj < 2 * kDim; jj += 256) {
+  const int jj = blockIdx.y * 256 + tid;
+  if (jj < 2 * kDim) {
     float acc = jj < kDim ? a.loc_b[jj] : 0.f;
     for (int k = 0; k < kPosDim; ++k) acc += a.loc_wt[(size_t)k * (2 * kDim) + jj] * s_pos[k];
     out[jj] = acc;
@@ -201,97 +204,100 @@ __global__ void enumerate_pairs_kernel(int n, int64_t* __restrict__ out) {
   out[2 * p + 1] = r + (r >= i ? 1 : 0);
 }
 
-// A 576-wide row lives in one wave as float2 pairs: pair index lane + 64*i (i < 4) covers columns
-// 0..511, lanes 0..31 additionally hold pair 256 + lane (columns 512..575).
-struct RowRegs { float v[10]; };
+// A 576-wide row is handled by a QUARTER wave: lane q (0..15) of the group holds the float4 chunks
+// q + 16 j, j = 0..8 (16-byte global accesses, 256 contiguous bytes per group and j).  A wave works
+// on 4 rows, a 256-thread block on 16.
+struct RowQ { f32x4 v[9]; };
 
-__device__ __forceinline__ int row_col(int lane, int i) { return i < 4 ? 2 * (lane + 64 * i) : 512 + 2 * lane; }
+__device__ __forceinline__ float group16_sum(float v) {
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
 
-__device__ __forceinline__ void row_layernorm_store(const RowRegs& r, int lane, const float* __restrict__ w,
-                                                    const float* __restrict__ b, __bf16* __restrict__ dst) {
-  const bool tail = lane < 32;
+// LayerNorm (eps 1e-5, model_veto.py:125-132) of the row in registers -> split-row operand
+__device__ __forceinline__ void rowq_layernorm_store(const RowQ& r, int q, const float* __restrict__ w,
+                                                     const float* __restrict__ b, __bf16* __restrict__ dst) {
   float s = 0.f;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) s += r.v[i];
-  if (tail) s += r.v[8] + r.v[9];
-  const float mean = wave_sum(s) * (1.f / kDim);
-  float q = 0.f;
+  for (int j = 0; j < 9; ++j) s += (r.v[j][0] + r.v[j][1]) + (r.v[j][2] + r.v[j][3]);
+  const float mean = group16_sum(s) * (1.f / kDim);
+  float sq = 0.f;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) { const float d = r.v[i] - mean; q += d * d; }
-  if (tail) { const float d0 = r.v[8] - mean, d1 = r.v[9] - mean; q += d0 * d0 + d1 * d1; }
-  const float rstd = 1.f / sqrtf(wave_sum(q) * (1.f / kDim) + 1e-5f);
+  for (int j = 0; j < 9; ++j)
 #pragma unroll
-  for (int i = 0; i < 5; ++i) {
-    if (i == 4 && !tail) break;
-    const int c = row_col(lane, i);
-    const float y0 = (r.v[2 * i] - mean) * rstd * w[c] + b[c];
-    const float y1 = (r.v[2 * i + 1] - mean) * rstd * w[c + 1] + b[c + 1];
-    __bf16 h0, l0, h1, l1;
-    split_bf16(y0, h0, l0);
-    split_bf16(y1, h1, l1);
-    __bf16* d = dst + split_index(c);  // c is even: the pair stays inside one 32-k block
-    *(bf16x2*)d = bf16x2{h0, h1};
-    *(bf16x2*)(d + 32) = bf16x2{l0, l1};
+    for (int e = 0; e < 4; ++e) { const float d = r.v[j][e] - mean; sq += d * d; }
+  const float rstd = 1.f / sqrtf(group16_sum(sq) * (1.f / kDim) + 1e-5f);
+#pragma unroll
+  for (int j = 0; j < 9; ++j) {
+    const int c = 4 * (q + 16 * j);
+    const f32x4 wv = *(const f32x4*)(w + c), bv = *(const f32x4*)(b + c);
+    bf16x4 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      __bf16 h, l;
+      split_bf16((r.v[j][e] - mean) * rstd * wv[e] + bv[e], h, l);
+      hi[e] = h;
+      lo[e] = l;
+    }
+    __bf16* d = dst + split_index(c);  // 4 consecutive columns stay inside one 32-k block
+    *(bf16x4*)d = hi;
+    *(bf16x4*)(d + 32) = lo;
   }
 }
 
-// One workgroup per pair; wave w builds token rows w, w+4, ...  Reads of the per-object tables hit
-// L2 / Infinity Cache (each object row is re-used by 2(N-1) pairs); writes are the HBM stream.
+// Token assembly (model_veto.py:56-63 with the per-object partial products of section 4 of DESIGN.md):
+// one quarter wave per token row.  Reads of the per-object tables hit L2 / Infinity Cache (each object
+// row is re-used by 2(N-1) pairs); the writes (x fp32 + LN(x) split) are the HBM stream.
 __global__ __launch_bounds__(256) void assemble_kernel(AssembleArgs a) {
-  const int p = blockIdx.x;
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const long row = (long)blockIdx.x * 16 + (threadIdx.x >> 4);
+  if (row >= (long)a.n_pair * kTokens) return;
+  const int q = threadIdx.x & 15;
+  const int p = (int)(row / kTokens), t = (int)(row % kTokens);
   const int s = a.subj[p], o = a.obj[p];
-  const bool tail = lane < 32;
-  for (int t = w; t < kTokens; t += 4) {
-    RowRegs r;
-#pragma unroll
-    for (int i = 0; i < 5; ++i) {
-      if (i == 4 && !tail) { r.v[8] = 0.f; r.v[9] = 0.f; break; }
-      const int c = row_col(lane, i);
-      float2 v;
-      const float2 pe = *(const float2*)(a.pos_embedding + c);
-      if (t == 0) {
-        v = *(const float2*)(a.cls_token + c);
-      } else if (t <= kPatchTokens) {
-        const float2 vs = *(const float2*)(a.patch_tab + ((size_t)s * 16 + (t - 1)) * (2 * kDim) + c);
-        const float2 vo = *(const float2*)(a.patch_tab + ((size_t)o * 16 + (t - 1)) * (2 * kDim) + kDim + c);
-        v.x = vs.x + vo.x;
-        v.y = vs.y + vo.y;
-      } else {
-        const int which = t - kPatchTokens - 1;  // 0 location, 1 class
-        const float2 vs = *(const float2*)(a.lc + ((size_t)s * 2 + which) * (2 * kDim) + c);
-        const float2 vo = *(const float2*)(a.lc + ((size_t)o * 2 + which) * (2 * kDim) + kDim + c);
-        v.x = fmaxf(vs.x + vo.x, 0.f);
-        v.y = fmaxf(vs.y + vo.y, 0.f);
-      }
-      v.x += pe.x;
-      v.y += pe.y;
-      r.v[2 * i] = v.x;
-      r.v[2 * i + 1] = v.y;
-      *(float2*)(a.x + ((size_t)p * kTokens + t) * kDim + c) = v;
-    }
-    const size_t row = (size_t)p * kTokens + t;
-    row_layernorm_store(r, lane, a.ln_w, a.ln_b, a.a + row * (2 * kDim));
+  const float *ps = nullptr, *po = nullptr;
+  if (t >= 1 && t <= kPatchTokens) {
+    ps = a.patch_tab + ((size_t)s * 16 + (t - 1)) * (2 * kDim);
+    po = a.patch_tab + ((size_t)o * 16 + (t - 1)) * (2 * kDim) + kDim;
+  } else if (t > kPatchTokens) {
+    const int which = t - kPatchTokens - 1;  // 0 location, 1 class
+    ps = a.lc + ((size_t)s * 2 + which) * (2 * kDim);
+    po = a.lc + ((size_t)o * 2 + which) * (2 * kDim) + kDim;
   }
+  RowQ r;
+  float* xr = a.x + (size_t)row * kDim;
+#pragma unroll
+  for (int j = 0; j < 9; ++j) {
+    const int c = 4 * (q + 16 * j);
+    f32x4 v;
+    if (t == 0) {
+      v = *(const f32x4*)(a.cls_token + c);
+    } else {
+      v = *(const f32x4*)(ps + c) + *(const f32x4*)(po + c);
+      if (t > kPatchTokens) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);  // ReLU of location / class projection
+      }
+    }
+    v += *(const f32x4*)(a.pos_embedding + c);
+    r.v[j] = v;
+    *(f32x4*)(xr + c) = v;
+  }
+  rowq_layernorm_store(r, q, a.ln_w, a.ln_b, a.a + (size_t)row * (2 * kDim));
 }
 
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, long ldx,
                                                         const float* __restrict__ w,
                                                         const float* __restrict__ b,
                                                         __bf16* __restrict__ dst, int rows) {
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int row = blockIdx.x * 16 + (threadIdx.x >> 4);
   if (row >= rows) return;
-  const int lane = threadIdx.x & 63;
+  const int q = threadIdx.x & 15;
   const float* xr = x + (size_t)row * ldx;
-  RowRegs r;
+  RowQ r;
 #pragma unroll
-  for (int i = 0; i < 5; ++i) {
-    if (i == 4 && lane >= 32) { r.v[8] = 0.f; r.v[9] = 0.f; break; }
-    const float2 v = *(const float2*)(xr + row_col(lane, i));
-    r.v[2 * i] = v.x;
-    r.v[2 * i + 1] = v.y;
-  }
-  row_layernorm_store(r, lane, w, b, dst + (size_t)row * (2 * kDim));
+  for (int j = 0; j < 9; ++j) r.v[j] = *(const f32x4*)(xr + 4 * (q + 16 * j));
+  rowq_layernorm_store(r, q, w, b, dst + (size_t)row * (2 * kDim));
 }
 
 // logits[p][c] = cls[p] . W[c] + b[c]; weights pre-transposed to [576][n_out]; 4 pairs per block.
@@ -348,7 +354,7 @@ hipError_t launch_transpose_head(const float* src, float* dst, int n_out, hipStr
 
 hipError_t launch_obj_prep(const ObjPrepArgs& a, hipStream_t s) {
   if (a.num_obj_cls > 256 || a.embed_dim > 256) return hipErrorInvalidValue;
-  VETO_LAUNCH(obj_prep_kernel, dim3(a.n_obj), dim3(256), 0, s, a);
+  VETO_LAUNCH(obj_prep_kernel, dim3(a.n_obj, (2 * kDim + 255) / 256), dim3(256), 0, s, a);
   return hipGetLastError();
 }
 
@@ -372,13 +378,13 @@ hipError_t launch_enumerate_pairs(int n, int64_t* out, hipStream_t s) {
 }
 
 hipError_t launch_assemble(const AssembleArgs& a, hipStream_t s) {
-  VETO_LAUNCH(assemble_kernel, dim3(a.n_pair), dim3(256), 0, s, a);
+  VETO_LAUNCH(assemble_kernel, dim3((unsigned)(((long)a.n_pair * kTokens + 15) / 16)), dim3(256), 0, s, a);
   return hipGetLastError();
 }
 
 hipError_t launch_layernorm(const float* x, long ldx, const float* w, const float* b, __bf16* dst, int rows,
                             hipStream_t s) {
-  VETO_LAUNCH(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, ldx, w, b, dst, rows);
+  VETO_LAUNCH(layernorm_kernel, dim3((rows + 15) / 16), dim3(256), 0, s, x, ldx, w, b, dst, rows);
   return hipGetLastError();
 }
 
