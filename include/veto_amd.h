@@ -138,6 +138,31 @@ typedef struct veto_post_args {
 size_t veto_postprocess_workspace_bytes(int32_t n_pair, int32_t n_rel_cls);
 int veto_postprocess(void* stream, const veto_post_args_t* args, void* workspace, size_t workspace_bytes);
 
+/* MEET merge branch (ENSEMBLE_LEARNING.ENABLED, EXPERT_GROUP False), inference.py:284-397, for ONE image
+ * (the reference zips the group logits with the first image only).  Each of the n_groups heads is
+ * soft-maxed over its g_k+2 logits, the last column dropped, the arg-max over columns 1..g_k taken as a
+ * GROUP-LOCAL label; all n_groups*n_pair rows are merged and sorted by triple score; row probabilities are
+ * scattered into n_rel_cls-wide rows at columns [0] + {c : incre_idx_list[c] == k+1}. */
+typedef struct veto_post_meet_args {
+  int32_t struct_size;
+  int32_t n_obj, n_pair, n_groups;
+  int32_t n_rel_cls, n_obj_cls;
+  const float* const* group_logits;   /* HOST array of n_groups device pointers [n_pair, group_widths[k]] */
+  const int32_t* group_widths;        /* HOST array [n_groups]: g_k + 2 */
+  const int32_t* incre_idx_list;      /* HOST array [n_rel_cls]: 1-based group of each class, 0 = background */
+  const float* obj_logits;            /* device [n_obj, n_obj_cls] */
+  const int64_t* rel_pairs;           /* device [n_pair, 2] */
+  float* obj_scores;                  /* out device [n_obj] */
+  int64_t* obj_pred;                  /* out device [n_obj] */
+  float* rel_prob_sorted;             /* out device [n_groups*n_pair, n_rel_cls] */
+  int64_t* rel_pairs_sorted;          /* out device [n_groups*n_pair, 2] */
+  int64_t* rel_labels_sorted;         /* out device [n_groups*n_pair] (group-local labels, as the reference) */
+  float* triple_sorted;               /* optional out device [n_groups*n_pair] */
+} veto_post_meet_args_t;
+
+/* workspace: veto_postprocess_workspace_bytes(n_groups * n_pair, n_rel_cls) */
+int veto_postprocess_meet(void* stream, const veto_post_meet_args_t* args, void* workspace, size_t workspace_bytes);
+
 /* ---- measurement hooks (bench.py): per-kernel device time from hipEvents on `stream` ---------- */
 int veto_profile_enable(veto_handle_t h, int32_t on);
 /* Synchronises the recorded events; returns the number of distinct kernels. */

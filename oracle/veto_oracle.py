@@ -240,6 +240,42 @@ def postprocess(rel_logits, obj_logits, rel_pair_idxs, num_objs, dtype=torch.flo
     return out
 
 
+def postprocess_meet(rel_logits_by_group, obj_logits, rel_pair_idx, incre_idx_list, num_rel_cls, dtype=torch.float32):
+    """MEET merge branch of PostProcessor.forward (ENSEMBLE_LEARNING.ENABLED, EXPERT_GROUP False),
+    inference.py:284-397, one image (the reference zips the batch-wide group logits with the FIRST
+    image only, so it is only meaningful for one image per batch).
+    Per group i: softmax over its g_i+2 logits, DROP the last ("other group") column (:350-351),
+    rel_class = argmax over columns 1.. (+1) -- a GROUP-LOCAL label, kept as such (:352-353,:388) --,
+    triple score as in the vanilla branch; every pair is kept (:358-372); the group's g_i+1
+    probabilities are scattered into a zero [*, num_rel_cls] row at columns [0] + its own classes
+    (:354-357,:387); the K*P rows are sorted by triple score, descending (:390).  The pair indices come
+    out as a FLOAT tensor (torch.zeros(total, 2), :381)."""
+    obj_logits = _t(obj_logits, dtype)
+    pairs = torch.as_tensor(np.asarray(rel_pair_idx)).long()
+    obj_prob = torch.softmax(obj_logits, -1)
+    obj_prob[:, 0] = 0
+    obj_scores, obj_pred = obj_prob[:, 1:].max(dim=1)
+    obj_pred = obj_pred + 1
+    K = len(rel_logits_by_group)
+    triples, labels, probs, prs = [], [], [], []
+    for i in range(K):
+        logit = _t(rel_logits_by_group["group_%d" % i], dtype)
+        prob = torch.softmax(logit, -1)[:, :-1]
+        rel_scores, rel_class = prob[:, 1:].max(dim=1)
+        rel_class = rel_class + 1
+        cols = [0] + [c for c, x in enumerate(incre_idx_list) if x == i + 1]
+        full = torch.zeros(prob.shape[0], num_rel_cls, dtype=dtype)
+        full[:, cols] = prob
+        triples.append(rel_scores * obj_scores[pairs[:, 0]] * obj_scores[pairs[:, 1]])
+        labels.append(rel_class)
+        probs.append(full)
+        prs.append(pairs)
+    triple, label, prob, pr = torch.cat(triples), torch.cat(labels), torch.cat(probs), torch.cat(prs)
+    order = torch.sort(triple, descending=True, stable=True)[1]
+    return {"pred_scores": obj_scores, "pred_labels": obj_pred, "rel_pair_idxs": pr[order].to(torch.float32),
+            "pred_rel_scores": prob[order], "pred_rel_labels": label[order], "triple_scores": triple[order]}
+
+
 def meet_incre_idx_list(group_sizes):
     """SHA_GCL_extra/extra_function_utils.py:39-77 (first return value) for the contiguous
     splits of group_chosen_function.py:6-94: class c (1-based, frequency order) belongs to

@@ -19,11 +19,29 @@ def pytest_configure(config):
 
 def golden_names():
     """Predictor fixtures (the post_* files are PostProcessor fixtures, see post_golden_names)."""
-    return sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith(".npz") and not f.startswith("post_"))
+    return sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith(".npz") and not f.startswith("post"))
 
 
 def post_golden_names():
     return sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith(".npz") and f.startswith("post_"))
+
+
+def postmeet_golden_names():
+    return sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith(".npz") and f.startswith("postmeet_"))
+
+
+def load_postmeet_golden(name):
+    """Returns (fixture, {group_k: logits}, obj_logits, pairs, n) with the inputs regenerated."""
+    from oracle import veto_oracle as vo
+    from veto_amd import synth
+    g = dict(np.load(os.path.join(GOLDEN_DIR, name + ".npz")))
+    n = int(g["n"])
+    sizes = [int(x) for x in g["group_sizes"]]
+    n_objc = 151 if str(g["dataset"]) == "VG" else 201
+    P = n * (n - 1)
+    rel = {"group_%d" % k: synth.normal(23, "meet.group_%d" % k, (P, gk + 2), 0.0, 2.0) for k, gk in enumerate(sizes)}
+    obj_logits = synth.normal(23, "meet.obj_logits", (n, n_objc), 0.0, 3.0)
+    return g, rel, obj_logits, vo.enumerate_test_pairs(n), n
 
 
 def load_post_golden(name):

@@ -246,9 +246,49 @@ def run_postprocessor(cfg, BoxList, name, num_objs, onehot):
     print("%-24s postprocessor %s images, %d pairs" % (name, len(res), sum(P_list)))
 
 
+def run_postprocessor_meet(cfg, BoxList, name, n, dataset):
+    """The reference's MEET merge branch (inference.py:284-397) on portable-RNG group logits.  The
+    branch calls .cuda() unconditionally; in this CPU-only container Tensor.cuda is patched to the
+    identity for the duration of the call (a stand-in for the absent device, not for reference code)."""
+    from pysgg.modeling.roi_heads.relation_head.inference import make_roi_relation_post_processor
+    from SHA_GCL_extra.group_chosen_function import get_group_splits
+    from SHA_GCL_extra.extra_function_utils import get_current_predicate_idx
+    cfg.MODEL.ROI_RELATION_HEAD.USE_GT_BOX = True
+    cfg.ENSEMBLE_LEARNING.ENABLED = True
+    cfg.ENSEMBLE_LEARNING.EXPERT_GROUP = False
+    cfg.ENSEMBLE_LEARNING.TYPE = ["group"]
+    cfg.GLOBAL_SETTING.DATASET_CHOICE = dataset
+    cfg.MODEL.ATTRIBUTE_ON = False
+    post = make_roi_relation_post_processor(cfg).eval()
+    stage_list, sizes = get_group_splits(dataset, "divide4")
+    incre_idx_list = get_current_predicate_idx(stage_list, 0.1, dataset)[0]
+    n_objc = 151 if dataset == "VG" else 201
+    P_ = n * (n - 1)
+    rel = {"group_%d" % k: torch.from_numpy(synth.normal(23, "meet.group_%d" % k, (P_, g + 2), 0.0, 2.0))
+           for k, g in enumerate(sizes)}
+    obj_logits = torch.from_numpy(synth.normal(23, "meet.obj_logits", (n, n_objc), 0.0, 3.0))
+    pairs = test_pairs([n])
+    boxes = [BoxList(torch.zeros(n, 4), (800, 600), mode="xyxy")]
+    orig = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        with torch.no_grad():
+            res = post((rel, [obj_logits]), pairs, boxes, incre_idx_list=incre_idx_list, ensemble=True)
+    finally:
+        torch.Tensor.cuda = orig
+    r = res[0]
+    out = {"n": n, "dataset": dataset, "group_sizes": np.array(sizes), "incre_idx_list": np.array(incre_idx_list)}
+    for f in ("pred_labels", "pred_scores", "rel_pair_idxs", "pred_rel_scores", "pred_rel_labels"):
+        out[f] = r.get_field(f).numpy()
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print("%-24s MEET merge: %d rows, pair dtype %s" % (name, out["rel_pair_idxs"].shape[0], out["rel_pair_idxs"].dtype))
+
+
 def main():
     torch.set_num_threads(8)
     P, cfg, BoxList = import_reference()
+    run_postprocessor_meet(cfg, BoxList, "postmeet_vg_n10", 10, "VG")
+    run_postprocessor_meet(cfg, BoxList, "postmeet_gqa_n7", 7, "GQA")
     run_postprocessor(cfg, BoxList, "post_sgcls_ragged", [5, 1, 9], onehot=False)
     run_postprocessor(cfg, BoxList, "post_predcls_n36", [36], onehot=True)
     run_case(P, cfg, BoxList, "predcls_n10_l6h6", "predcls", 6, 6, [10], train=True)

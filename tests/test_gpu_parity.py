@@ -8,7 +8,8 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import golden_names, load_golden, load_post_golden, post_golden_names
+from conftest import (golden_names, load_golden, load_post_golden, load_postmeet_golden, post_golden_names,
+                      postmeet_golden_names)
 
 pytestmark = pytest.mark.gpu
 
@@ -274,3 +275,37 @@ def test_postprocessor_full_size_properties():
     k100, k101 = int(pairs[0][100, 0] * 64 + pairs[0][100, 1]), int(pairs[0][101, 0] * 64 + pairs[0][101, 1])
     if (post.last_triple_scores[0][key.index(k100)] == post.last_triple_scores[0][key.index(k101)]):
         assert key.index(k100) < key.index(k101)
+
+
+@pytest.mark.parametrize("name", postmeet_golden_names())
+def test_postprocessor_meet_golden_parity(name):
+    """HIP MEET merge (veto_postprocess_meet) vs the committed outputs of the reference's MEET branch."""
+    from oracle import veto_oracle as vo
+    from veto_amd.postprocess import PostProcessor
+    from veto_amd.structures import BoxList
+    dev = _dev()
+    g, rel, obj_logits, pairs, n = load_postmeet_golden(name)
+    incre = [int(x) for x in g["incre_idx_list"]]
+    post = PostProcessor(False, use_gt_box=True)
+    box = BoxList(torch.zeros(n, 4), (800, 600)).to(dev)
+    res = post(({k: torch.from_numpy(v).to(dev) for k, v in rel.items()}, [torch.from_numpy(obj_logits).to(dev)]),
+               [torch.from_numpy(pairs).to(dev)], [box], incre_idx_list=incre, ensemble=True)[0]
+    torch.cuda.synchronize()
+    ref = vo.postprocess_meet(rel, obj_logits, pairs, incre, len(incre))
+    assert np.array_equal(res.get_field("pred_labels").cpu().numpy(), g["pred_labels"])
+    assert np.abs(res.get_field("pred_scores").cpu().numpy() - g["pred_scores"]).max() <= 1e-6
+    assert res.get_field("rel_pair_idxs").dtype == torch.float32
+    # rows are (pair, group) items: compare on (pair, label, row sum pattern) where the order agrees
+    got_pairs = res.get_field("rel_pair_idxs").cpu().numpy()
+    same = (got_pairs == g["rel_pair_idxs"]).all(1) & (res.get_field("pred_rel_labels").cpu().numpy() == g["pred_rel_labels"])
+    ts = ref["triple_scores"].numpy()
+    if not same.all():
+        bad = np.nonzero(~same)[0]
+        assert np.abs(ts[bad][:, None] - ts[bad][None, :] + np.eye(len(bad))).min(1).max() <= 2e-6
+    assert same.mean() > 0.95
+    assert np.abs(res.get_field("pred_rel_scores").cpu().numpy()[same] - g["pred_rel_scores"][same]).max() <= 2e-6
+    got_ts = post.last_triple_scores[0].cpu().numpy()
+    assert (np.diff(got_ts) <= 0).all() and np.abs(np.sort(got_ts) - np.sort(ts)).max() <= 2e-6
+    with pytest.raises(ValueError):
+        post(({k: torch.from_numpy(v).to(dev) for k, v in rel.items()}, [torch.from_numpy(obj_logits).to(dev)] * 2),
+             [torch.from_numpy(pairs).to(dev)] * 2, [box, box], incre_idx_list=incre, ensemble=True)

@@ -109,7 +109,16 @@ struct PostArgs {
   float* triple;                 // workspace [n_pair]
   int32_t* label_tmp;            // workspace [n_pair]
   int32_t* perm;                 // workspace [n_pair]
+  int single_cnt;                // > 0: one segment of this many rows (MEET merge) instead of img_pair_off
+  int pair_mod;                  // > 0: row r refers to pair r % pair_mod (MEET: K copies of the pair list)
 };
+struct MeetGroup {               // one MEET head, passed by value
+  const float* logits;           // [n_pair, width], width = g + 2
+  int width;
+  int row0;                      // first row of this group in the merged list
+  int cols[104];                 // cols[c] = global class of the group's column c (cols[0] = 0), c < width - 1
+};
+hipError_t launch_postprocess_meet(PostArgs a, const MeetGroup* groups, int n_groups, hipStream_t s);
 int postprocess_max_pairs_per_image();
 hipError_t launch_postprocess(const PostArgs& a, hipStream_t s);
 

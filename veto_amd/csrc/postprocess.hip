@@ -72,14 +72,15 @@ __global__ __launch_bounds__(256) void rel_score_kernel(PostArgs a) {
   }
 }
 
-constexpr int kSortMax = 4096;
+constexpr int kSortMax = 16384;  // 128 KiB of LDS: 5 MEET groups x MAX_PROPOSAL_PAIR (2048) pairs fit
 
 // one workgroup per image: sort its pairs by (score descending, original index ascending)
 __global__ __launch_bounds__(1024) void segment_sort_kernel(PostArgs a) {
   __shared__ float s_key[kSortMax];
   __shared__ int s_idx[kSortMax];
   const int img = blockIdx.x;
-  const int p0 = a.img_pair_off[img], cnt = a.img_pair_off[img + 1] - p0;
+  const int p0 = a.single_cnt > 0 ? 0 : a.img_pair_off[img];
+  const int cnt = a.single_cnt > 0 ? a.single_cnt : a.img_pair_off[img + 1] - p0;
   int n2 = 1;
   while (n2 < cnt) n2 <<= 1;
   for (int i = threadIdx.x; i < n2; i += blockDim.x) {
@@ -115,14 +116,72 @@ __global__ __launch_bounds__(256) void gather_sorted_kernel(PostArgs a) {
   const int src = a.perm[p];
   for (int c = lane; c < a.n_rel_cls; c += 64) a.out_prob[(size_t)p * a.n_rel_cls + c] = a.prob_tmp[(size_t)src * a.n_rel_cls + c];
   if (lane == 0) {
-    a.out_pairs[2 * (size_t)p] = a.rel_pairs[2 * (size_t)src];
-    a.out_pairs[2 * (size_t)p + 1] = a.rel_pairs[2 * (size_t)src + 1];
+    const int psrc = a.pair_mod > 0 ? src % a.pair_mod : src;  // MEET: K copies of the same pair list
+    a.out_pairs[2 * (size_t)p] = a.rel_pairs[2 * (size_t)psrc];
+    a.out_pairs[2 * (size_t)p + 1] = a.rel_pairs[2 * (size_t)psrc + 1];
     a.out_labels[p] = a.label_tmp[src];
     if (a.out_triple) a.out_triple[p] = a.triple[src];
   }
 }
 
+// MEET group head (inference.py:346-372): softmax over the group's g+2 logits, the last ("other
+// group") column dropped, arg-max over columns 1..g (a group-local label), the g+1 probabilities
+// scattered into a zero num_rel_cls-wide row at columns [0] + the group's own classes.
+__global__ __launch_bounds__(256) void meet_rel_score_kernel(PostArgs a, MeetGroup grp) {
+  const int p = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (p >= a.n_pair) return;
+  const float* logit = grp.logits + (size_t)p * grp.width;
+  const size_t out_row = (size_t)grp.row0 + p;
+  float* prob = a.prob_tmp + out_row * a.n_rel_cls;
+  for (int c = lane; c < a.n_rel_cls; c += 64) prob[c] = 0.f;
+  float mx = -INFINITY;
+  for (int c = lane; c < grp.width; c += 64) mx = fmaxf(mx, logit[c]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  float sum = 0.f;
+  for (int c = lane; c < grp.width; c += 64) sum += expf(logit[c] - mx);
+  sum = wave_sum(sum);
+  const float inv = 1.f / sum;
+  float best = -1.f;
+  int best_cls = 0x7fffffff;
+  for (int c = lane; c < grp.width - 1; c += 64) {  // the last column is dropped
+    const float pr = expf(logit[c] - mx) * inv;
+    prob[grp.cols[c]] = pr;
+    if (c >= 1 && pr > best) { best = pr; best_cls = c; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ob = __shfl_xor(best, o, 64);
+    const int oc = __shfl_xor(best_cls, o, 64);
+    if (ob > best || (ob == best && oc < best_cls)) { best = ob; best_cls = oc; }
+  }
+  if (lane == 0) {
+    const float s0 = a.obj_scores[a.rel_pairs[2 * (size_t)p]];
+    const float s1 = a.obj_scores[a.rel_pairs[2 * (size_t)p + 1]];
+    a.triple[out_row] = best * s0 * s1;
+    a.label_tmp[out_row] = best_cls;
+  }
+}
+
 }  // namespace
+
+hipError_t launch_postprocess_meet(PostArgs a, const MeetGroup* groups, int n_groups, hipStream_t s) {
+  VETO_LAUNCH(obj_score_kernel, dim3((a.n_obj + 3) / 4), dim3(256), 0, s, a.obj_logits, a.n_obj, a.n_obj_cls, a.obj_scores, a.obj_pred);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  for (int k = 0; k < n_groups; ++k) {
+    VETO_LAUNCH(meet_rel_score_kernel, dim3((a.n_pair + 3) / 4), dim3(256), 0, s, a, groups[k]);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+  }
+  PostArgs m = a;  // the merged list: one "image" of n_groups * n_pair rows
+  m.single_cnt = n_groups * a.n_pair;
+  m.pair_mod = a.n_pair;
+  m.n_pair = m.single_cnt;
+  VETO_LAUNCH(segment_sort_kernel, dim3(1), dim3(1024), 0, s, m);
+  if ((e = hipGetLastError()) != hipSuccess) return e;
+  VETO_LAUNCH(gather_sorted_kernel, dim3((m.n_pair + 3) / 4), dim3(256), 0, s, m);
+  return hipGetLastError();
+}
 
 int postprocess_max_pairs_per_image() { return kSortMax; }
 

@@ -19,7 +19,7 @@ EXPORTS = [
     "veto_weight_info", "veto_load_weights", "veto_workspace_bytes", "veto_forward",
     "veto_enumerate_pairs", "veto_profile_enable", "veto_profile_collect", "veto_profile_entry",
     "veto_profile_reset", "veto_debug_gemm", "veto_debug_gemm_workspace_bytes",
-    "veto_postprocess", "veto_postprocess_workspace_bytes",
+    "veto_postprocess", "veto_postprocess_workspace_bytes", "veto_postprocess_meet",
 ]
 
 VETO_PRECISE, VETO_FAST = 0, 1
@@ -52,6 +52,13 @@ class VetoPostArgs(Structure):
     _fields_ = [(n, c_int32) for n in ("struct_size", "n_img", "n_obj", "n_pair", "n_rel_cls", "n_obj_cls",
                                        "max_pairs_per_image", "reserved0")] + \
                [(n, c_void_p) for n in ("rel_logits", "obj_logits", "rel_pairs", "img_obj_offset", "img_pair_offset",
+                                        "obj_scores", "obj_pred", "rel_prob_sorted", "rel_pairs_sorted",
+                                        "rel_labels_sorted", "triple_sorted")]
+
+
+class VetoPostMeetArgs(Structure):
+    _fields_ = [(n, c_int32) for n in ("struct_size", "n_obj", "n_pair", "n_groups", "n_rel_cls", "n_obj_cls")] + \
+               [(n, c_void_p) for n in ("group_logits", "group_widths", "incre_idx_list", "obj_logits", "rel_pairs",
                                         "obj_scores", "obj_pred", "rel_prob_sorted", "rel_pairs_sorted",
                                         "rel_labels_sorted", "triple_sorted")]
 
@@ -100,6 +107,7 @@ def load_library():
     lib.veto_postprocess_workspace_bytes.argtypes = [c_int32, c_int32]
     lib.veto_postprocess_workspace_bytes.restype = c_size_t
     lib.veto_postprocess.argtypes = [c_void_p, POINTER(VetoPostArgs), c_void_p, c_size_t]
+    lib.veto_postprocess_meet.argtypes = [c_void_p, POINTER(VetoPostMeetArgs), c_void_p, c_size_t]
     _LIB = lib
     return lib
 

@@ -5,8 +5,11 @@ Mirrors the vanilla, GT-box branch of the reference's PostProcessor
 `forward(x, rel_pair_idxs, boxes)` call, and the same BoxList fields on the results
 (`pred_labels`, `pred_scores`, `rel_pair_idxs`, `pred_rel_scores`, `pred_rel_labels`).  The
 arithmetic (softmax, foreground max, triple score, per-image descending sort, gather) runs in
-libveto_amd.so (veto_postprocess).  sgdet decoding (per-class NMS, inference.py:413-418), attributes
-and the MEET merge (inference.py:93-397) are not built; they raise."""
+libveto_amd.so (veto_postprocess).  When the relation logits are the MEET dict of group heads
+(ENSEMBLE_LEARNING.ENABLED with EXPERT_GROUP False), the MEET merge branch (inference.py:284-397) runs
+through veto_postprocess_meet with the reference's quirks kept: one image per call, group-local
+labels, float pair indices.  sgdet decoding (per-class NMS, inference.py:413-418), attributes and the
+EXPERT_GROUP voting branch (inference.py:93-283) are not built; they raise."""
 import ctypes
 
 import torch
@@ -31,8 +34,8 @@ class PostProcessor(nn.Module):
             raise NotImplementedError("veto_amd.PostProcessor: attribute head is outside the VETO path")
         if not self.use_gt_box:
             raise NotImplementedError("veto_amd.PostProcessor: sgdet decoding (per-class NMS) is not built")
-        if isinstance(relation_logits, dict) or ensemble:
-            raise NotImplementedError("veto_amd.PostProcessor: MEET group merge (inference.py:284-397) is not built")
+        if isinstance(relation_logits, dict):
+            return self._forward_meet(relation_logits, refine_logits, rel_pair_idxs, boxes, incre_idx_list)
         rel = torch.cat(list(relation_logits), 0) if isinstance(relation_logits, (list, tuple)) else relation_logits
         obj = torch.cat(list(refine_logits), 0) if isinstance(refine_logits, (list, tuple)) else refine_logits
         device = rel.device
@@ -86,6 +89,57 @@ class PostProcessor(nn.Module):
             box.add_field("pred_rel_labels", lab)
             results.append(box)
         return results
+
+
+    def _forward_meet(self, relation_logits, refine_logits, rel_pair_idxs, boxes, incre_idx_list):
+        if incre_idx_list is None:
+            raise ValueError("the MEET merge needs incre_idx_list (4th element of the predictor's return tuple)")
+        if len(boxes) != 1:
+            raise ValueError("the MEET merge (inference.py:303-306) pairs the batch-wide group logits with the first "
+                             "image only; call it with one image per batch, got %d" % len(boxes))
+        lib = native.load_library()
+        keys = ["group_%d" % k for k in range(len(relation_logits))]
+        device = relation_logits[keys[0]].device
+        if device.type != "cuda":
+            raise RuntimeError("veto_amd.PostProcessor runs only on a HIP device (got %s)" % device)
+        f32 = dict(device=device, dtype=torch.float32)
+        groups = [relation_logits[k].detach().to(**f32).contiguous() for k in keys]
+        obj = (refine_logits[0] if isinstance(refine_logits, (list, tuple)) else refine_logits).detach().to(**f32).contiguous()
+        pairs = rel_pair_idxs[0].reshape(-1, 2).to(device=device, dtype=torch.int64).contiguous()
+        n_obj, n_pair, K, n_rel = obj.shape[0], pairs.shape[0], len(groups), len(incre_idx_list)
+        total = K * n_pair
+        out = {"obj_scores": torch.empty(n_obj, **f32), "obj_pred": torch.empty(n_obj, dtype=torch.int64, device=device),
+               "prob": torch.empty((total, n_rel), **f32), "pairs": torch.empty((total, 2), dtype=torch.int64, device=device),
+               "labels": torch.empty(total, dtype=torch.int64, device=device), "triple": torch.empty(total, **f32)}
+        need = lib.veto_postprocess_workspace_bytes(total, n_rel)
+        if self._workspace is None or self._workspace.numel() < need or self._workspace.device != device:
+            self._workspace = torch.empty(need, dtype=torch.uint8, device=device)
+        ptrs = (ctypes.c_void_p * K)(*[g.data_ptr() for g in groups])
+        widths = (ctypes.c_int32 * K)(*[g.shape[1] for g in groups])
+        incre = (ctypes.c_int32 * n_rel)(*[int(x) for x in incre_idx_list])
+        a = native.VetoPostMeetArgs()
+        a.struct_size = ctypes.sizeof(native.VetoPostMeetArgs)
+        a.n_obj, a.n_pair, a.n_groups, a.n_rel_cls, a.n_obj_cls = n_obj, n_pair, K, n_rel, obj.shape[1]
+        a.group_logits = ctypes.cast(ptrs, ctypes.c_void_p)
+        a.group_widths = ctypes.cast(widths, ctypes.c_void_p)
+        a.incre_idx_list = ctypes.cast(incre, ctypes.c_void_p)
+        a.obj_logits, a.rel_pairs = obj.data_ptr(), pairs.data_ptr()
+        a.obj_scores, a.obj_pred = out["obj_scores"].data_ptr(), out["obj_pred"].data_ptr()
+        a.rel_prob_sorted, a.rel_pairs_sorted = out["prob"].data_ptr(), out["pairs"].data_ptr()
+        a.rel_labels_sorted, a.triple_sorted = out["labels"].data_ptr(), out["triple"].data_ptr()
+        stream = torch.cuda.current_stream(device)
+        native.check(lib.veto_postprocess_meet(ctypes.c_void_p(stream.cuda_stream), ctypes.byref(a),
+                                               ctypes.c_void_p(self._workspace.data_ptr()), self._workspace.numel()))
+        for t in groups + [obj, pairs]:
+            t.record_stream(stream)
+        self.last_triple_scores = [out["triple"]]
+        box = boxes[0]
+        box.add_field("pred_labels", out["obj_pred"])
+        box.add_field("pred_scores", out["obj_scores"])
+        box.add_field("rel_pair_idxs", out["pairs"].to(torch.float32))  # torch.zeros(total, 2) in the reference (:381)
+        box.add_field("pred_rel_scores", out["prob"])
+        box.add_field("pred_rel_labels", out["labels"])                 # group-local labels, as the reference (:388)
+        return [box]
 
 
 def make_roi_relation_post_processor(cfg):
