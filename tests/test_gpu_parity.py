@@ -309,3 +309,37 @@ def test_postprocessor_meet_golden_parity(name):
     with pytest.raises(ValueError):
         post(({k: torch.from_numpy(v).to(dev) for k, v in rel.items()}, [torch.from_numpy(obj_logits).to(dev)] * 2),
              [torch.from_numpy(pairs).to(dev)] * 2, [box, box], incre_idx_list=incre, ensemble=True)
+
+
+def test_relation_head_chain_against_oracle_chain():
+    """proposals + ROI maps -> pairs -> predictor -> PostProcessor, all on the device, against the
+    oracle's predictor + postprocess chain (predcls: one-hot +-1000 object logits, obj scores == 1)."""
+    from oracle import veto_oracle as vo
+    from veto_amd import synth, testing
+    from veto_amd.relation_head import VETORelationHead
+    dev = _dev()
+    num_objs = [8, 5]
+    sd = synth.predictor_state_dict(3, layers=2)
+    batch = synth.synthetic_batch(13, 2, num_objs)
+    cfg = testing.make_config(2, 8)
+    head = VETORelationHead(cfg)
+    head.predictor = testing.make_predictor(cfg, sd, dev)
+    head.eval()
+    props = testing.make_proposals(batch, "predcls", dev)
+    _, result, losses = head(props, torch.from_numpy(batch["roi_features"]).to(dev),
+                             torch.from_numpy(batch["roi_depth_features"]).to(dev))
+    torch.cuda.synchronize()
+    assert losses == {}
+    logits, _, _ = vo.forward(sd, vo.OracleConfig(layers=2, heads=8), batch)
+    pairs = [vo.enumerate_test_pairs(n) for n in num_objs]
+    onehot = np.full((sum(num_objs), 151), -1000.0, dtype=np.float32)
+    onehot[np.arange(sum(num_objs)), batch["labels"]] = 1000.0
+    ref = vo.postprocess(logits.numpy(), onehot, pairs, num_objs)
+    for r, o in zip(result, ref):
+        assert torch.equal(r.get_field("pred_labels").cpu(), o["pred_labels"])
+        assert (r.get_field("pred_scores").cpu() - 1).abs().max() < 1e-6
+        got_p, ref_p = r.get_field("rel_pair_idxs").cpu().numpy(), o["rel_pair_idxs"].numpy()
+        same = (got_p == ref_p).all(1)
+        assert same.mean() > 0.9   # near-ties (logit noise 3e-5) may swap neighbours
+        assert np.abs(r.get_field("pred_rel_scores").cpu().numpy()[same] - o["pred_rel_scores"].numpy()[same]).max() < 1e-4
+        assert np.array_equal(r.get_field("pred_rel_labels").cpu().numpy()[same], o["pred_rel_labels"].numpy()[same])

@@ -1,0 +1,63 @@
+"""Eval-time glue of the relation head around the HIP predictor, for the VETO predictors.
+
+Mirrors the caller of the hot path, `ROIRelationHead.forward`
+(pysgg/modeling/roi_heads/relation_head/relation_head.py:90-248), for the branch VETO takes in
+test mode with GT boxes:
+  :104-111  predcls: `predict_logits` overloaded with +-1000 one-hots of the GT labels
+            (utils_motifs.py:92-107), `pred_scores` = 1, `pred_labels` = labels
+  :134      rel_pair_idxs = samp_processor.prepare_test_pairs(device, proposals)
+  :140-141  ROI feature extraction (VETOFeatureExtractor / ROIAlign) -- NOT part of this module:
+            the pooled RGB / depth ROI maps are an input
+  :196-203  predictor(proposals, rel_pair_idxs, rel_labels, logger, roi_features=, roi_depth_features=)
+  :229-230  object refine logits = the proposals' `predict_logits`
+  :241-243  post_processor((relation_logits, obj_refine_logits), rel_pair_idxs, proposals, incre_idx_list=...)
+Everything numeric runs in libveto_amd.so; this file only moves fields around."""
+import torch
+from torch import nn
+
+from . import registry
+from .pairs import prepare_test_pairs
+from .postprocess import make_roi_relation_post_processor
+
+
+def to_onehot(vec, num_classes, fill=1000.0):
+    """[n, num_classes] float tensor with +fill at vec[i] and -fill elsewhere (utils_motifs.py:92-107)."""
+    out = torch.full((vec.shape[0], num_classes), -fill, dtype=torch.float32, device=vec.device)
+    out[torch.arange(vec.shape[0], device=vec.device), vec.long()] = fill
+    return out
+
+
+class VETORelationHead(nn.Module):
+    def __init__(self, cfg, in_channels=512):
+        super().__init__()
+        self.cfg = cfg
+        rh = cfg.MODEL.ROI_RELATION_HEAD
+        if rh.PREDICTOR not in ("VETOPredictor", "VETOPredictor_MEET"):
+            raise ValueError("VETORelationHead only drives the VETO predictors, got %r" % (rh.PREDICTOR,))
+        if not rh.USE_GT_BOX:
+            raise NotImplementedError("sgdet (detected boxes) is outside the built path")
+        self.mode = "predcls" if rh.USE_GT_OBJECT_LABEL else "sgcls"
+        self.predictor = registry.make_roi_relation_predictor(cfg, in_channels)
+        self.post_processor = make_roi_relation_post_processor(cfg)
+        self.num_obj_cls = self.predictor.num_obj_cls
+        self.max_proposal_pairs = int(getattr(rh, "MAX_PROPOSAL_PAIR", 2048))
+
+    def forward(self, proposals, roi_features, roi_depth_features, logger=None):
+        """proposals: list[BoxList] on the HIP device; roi_features / roi_depth_features: [sum N, 256, 8, 8].
+        Returns (roi_features, result, {}) like the reference's test branch (:243)."""
+        if self.training:
+            raise NotImplementedError("veto_amd: the training branch (pair sampling, losses, backward) is not built")
+        device = roi_features.device
+        if self.mode == "predcls":
+            for p in proposals:
+                labels = p.get_field("labels")
+                p.add_field("predict_logits", to_onehot(labels, self.num_obj_cls))
+                p.add_field("pred_scores", torch.ones(len(labels), device=device))
+                p.add_field("pred_labels", labels.to(device))
+        rel_pair_idxs = prepare_test_pairs(device, proposals, self.max_proposal_pairs)
+        obj_dists, relation_logits, add_losses, incre_idx_list, _, _ = self.predictor(
+            proposals, rel_pair_idxs, None, logger, roi_features=roi_features, roi_depth_features=roi_depth_features)
+        obj_refine_logits = [p.get_field("predict_logits") for p in proposals]
+        result = self.post_processor((relation_logits, obj_refine_logits), rel_pair_idxs, proposals,
+                                     incre_idx_list=incre_idx_list, ensemble=isinstance(relation_logits, dict))
+        return roi_features, result, {}
