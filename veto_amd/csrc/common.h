@@ -49,7 +49,7 @@ __device__ __forceinline__ float wave_sum(float v) {
 // the ~30-instruction libm erff: the FeedForward epilogue applies it to 96 values per lane.
 __device__ __forceinline__ float gelu_erf(float x) {
   const float z = fabsf(x) * 0.70710678118654752440f;
-  const float t = __frcp_rn(1.0f + 0.3275911f * z);
+  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);  // raw v_rcp_f32 (1 ulp); __frcp_rn expands to a 10-instruction IEEE division
   const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
   const float erf_abs = 1.0f - poly * __expf(-z * z);
   return 0.5f * x * (1.0f + copysignf(erf_abs, x));
