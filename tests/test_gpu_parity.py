@@ -343,3 +343,53 @@ def test_relation_head_chain_against_oracle_chain():
         assert same.mean() > 0.9   # near-ties (logit noise 3e-5) may swap neighbours
         assert np.abs(r.get_field("pred_rel_scores").cpu().numpy()[same] - o["pred_rel_scores"].numpy()[same]).max() < 1e-4
         assert np.array_equal(r.get_field("pred_rel_labels").cpu().numpy()[same], o["pred_rel_labels"].numpy()[same])
+
+
+def test_repeated_runs_are_bit_identical():
+    """The GEMM's LDS-DMA / barrier protocol has no data race: 25 back-to-back forwards at full size,
+    interleaved with an unrelated memory-bound kernel, give bit-identical logits every time."""
+    from veto_amd import synth, testing
+    dev = _dev()
+    sd = synth.predictor_state_dict(0, layers=4)
+    batch = synth.synthetic_batch(7, 12, 36)
+    model = testing.make_predictor(testing.make_config(4, 8), sd, dev)
+    out, pairs = _run(model, batch, "predcls", dev)
+    first = torch.cat(list(out[1])).clone()
+    junk = torch.empty(64 << 20, device=dev)
+    for i in range(25):
+        junk.normal_()                                   # perturbs cache state and timing between runs
+        out, _ = _run(model, batch, "predcls", dev, pairs=pairs)
+        assert torch.equal(torch.cat(list(out[1])), first), i
+
+
+def test_plain_gemm_variant_matches_persistent_variant(tmp_path):
+    """VETO_GEMM_VARIANT=plain (homogeneous waves, one workgroup per tile) is the A/B twin of the
+    persistent loader-wave kernel: same MFMA order, so bit-identical logits.  The variant is read once
+    per process, hence the subprocess."""
+    import subprocess, sys, os
+    script = tmp_path / "run_variant.py"
+    script.write_text(
+        "import sys, torch, numpy as np\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "from conftest import load_golden\n"
+        "from veto_amd import testing\n"
+        "from veto_amd.pairs import prepare_test_pairs\n"
+        "g, sd, batch = load_golden('predcls_n36_l4h8')\n"
+        "dev = torch.device('cuda:0')\n"
+        "m = testing.make_predictor(testing.make_config(4, 8), sd, dev)\n"
+        "props = testing.make_proposals(batch, 'predcls', dev)\n"
+        "pairs = prepare_test_pairs(dev, props)\n"
+        "with torch.no_grad():\n"
+        "    out = m(props, pairs, None, None, roi_features=torch.from_numpy(batch['roi_features']).to(dev),\n"
+        "            roi_depth_features=torch.from_numpy(batch['roi_depth_features']).to(dev))\n"
+        "np.save(sys.argv[1], out[1][0].cpu().numpy())\n" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                          os.path.dirname(os.path.abspath(__file__))))
+    res = {}
+    for variant in ("ps", "plain"):
+        out = str(tmp_path / (variant + ".npy"))
+        env = dict(os.environ, VETO_GEMM_VARIANT=variant)
+        subprocess.run([sys.executable, str(script), out], check=True, env=env, timeout=600)
+        res[variant] = np.load(out)
+    assert np.array_equal(res["ps"], res["plain"])
+    g, _, _ = load_golden("predcls_n36_l4h8")
+    assert np.abs(res["plain"] - g["rel_dists"]).max() <= LOGIT_TOL
