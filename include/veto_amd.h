@@ -163,6 +163,34 @@ typedef struct veto_post_meet_args {
 /* workspace: veto_postprocess_workspace_bytes(n_groups * n_pair, n_rel_cls) */
 int veto_postprocess_meet(void* stream, const veto_post_meet_args_t* args, void* workspace, size_t workspace_bytes);
 
+/* EXPERT_GROUP voting branch (ENSEMBLE_LEARNING.EXPERT_GROUP True, the defaults.py:864 default),
+ * inference.py:93-283, for ONE image: every group has three expert heads ('group_<k>1..3'); a pair's row
+ * for group k is kept when two experts ('C', consensus) or all three ('U', unanimous) pick the same
+ * class; kept rows carry the averaged score / probabilities of the agreeing experts.  Outputs are sized
+ * for n_groups*n_pair rows; the first *kept_count rows (score order) are the result, the rest is padding. */
+typedef struct veto_post_vote_args {
+  int32_t struct_size;
+  int32_t n_obj, n_pair, n_groups;
+  int32_t n_rel_cls, n_obj_cls;
+  int32_t voting;                     /* 0 = 'C' (two of three agree), 1 = 'U' (all agree): ENSEMBLE_LEARNING.VOTING */
+  int32_t reserved0;
+  const float* const* expert_logits;  /* HOST array of 3*n_groups device pointers, [3*k + e] = 'group_<k><e+1>' */
+  const int32_t* group_widths;        /* HOST array [n_groups]: g_k + 2 */
+  const int32_t* incre_idx_list;      /* HOST array [n_rel_cls] */
+  const float* obj_logits;            /* device [n_obj, n_obj_cls] */
+  const int64_t* rel_pairs;           /* device [n_pair, 2] */
+  float* obj_scores;                  /* out device [n_obj] */
+  int64_t* obj_pred;                  /* out device [n_obj] */
+  float* rel_prob_sorted;             /* out device [n_groups*n_pair, n_rel_cls] */
+  int64_t* rel_pairs_sorted;          /* out device [n_groups*n_pair, 2] */
+  int64_t* rel_labels_sorted;         /* out device [n_groups*n_pair] (group-local labels) */
+  float* triple_sorted;               /* optional out device [n_groups*n_pair]; -1 marks padding rows */
+  int32_t* kept_count;                /* out device [1] */
+} veto_post_vote_args_t;
+
+/* workspace: veto_postprocess_workspace_bytes(n_groups * n_pair, n_rel_cls) */
+int veto_postprocess_vote(void* stream, const veto_post_vote_args_t* args, void* workspace, size_t workspace_bytes);
+
 /* ---- measurement hooks (bench.py): per-kernel device time from hipEvents on `stream` ---------- */
 int veto_profile_enable(veto_handle_t h, int32_t on);
 /* Synchronises the recorded events; returns the number of distinct kernels. */

@@ -32,10 +32,11 @@ def _t(x, dtype):
 
 class OracleConfig:
     def __init__(self, layers=6, heads=6, dim=576, patch=2, mode="predcls", meet_groups=None,
-                 prefix=""):
+                 prefix="", experts=0):
         self.layers, self.heads, self.dim, self.patch = layers, heads, dim, patch
         self.mode = mode
         self.meet_groups = meet_groups  # list of group sizes, or None for the vanilla head
+        self.experts = experts          # 3 with ENSEMBLE_LEARNING.EXPERT_GROUP (:3717-3723), else 0
         self.prefix = prefix            # "model." for VETOPredictor_MEET state dicts
 
 
@@ -178,6 +179,10 @@ def forward(sd, cfg, batch, rel_pair_idxs=None, dtype=torch.float32, return_inte
     if cfg.meet_groups is None:
         Wh = _t(sd[pre + "rel_out.weight"], dtype)
         bh = _t(sd[pre + "rel_out.bias"], dtype)
+    elif cfg.experts:   # :3833-3837 rel_out_group[j][k]; columns expert-major, then group
+        names = [pre + "rel_out_group.%d.%d" % (e, k) for e in range(cfg.experts) for k in range(len(cfg.meet_groups))]
+        Wh = torch.cat([_t(sd[n + ".weight"], dtype) for n in names])
+        bh = torch.cat([_t(sd[n + ".bias"], dtype) for n in names])
     else:
         Wh = torch.cat([_t(sd[pre + "rel_out.%d.weight" % k], dtype) for k in range(len(cfg.meet_groups))])
         bh = torch.cat([_t(sd[pre + "rel_out.%d.bias" % k], dtype) for k in range(len(cfg.meet_groups))])
@@ -270,6 +275,70 @@ def postprocess_meet(rel_logits_by_group, obj_logits, rel_pair_idx, incre_idx_li
         labels.append(rel_class)
         probs.append(full)
         prs.append(pairs)
+    triple, label, prob, pr = torch.cat(triples), torch.cat(labels), torch.cat(probs), torch.cat(prs)
+    order = torch.sort(triple, descending=True, stable=True)[1]
+    return {"pred_scores": obj_scores, "pred_labels": obj_pred, "rel_pair_idxs": pr[order].to(torch.float32),
+            "pred_rel_scores": prob[order], "pred_rel_labels": label[order], "triple_scores": triple[order]}
+
+
+def postprocess_vote(rel_logits, obj_logits, rel_pair_idx, incre_idx_list, num_rel_cls, voting="C",
+                     dtype=torch.float32):
+    """EXPERT_GROUP voting branch of PostProcessor.forward, inference.py:93-283, one image.
+    rel_logits: dict 'group_<k><e>' (k = group 0.., e = expert 1..3) of [P, g_k+2] logits.
+    Per group, per expert e: prob_e = softmax(logit_e)[:, :-1]; (score_e, cls_e) = max over columns 1..
+    (+1); t_e = score_e * obj_s * obj_o (:178-190; `chosen_idx_bool` is always true once the last column
+    is dropped).  agree_ab = cls_a == cls_b for the expert pairs (0,1), (1,2), (0,2) (:192-199).
+      'C' (two agree, :211-255): pair means t_ab = (t_a + t_b)/2 and p_ab = (p_a + p_b)/2 -- EXCEPT that
+          the (1,2) probability mean is built from expert 1 twice (:224-226), i.e. p_12 = p_1 --; a row is
+          kept if any pair agrees; its score / probabilities are the sum over the agreeing pairs divided
+          by their count, its label the agreed class.
+      'U' (all agree, :257-261): kept if all three pairs agree; score / probabilities are the three-way
+          means (sum / 3), label = the experts' common class.
+    Kept rows of all groups are concatenated in (group, pair) order, each group's g+1 probabilities
+    scattered to columns [0] + its own classes of a zero [*, num_rel_cls] row, and sorted by score
+    descending (:263-283).  Pair indices come out as a FLOAT tensor, labels are group-local."""
+    assert voting in ("C", "U")
+    obj_logits = _t(obj_logits, dtype)
+    pairs = torch.as_tensor(np.asarray(rel_pair_idx)).long()
+    obj_prob = torch.softmax(obj_logits, -1)
+    obj_prob[:, 0] = 0
+    obj_scores, obj_pred = obj_prob[:, 1:].max(dim=1)
+    obj_pred = obj_pred + 1
+    s0, s1 = obj_scores[pairs[:, 0]], obj_scores[pairs[:, 1]]
+    K = len(rel_logits) // 3
+    triples, labels, probs, prs = [], [], [], []
+    for k in range(K):
+        p, c, t = [], [], []
+        for e in range(3):
+            prob = torch.softmax(_t(rel_logits["group_%d%d" % (k, e + 1)], dtype), -1)[:, :-1]
+            sc, cl = prob[:, 1:].max(dim=1)
+            p.append(prob)
+            c.append(cl + 1)
+            t.append(sc * s0 * s1)
+        agree = [c[0] == c[1], c[1] == c[2], c[0] == c[2]]
+        if voting == "C":
+            t_pair = torch.stack([(t[0] + t[1]) / 2, (t[1] + t[2]) / 2, (t[0] + t[2]) / 2], 1)
+            p_pair = torch.stack([(p[0] + p[1]) / 2, (p[1] + p[1]) / 2, (p[0] + p[2]) / 2], 1)
+            mask = torch.stack(agree, 1)
+            cnt = mask.sum(1)
+            keep = cnt > 0
+            triple = (t_pair * mask).sum(1) / cnt
+            prob = (p_pair * mask.unsqueeze(2)).sum(1) / cnt.unsqueeze(1)
+            label = torch.zeros_like(c[0])
+            for cl, ag in zip(c, agree):
+                label[ag] = cl[ag]
+        else:
+            keep = agree[0] & agree[1] & agree[2]
+            triple = (t[0] + t[1] + t[2]) / 3
+            prob = (p[0] + p[1] + p[2]) / 3
+            label = c[2]
+        cols = [0] + [cc for cc, x in enumerate(incre_idx_list) if x == k + 1]
+        full = torch.zeros(int(keep.sum()), num_rel_cls, dtype=dtype)
+        full[:, cols] = prob[keep]
+        triples.append(triple[keep])
+        labels.append(label[keep])
+        probs.append(full)
+        prs.append(pairs[keep])
     triple, label, prob, pr = torch.cat(triples), torch.cat(labels), torch.cat(probs), torch.cat(prs)
     order = torch.sort(triple, descending=True, stable=True)[1]
     return {"pred_scores": obj_scores, "pred_labels": obj_pred, "rel_pair_idxs": pr[order].to(torch.float32),

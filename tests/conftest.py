@@ -30,6 +30,29 @@ def postmeet_golden_names():
     return sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith(".npz") and f.startswith("postmeet_"))
 
 
+def postvote_golden_names():
+    return sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith(".npz") and f.startswith("postvote_"))
+
+
+def load_postvote_golden(name):
+    """Returns (fixture, {group_<k><e>: logits}, obj_logits, pairs, n) with the inputs regenerated."""
+    from oracle import veto_oracle as vo
+    from veto_amd import synth
+    g = dict(np.load(os.path.join(GOLDEN_DIR, name + ".npz")))
+    n = int(g["n"])
+    sizes = [int(x) for x in g["group_sizes"]]
+    n_objc = 151 if str(g["dataset"]) == "VG" else 201
+    P = n * (n - 1)
+    rel = {}
+    for k, gk in enumerate(sizes):
+        base = synth.normal(29, "vote.base_%d" % k, (P, gk + 2), 0.0, 1.5)
+        for e in range(3):
+            own = synth.normal(29, "vote.group_%d%d" % (k, e + 1), (P, gk + 2), 0.0, 1.0)
+            rel["group_%d%d" % (k, e + 1)] = (base + own).astype(np.float32)
+    obj_logits = synth.normal(29, "vote.obj_logits", (n, n_objc), 0.0, 3.0)
+    return g, rel, obj_logits, vo.enumerate_test_pairs(n), n
+
+
 def load_postmeet_golden(name):
     """Returns (fixture, {group_k: logits}, obj_logits, pairs, n) with the inputs regenerated."""
     from oracle import veto_oracle as vo
@@ -73,7 +96,8 @@ def load_golden(name):
     num_objs = [int(x) for x in g["num_objs"]]
     if int(g["meet"]):
         groups = [int(x) for x in g["group_sizes"]]
-        sd = synth.meet_state_dict(0, groups, layers=layers, num_obj_cls=n_obj)
+        sd = synth.meet_state_dict(0, groups, layers=layers, num_obj_cls=n_obj,
+                                   experts=3 if int(g.get("experts", 0)) else 0)
     else:
         sd = synth.predictor_state_dict(0, layers=layers, num_obj_cls=n_obj, num_rel_cls=n_rel)
     batch = synth.synthetic_batch(7, len(num_objs), num_objs, num_obj_cls=n_obj)

@@ -156,14 +156,15 @@ def load_sd(module, sd_np):
 
 
 def run_case(P, cfg, BoxList, name, mode, layers, heads, num_objs, meet=False, dataset="VG",
-             train=False):
+             train=False, experts=False):
     n_obj, n_rel = configure(P, cfg, mode, layers, heads,
                              "VETOPredictor_MEET" if meet else "VETOPredictor", dataset)
+    cfg.ENSEMBLE_LEARNING.EXPERT_GROUP = bool(experts)   # defaults.py:864 default True: 3 experts per group
     torch.manual_seed(0)
     if meet:
         model = P.VETOPredictor_MEET(cfg, 512)
         groups = list(model.max_group_element_number_list)
-        sd = synth.meet_state_dict(0, groups, layers=layers, num_obj_cls=n_obj)
+        sd = synth.meet_state_dict(0, groups, layers=layers, num_obj_cls=n_obj, experts=3 if experts else 0)
     else:
         model = P.VETOPredictor(cfg, 512)
         sd = synth.predictor_state_dict(0, layers=layers, num_obj_cls=n_obj, num_rel_cls=n_rel)
@@ -175,7 +176,7 @@ def run_case(P, cfg, BoxList, name, mode, layers, heads, num_objs, meet=False, d
     rgb = torch.from_numpy(batch["roi_features"])
     dep = torch.from_numpy(batch["roi_depth_features"])
     out = {"layers": layers, "heads": heads, "num_objs": np.array(batch["num_objs"]),
-           "mode": mode, "dataset": dataset, "meet": int(meet)}
+           "mode": mode, "dataset": dataset, "meet": int(meet), "experts": int(bool(experts))}
     with torch.no_grad():
         res = model(props, pairs, None, None, roi_features=rgb, roi_depth_features=dep)
     obj_dists, rel_dists = res[0], res[1]
@@ -214,7 +215,7 @@ def run_case(P, cfg, BoxList, name, mode, layers, heads, num_objs, meet=False, d
     path = os.path.join(HERE, name + ".npz")
     np.savez_compressed(path, **out)
     sz = os.path.getsize(path)
-    key = "rel_dists" if not meet else "rel_group_0"
+    key = "rel_dists" if not meet else ("rel_group_01" if experts else "rel_group_0")
     print("%-24s %s %s  |max|=%.3f  %d bytes" % (name, mode, out[key].shape, np.abs(out[key]).max(), sz))
 
 
@@ -284,9 +285,64 @@ def run_postprocessor_meet(cfg, BoxList, name, n, dataset):
     print("%-24s MEET merge: %d rows, pair dtype %s" % (name, out["rel_pair_idxs"].shape[0], out["rel_pair_idxs"].dtype))
 
 
+def run_postprocessor_vote(cfg, BoxList, name, n, dataset, voting):
+    """The reference's EXPERT_GROUP voting branch (inference.py:93-283): three experts per group,
+    VOTING 'C' (two of three agree) or 'U' (all agree), on portable-RNG logits.  Expert logits share a
+    common component so that all agreement patterns (none / one pair / all) occur.  Tensor.cuda is
+    patched to the identity as in run_postprocessor_meet."""
+    from pysgg.modeling.roi_heads.relation_head.inference import make_roi_relation_post_processor
+    from SHA_GCL_extra.group_chosen_function import get_group_splits
+    from SHA_GCL_extra.extra_function_utils import get_current_predicate_idx
+    cfg.MODEL.ROI_RELATION_HEAD.USE_GT_BOX = True
+    cfg.ENSEMBLE_LEARNING.ENABLED = True
+    cfg.ENSEMBLE_LEARNING.EXPERT_GROUP = True
+    cfg.ENSEMBLE_LEARNING.VOTING = voting
+    cfg.ENSEMBLE_LEARNING.TYPE = ["group"]
+    cfg.GLOBAL_SETTING.DATASET_CHOICE = dataset
+    cfg.MODEL.ATTRIBUTE_ON = False
+    post = make_roi_relation_post_processor(cfg).eval()
+    stage_list, sizes = get_group_splits(dataset, "divide4")
+    incre_idx_list = get_current_predicate_idx(stage_list, 0.1, dataset)[0]
+    n_objc = 151 if dataset == "VG" else 201
+    P_ = n * (n - 1)
+    rel = {}
+    for k, g in enumerate(sizes):
+        base = synth.normal(29, "vote.base_%d" % k, (P_, g + 2), 0.0, 1.5)
+        for e in range(3):
+            own = synth.normal(29, "vote.group_%d%d" % (k, e + 1), (P_, g + 2), 0.0, 1.0)
+            rel["group_%d%d" % (k, e + 1)] = torch.from_numpy((base + own).astype(np.float32))
+    obj_logits = torch.from_numpy(synth.normal(29, "vote.obj_logits", (n, n_objc), 0.0, 3.0))
+    pairs = test_pairs([n])
+    boxes = [BoxList(torch.zeros(n, 4), (800, 600), mode="xyxy")]
+    orig = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        with torch.no_grad():
+            res = post((rel, [obj_logits]), pairs, boxes, incre_idx_list=incre_idx_list, ensemble=True)
+    finally:
+        torch.Tensor.cuda = orig
+    r = res[0]
+    out = {"n": n, "dataset": dataset, "voting": voting, "group_sizes": np.array(sizes),
+           "incre_idx_list": np.array(incre_idx_list)}
+    for f in ("pred_labels", "pred_scores", "rel_pair_idxs", "pred_rel_scores", "pred_rel_labels"):
+        out[f] = r.get_field(f).numpy()
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print("%-24s expert voting %s: %d of %d rows kept" % (name, voting, out["rel_pair_idxs"].shape[0], len(sizes) * P_))
+
+
 def main():
     torch.set_num_threads(8)
     P, cfg, BoxList = import_reference()
+    if os.environ.get("GOLDEN_ONLY") == "experts":   # regenerate only the EXPERT_GROUP fixtures
+        run_postprocessor_vote(cfg, BoxList, "postvote_vg_c_n10", 10, "VG", "C")
+        run_postprocessor_vote(cfg, BoxList, "postvote_vg_u_n10", 10, "VG", "U")
+        run_postprocessor_vote(cfg, BoxList, "postvote_gqa_c_n7", 7, "GQA", "C")
+        run_case(P, cfg, BoxList, "meetx_n10_l4h8", "predcls", 4, 8, [10], meet=True, experts=True)
+        return
+    run_postprocessor_vote(cfg, BoxList, "postvote_vg_c_n10", 10, "VG", "C")
+    run_postprocessor_vote(cfg, BoxList, "postvote_vg_u_n10", 10, "VG", "U")
+    run_postprocessor_vote(cfg, BoxList, "postvote_gqa_c_n7", 7, "GQA", "C")
+    run_case(P, cfg, BoxList, "meetx_n10_l4h8", "predcls", 4, 8, [10], meet=True, experts=True)
     run_postprocessor_meet(cfg, BoxList, "postmeet_vg_n10", 10, "VG")
     run_postprocessor_meet(cfg, BoxList, "postmeet_gqa_n7", 7, "GQA")
     run_postprocessor(cfg, BoxList, "post_sgcls_ragged", [5, 1, 9], onehot=False)

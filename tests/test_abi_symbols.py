@@ -31,6 +31,19 @@ def test_struct_sizes_match_the_header_layout():
     assert ctypes.sizeof(native.VetoConfig) == 52
     assert ctypes.sizeof(native.VetoInputs) == 16 + 3 * 8 + 8 + 5 * 8
     assert ctypes.sizeof(native.VetoDebugOutputs) == 8 + 4 * 8
+    assert ctypes.sizeof(native.VetoPostMeetArgs) == 6 * 4 + 11 * 8
+    assert ctypes.sizeof(native.VetoPostVoteArgs) == 8 * 4 + 12 * 8
+
+
+def test_postprocess_vote_rejects_bad_arguments_without_a_gpu():
+    lib = native.load_library()
+    a = native.VetoPostVoteArgs()
+    assert lib.veto_postprocess_vote(None, ctypes.byref(a), ctypes.c_void_p(8), 0) == -1
+    assert b"size mismatch" in lib.veto_last_error()
+    a.struct_size = ctypes.sizeof(native.VetoPostVoteArgs)
+    a.n_obj, a.n_pair, a.n_groups, a.n_rel_cls, a.n_obj_cls, a.voting = 3, 6, 5, 51, 151, 2
+    assert lib.veto_postprocess_vote(None, ctypes.byref(a), ctypes.c_void_p(8), 0) == -1
+    assert b"voting" in lib.veto_last_error()
 
 
 def test_create_rejects_bad_configs_without_a_gpu():

@@ -8,8 +8,8 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import (golden_names, load_golden, load_post_golden, load_postmeet_golden, post_golden_names,
-                      postmeet_golden_names)
+from conftest import (golden_names, load_golden, load_post_golden, load_postmeet_golden, load_postvote_golden,
+                      post_golden_names, postmeet_golden_names, postvote_golden_names)
 
 pytestmark = pytest.mark.gpu
 
@@ -98,6 +98,8 @@ def test_golden_parity(name):
     g, sd, batch = load_golden(name)
     meet, mode = bool(int(g["meet"])), str(g["mode"])
     cfg = testing.make_config(g["_layers"], g["_heads"], mode, meet, str(g["dataset"]))
+    experts = bool(int(g.get("experts", 0)))
+    cfg.ENSEMBLE_LEARNING.EXPERT_GROUP = experts
     model = testing.make_predictor(cfg, sd, dev)
     out, pairs = _run(model, batch, mode, dev, debug=True)
     assert np.array_equal(torch.cat(pairs).cpu().numpy(), g["pair_idx"])
@@ -106,8 +108,11 @@ def test_golden_parity(name):
     assert [tuple(o.shape) for o in obj_dists] == [(n, g["_n_obj"]) for n in batch["num_objs"]]
     if meet:
         assert out[3] == [int(x) for x in g["incre_idx_list"]]
-        for k in range(len(g["group_sizes"])):
-            err = np.abs(rel["group_%d" % k].cpu().numpy() - g["rel_group_%d" % k]).max()
+        keys = ["group_%d%d" % (k, e) for k in range(len(g["group_sizes"])) for e in (1, 2, 3)] if experts \
+            else ["group_%d" % k for k in range(len(g["group_sizes"]))]
+        assert sorted(rel.keys()) == sorted(keys)
+        for k in keys:
+            err = np.abs(rel[k].cpu().numpy() - g["rel_" + k]).max()
             assert err <= LOGIT_TOL, (name, k, err)
     else:
         assert out[2] == {} and out[3] is None and out[4] is None and out[5] is None
@@ -309,6 +314,78 @@ def test_postprocessor_meet_golden_parity(name):
     with pytest.raises(ValueError):
         post(({k: torch.from_numpy(v).to(dev) for k, v in rel.items()}, [torch.from_numpy(obj_logits).to(dev)] * 2),
              [torch.from_numpy(pairs).to(dev)] * 2, [box, box], incre_idx_list=incre, ensemble=True)
+
+
+@pytest.mark.parametrize("name", postvote_golden_names())
+def test_postprocessor_vote_golden_parity(name):
+    """HIP expert voting (veto_postprocess_vote) vs the committed outputs of the reference's EXPERT_GROUP
+    branch (inference.py:93-283): same kept rows, same order (up to score near-ties), same probabilities."""
+    from oracle import veto_oracle as vo
+    from veto_amd import testing
+    from veto_amd.postprocess import PostProcessor
+    from veto_amd.structures import BoxList
+    dev = _dev()
+    g, rel, obj_logits, pairs, n = load_postvote_golden(name)
+    incre = [int(x) for x in g["incre_idx_list"]]
+    cfg = testing.make_config(1, 8, meet=True, dataset=str(g["dataset"]))
+    cfg.ENSEMBLE_LEARNING.EXPERT_GROUP = True
+    cfg.ENSEMBLE_LEARNING.VOTING = str(g["voting"])
+    post = PostProcessor(False, use_gt_box=True, cfg=cfg)
+    box = BoxList(torch.zeros(n, 4), (800, 600)).to(dev)
+    res = post(({k: torch.from_numpy(v).to(dev) for k, v in rel.items()}, [torch.from_numpy(obj_logits).to(dev)]),
+               [torch.from_numpy(pairs).to(dev)], [box], incre_idx_list=incre, ensemble=True)[0]
+    ref = vo.postprocess_vote(rel, obj_logits, pairs, incre, len(incre), voting=str(g["voting"]))
+    assert np.array_equal(res.get_field("pred_labels").cpu().numpy(), g["pred_labels"])
+    assert res.get_field("rel_pair_idxs").dtype == torch.float32
+    got_pairs = res.get_field("rel_pair_idxs").cpu().numpy()
+    assert got_pairs.shape == g["rel_pair_idxs"].shape                      # the same number of rows survive the vote
+    same = (got_pairs == g["rel_pair_idxs"]).all(1) & (res.get_field("pred_rel_labels").cpu().numpy() == g["pred_rel_labels"])
+    ts = ref["triple_scores"].numpy()
+    if not same.all():
+        bad = np.nonzero(~same)[0]
+        assert np.abs(ts[bad][:, None] - ts[bad][None, :] + np.eye(len(bad))).min(1).max() <= 2e-6
+    assert same.mean() > 0.95
+    assert np.abs(res.get_field("pred_rel_scores").cpu().numpy()[same] - g["pred_rel_scores"][same]).max() <= 2e-6
+    got_ts = post.last_triple_scores[0].cpu().numpy()
+    assert (got_ts >= 0).all() and (np.diff(got_ts) <= 0).all() and np.abs(np.sort(got_ts) - np.sort(ts)).max() <= 2e-6
+
+
+def test_expert_group_predictor_into_voting_postprocessor():
+    """VETOPredictor_MEET with EXPERT_GROUP (15 heads) -> PostProcessor voting, on the device, against the
+    oracle chain at a size no golden covers."""
+    from oracle import veto_oracle as vo
+    from veto_amd import synth, testing
+    from veto_amd.postprocess import PostProcessor
+    dev = _dev()
+    groups = [4, 6, 9, 19, 12]
+    sd = synth.meet_state_dict(5, groups, layers=2, experts=3)
+    batch = synth.synthetic_batch(17, 1, [14])
+    cfg = testing.make_config(2, 8, "sgcls", meet=True)
+    cfg.ENSEMBLE_LEARNING.EXPERT_GROUP = True
+    cfg.ENSEMBLE_LEARNING.VOTING = "C"
+    model = testing.make_predictor(cfg, sd, dev)
+    out, pairs = _run(model, batch, "sgcls", dev)
+    ocfg = vo.OracleConfig(layers=2, heads=8, mode="sgcls", meet_groups=groups, prefix="model.", experts=3)
+    logits, _, _ = vo.forward(sd, ocfg, batch)
+    col, ref_rel = 0, {}
+    for e in range(3):
+        for k, gk in enumerate(groups):
+            ref_rel["group_%d%d" % (k, e + 1)] = logits[:, col:col + gk + 2].numpy()
+            col += gk + 2
+    for k, v in ref_rel.items():
+        assert np.abs(out[1][k].cpu().numpy() - v).max() <= LOGIT_TOL
+    post = PostProcessor(False, use_gt_box=True, cfg=cfg)
+    props = testing.make_proposals(batch, "sgcls", dev)
+    obj_logits = torch.from_numpy(batch["predict_logits"]).to(dev)
+    res = post((out[1], [obj_logits]), pairs, props, incre_idx_list=out[3], ensemble=True)[0]
+    ref = vo.postprocess_vote(ref_rel, batch["predict_logits"], pairs[0].cpu().numpy(), out[3], 51, voting="C")
+    # the vote itself is discrete: the kept (pair, group-local label) multiset must agree unless two experts'
+    # top probabilities are within the logit noise of each other
+    got = sorted(zip(res.get_field("rel_pair_idxs").cpu().numpy().astype(int).tolist(), res.get_field("pred_rel_labels").cpu().tolist(),
+                     np.round(res.get_field("pred_rel_scores").cpu().numpy().sum(1), 3).tolist()), key=str)
+    want = sorted(zip(ref["rel_pair_idxs"].numpy().astype(int).tolist(), ref["pred_rel_labels"].tolist(),
+                      np.round(ref["pred_rel_scores"].numpy().sum(1), 3).tolist()), key=str)
+    assert abs(len(got) - len(want)) <= 2 and len(set(map(str, got)) & set(map(str, want))) >= 0.98 * len(want)
 
 
 def test_relation_head_chain_against_oracle_chain():

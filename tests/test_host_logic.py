@@ -67,9 +67,12 @@ def test_modes_and_constructor_errors():
     with pytest.raises(ValueError):
         predictor.VETOPredictor(cfg, 512)
     cfg = testing.make_config(2, 8, meet=True)
-    cfg.ENSEMBLE_LEARNING.EXPERT_GROUP = True
-    with pytest.raises(NotImplementedError):
-        predictor.VETOPredictor_MEET(cfg, 512)
+    cfg.ENSEMBLE_LEARNING.EXPERT_GROUP = True      # 3 experts x 5 groups, `rel_out` aliases the last expert
+    m = predictor.VETOPredictor_MEET(cfg, 512)
+    want = set(synth.meet_state_dict(0, m.max_group_element_number_list, layers=2, experts=3))
+    got = set(m.state_dict())
+    assert got == want and m._num_out == 3 * sum(g + 2 for g in m.max_group_element_number_list)
+    assert m.model.rel_out[0].weight is m.model.rel_out_group[2][0].weight
     cfg = testing.make_config(2, 8)
     cfg.VETO_AMD.PRECISION = "int4"
     with pytest.raises(ValueError):

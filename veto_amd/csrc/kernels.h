@@ -111,6 +111,7 @@ struct PostArgs {
   int32_t* perm;                 // workspace [n_pair]
   int single_cnt;                // > 0: one segment of this many rows (MEET merge) instead of img_pair_off
   int pair_mod;                  // > 0: row r refers to pair r % pair_mod (MEET: K copies of the pair list)
+  int32_t* kept_count;           // optional out [1]: rows of the sorted segment with score >= 0 (expert voting)
 };
 struct MeetGroup {               // one MEET head, passed by value
   const float* logits;           // [n_pair, width], width = g + 2
@@ -119,6 +120,14 @@ struct MeetGroup {               // one MEET head, passed by value
   int cols[104];                 // cols[c] = global class of the group's column c (cols[0] = 0), c < width - 1
 };
 hipError_t launch_postprocess_meet(PostArgs a, const MeetGroup* groups, int n_groups, hipStream_t s);
+struct VoteGroup {               // one MEET group with its three expert heads, passed by value
+  const float* logits[3];        // each [n_pair, width]
+  int width;
+  int row0;
+  int cols[104];
+};
+// voting: 0 = consensus ('C', two of three experts agree), 1 = unanimous ('U')
+hipError_t launch_postprocess_vote(PostArgs a, const VoteGroup* groups, int n_groups, int voting, hipStream_t s);
 int postprocess_max_pairs_per_image();
 hipError_t launch_postprocess(const PostArgs& a, hipStream_t s);
 

@@ -108,6 +108,16 @@ __global__ __launch_bounds__(1024) void segment_sort_kernel(PostArgs a) {
     }
   }
   for (int i = threadIdx.x; i < cnt; i += blockDim.x) a.perm[p0 + i] = p0 + s_idx[i];
+  if (a.kept_count) {  // voted-out rows carry score -1 and sort last: the kept rows are a prefix
+    __shared__ int s_kept;
+    if (threadIdx.x == 0) s_kept = 0;
+    __syncthreads();
+    int mine = 0;
+    for (int i = threadIdx.x; i < cnt; i += blockDim.x) mine += s_key[i] >= 0.f;
+    if (mine) atomicAdd(&s_kept, mine);
+    __syncthreads();
+    if (threadIdx.x == 0) a.kept_count[img] = s_kept;
+  }
 }
 
 __global__ __launch_bounds__(256) void gather_sorted_kernel(PostArgs a) {
@@ -163,7 +173,107 @@ __global__ __launch_bounds__(256) void meet_rel_score_kernel(PostArgs a, MeetGro
   }
 }
 
+// EXPERT_GROUP voting (inference.py:93-283): three expert heads per group.  One wave per (pair, group);
+// a lane owns columns lane and lane + 64 of the group's g+1 kept columns (g + 2 <= 105).
+//   per expert e: p_e = softmax(logit_e) without its last column, (score_e, cls_e) = max over columns 1..,
+//                 t_e = score_e * obj_s * obj_o                                                   (:178-190)
+//   agree_ab = cls_a == cls_b for (0,1), (1,2), (0,2)                                              (:192-199)
+//   consensus: pair means t_ab = (t_a + t_b)/2, p_ab = (p_a + p_b)/2 with p_12 = p_1 (the reference
+//              averages expert 1 with itself, :224-226); row = sum over agreeing pairs / their count (:211-255)
+//   unanimous: all three agree; row = three-way mean                                                (:257-261)
+// A voted-out row gets score -1 (it sorts behind every kept row, whose scores are >= 0) and label 0.
+__global__ __launch_bounds__(256) void vote_rel_score_kernel(PostArgs a, VoteGroup grp, int voting) {
+  const int p = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (p >= a.n_pair) return;
+  const size_t out_row = (size_t)grp.row0 + p;
+  float* prob = a.prob_tmp + out_row * a.n_rel_cls;
+  for (int c = lane; c < a.n_rel_cls; c += 64) prob[c] = 0.f;
+  const float s0 = a.obj_scores[a.rel_pairs[2 * (size_t)p]];
+  const float s1 = a.obj_scores[a.rel_pairs[2 * (size_t)p + 1]];
+  const int keepw = grp.width - 1;  // the last column is dropped
+  float pr[3][2], t[3];
+  int cls[3];
+#pragma unroll
+  for (int e = 0; e < 3; ++e) {
+    const float* logit = grp.logits[e] + (size_t)p * grp.width;
+    float mx = -INFINITY;
+    for (int c = lane; c < grp.width; c += 64) mx = fmaxf(mx, logit[c]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    float sum = 0.f;
+    for (int c = lane; c < grp.width; c += 64) sum += expf(logit[c] - mx);
+    sum = wave_sum(sum);
+    const float inv = 1.f / sum;
+    float best = -1.f;
+    int best_cls = 0x7fffffff;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int c = lane + 64 * j;
+      pr[e][j] = c < keepw ? expf(logit[c] - mx) * inv : 0.f;
+      if (c >= 1 && c < keepw && pr[e][j] > best) { best = pr[e][j]; best_cls = c; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ob = __shfl_xor(best, o, 64);
+      const int oc = __shfl_xor(best_cls, o, 64);
+      if (ob > best || (ob == best && oc < best_cls)) { best = ob; best_cls = oc; }
+    }
+    t[e] = best * s0 * s1;
+    cls[e] = best_cls;
+  }
+  const bool ag01 = cls[0] == cls[1], ag12 = cls[1] == cls[2], ag02 = cls[0] == cls[2];
+  float triple, out[2];
+  int label;
+  bool keep;
+  if (voting == 0) {
+    const int cnt = (int)ag01 + (int)ag12 + (int)ag02;
+    keep = cnt > 0;
+    const float fc = (float)cnt;
+    triple = (((ag01 ? (t[0] + t[1]) * 0.5f : 0.f) + (ag12 ? (t[1] + t[2]) * 0.5f : 0.f)) + (ag02 ? (t[0] + t[2]) * 0.5f : 0.f)) / fc;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      out[j] = (((ag01 ? (pr[0][j] + pr[1][j]) * 0.5f : 0.f) + (ag12 ? (pr[1][j] + pr[1][j]) * 0.5f : 0.f)) +
+                (ag02 ? (pr[0][j] + pr[2][j]) * 0.5f : 0.f)) / fc;
+    label = ag02 ? cls[2] : ag12 ? cls[1] : ag01 ? cls[0] : 0;  // later assignments override (:250-251)
+  } else {
+    keep = ag01 && ag12 && ag02;
+    triple = ((t[0] + t[1]) + t[2]) / 3.f;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) out[j] = ((pr[0][j] + pr[1][j]) + pr[2][j]) / 3.f;
+    label = cls[2];
+  }
+  if (keep) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int c = lane + 64 * j;
+      if (c < keepw) prob[grp.cols[c]] = out[j];
+    }
+  }
+  if (lane == 0) {
+    a.triple[out_row] = keep ? triple : -1.f;
+    a.label_tmp[out_row] = keep ? label : 0;
+  }
+}
+
 }  // namespace
+
+hipError_t launch_postprocess_vote(PostArgs a, const VoteGroup* groups, int n_groups, int voting, hipStream_t s) {
+  VETO_LAUNCH(obj_score_kernel, dim3((a.n_obj + 3) / 4), dim3(256), 0, s, a.obj_logits, a.n_obj, a.n_obj_cls, a.obj_scores, a.obj_pred);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  for (int k = 0; k < n_groups; ++k) {
+    VETO_LAUNCH(vote_rel_score_kernel, dim3((a.n_pair + 3) / 4), dim3(256), 0, s, a, groups[k], voting);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+  }
+  PostArgs m = a;
+  m.single_cnt = n_groups * a.n_pair;
+  m.pair_mod = a.n_pair;
+  m.n_pair = m.single_cnt;
+  VETO_LAUNCH(segment_sort_kernel, dim3(1), dim3(1024), 0, s, m);
+  if ((e = hipGetLastError()) != hipSuccess) return e;
+  VETO_LAUNCH(gather_sorted_kernel, dim3((m.n_pair + 3) / 4), dim3(256), 0, s, m);
+  return hipGetLastError();
+}
 
 hipError_t launch_postprocess_meet(PostArgs a, const MeetGroup* groups, int n_groups, hipStream_t s) {
   VETO_LAUNCH(obj_score_kernel, dim3((a.n_obj + 3) / 4), dim3(256), 0, s, a.obj_logits, a.n_obj, a.n_obj_cls, a.obj_scores, a.obj_pred);

@@ -578,6 +578,54 @@ int veto_postprocess_meet(void* stream, const veto_post_meet_args_t* a, void* wo
   return VETO_OK;
 }
 
+int veto_postprocess_vote(void* stream, const veto_post_vote_args_t* a, void* workspace, size_t workspace_bytes) {
+  if (!a || !workspace) return fail(VETO_ERR_INVALID, "null argument");
+  if (a->struct_size != (int32_t)sizeof(veto_post_vote_args_t)) return fail(VETO_ERR_INVALID, "veto_post_vote_args_t size mismatch");
+  if (a->n_obj <= 0 || a->n_pair <= 0 || a->n_groups <= 0 || a->n_groups > 16 || a->n_rel_cls < 2 || a->n_obj_cls < 2)
+    return fail(VETO_ERR_INVALID, "bad sizes");
+  if (a->voting != 0 && a->voting != 1) return fail(VETO_ERR_INVALID, "voting must be 0 ('C') or 1 ('U')");
+  if (!a->expert_logits || !a->group_widths || !a->incre_idx_list || !a->obj_logits || !a->rel_pairs || !a->obj_scores ||
+      !a->obj_pred || !a->rel_prob_sorted || !a->rel_pairs_sorted || !a->rel_labels_sorted || !a->kept_count)
+    return fail(VETO_ERR_INVALID, "missing pointer");
+  const long total = (long)a->n_groups * a->n_pair;
+  if (total > postprocess_max_pairs_per_image())
+    return fail(VETO_ERR_INVALID, "n_groups * n_pair = %ld exceeds %d", total, postprocess_max_pairs_per_image());
+  if (workspace_bytes < veto_postprocess_workspace_bytes((int32_t)total, a->n_rel_cls)) return fail(VETO_ERR_WORKSPACE, "workspace too small");
+  std::vector<VoteGroup> groups(a->n_groups);
+  for (int k = 0; k < a->n_groups; ++k) {
+    VoteGroup& g = groups[k];
+    for (int e = 0; e < 3; ++e) {
+      g.logits[e] = a->expert_logits[3 * k + e];
+      if (!g.logits[e]) return fail(VETO_ERR_INVALID, "group %d expert %d: null logits", k, e + 1);
+    }
+    g.width = a->group_widths[k];
+    g.row0 = k * a->n_pair;
+    if (g.width < 3 || g.width - 1 > 104) return fail(VETO_ERR_INVALID, "bad group %d (width %d)", k, g.width);
+    int n = 0;
+    g.cols[n++] = 0;
+    for (int c = 0; c < a->n_rel_cls; ++c)
+      if (a->incre_idx_list[c] == k + 1) {
+        if (n >= g.width - 1) return fail(VETO_ERR_INVALID, "group %d has more classes than its head is wide", k);
+        g.cols[n++] = c;
+      }
+    if (n != g.width - 1) return fail(VETO_ERR_INVALID, "group %d: %d classes but head width %d", k, n - 1, g.width);
+  }
+  char* base = (char*)workspace;
+  PostArgs p{};
+  p.obj_logits = a->obj_logits; p.rel_pairs = a->rel_pairs;
+  p.n_img = 1; p.n_obj = a->n_obj; p.n_pair = a->n_pair; p.n_rel_cls = a->n_rel_cls; p.n_obj_cls = a->n_obj_cls;
+  p.obj_scores = a->obj_scores; p.obj_pred = a->obj_pred; p.out_prob = a->rel_prob_sorted;
+  p.out_pairs = a->rel_pairs_sorted; p.out_labels = a->rel_labels_sorted; p.out_triple = a->triple_sorted;
+  p.kept_count = a->kept_count;
+  p.prob_tmp = (float*)base;
+  base += align_up((size_t)total * a->n_rel_cls * 4, 256);
+  p.triple = (float*)base; base += align_up((size_t)total * 4, 256);
+  p.label_tmp = (int32_t*)base; base += align_up((size_t)total * 4, 256);
+  p.perm = (int32_t*)base;
+  HIP_TRY(launch_postprocess_vote(p, groups.data(), a->n_groups, a->voting, (hipStream_t)stream));
+  return VETO_OK;
+}
+
 int veto_profile_enable(veto_handle_t h, int32_t on) {
   if (!h) return fail(VETO_ERR_INVALID, "null handle");
   h->prof_on = on != 0;

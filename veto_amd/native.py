@@ -19,7 +19,7 @@ EXPORTS = [
     "veto_weight_info", "veto_load_weights", "veto_workspace_bytes", "veto_forward",
     "veto_enumerate_pairs", "veto_profile_enable", "veto_profile_collect", "veto_profile_entry",
     "veto_profile_reset", "veto_debug_gemm", "veto_debug_gemm_workspace_bytes",
-    "veto_postprocess", "veto_postprocess_workspace_bytes", "veto_postprocess_meet",
+    "veto_postprocess", "veto_postprocess_workspace_bytes", "veto_postprocess_meet", "veto_postprocess_vote",
 ]
 
 VETO_PRECISE, VETO_FAST = 0, 1
@@ -61,6 +61,14 @@ class VetoPostMeetArgs(Structure):
                [(n, c_void_p) for n in ("group_logits", "group_widths", "incre_idx_list", "obj_logits", "rel_pairs",
                                         "obj_scores", "obj_pred", "rel_prob_sorted", "rel_pairs_sorted",
                                         "rel_labels_sorted", "triple_sorted")]
+
+
+class VetoPostVoteArgs(Structure):
+    _fields_ = [(n, c_int32) for n in ("struct_size", "n_obj", "n_pair", "n_groups", "n_rel_cls", "n_obj_cls",
+                                       "voting", "reserved0")] + \
+               [(n, c_void_p) for n in ("expert_logits", "group_widths", "incre_idx_list", "obj_logits", "rel_pairs",
+                                        "obj_scores", "obj_pred", "rel_prob_sorted", "rel_pairs_sorted",
+                                        "rel_labels_sorted", "triple_sorted", "kept_count")]
 
 
 class VetoError(RuntimeError):
@@ -108,6 +116,7 @@ def load_library():
     lib.veto_postprocess_workspace_bytes.restype = c_size_t
     lib.veto_postprocess.argtypes = [c_void_p, POINTER(VetoPostArgs), c_void_p, c_size_t]
     lib.veto_postprocess_meet.argtypes = [c_void_p, POINTER(VetoPostMeetArgs), c_void_p, c_size_t]
+    lib.veto_postprocess_vote.argtypes = [c_void_p, POINTER(VetoPostVoteArgs), c_void_p, c_size_t]
     _LIB = lib
     return lib
 

@@ -8,8 +8,10 @@ arithmetic (softmax, foreground max, triple score, per-image descending sort, ga
 libveto_amd.so (veto_postprocess).  When the relation logits are the MEET dict of group heads
 (ENSEMBLE_LEARNING.ENABLED with EXPERT_GROUP False), the MEET merge branch (inference.py:284-397) runs
 through veto_postprocess_meet with the reference's quirks kept: one image per call, group-local
-labels, float pair indices.  sgdet decoding (per-class NMS, inference.py:413-418), attributes and the
-EXPERT_GROUP voting branch (inference.py:93-283) are not built; they raise."""
+labels, float pair indices.  With EXPERT_GROUP True (three expert heads per group, keys 'group_<k><e>') the
+voting branch (inference.py:93-283, ENSEMBLE_LEARNING.VOTING 'C' or 'U') runs through veto_postprocess_vote;
+its row count is data dependent, so that branch reads one int32 back from the device.  sgdet decoding
+(per-class NMS, inference.py:413-418) and attributes are not built; they raise."""
 import ctypes
 
 import torch
@@ -35,6 +37,8 @@ class PostProcessor(nn.Module):
         if not self.use_gt_box:
             raise NotImplementedError("veto_amd.PostProcessor: sgdet decoding (per-class NMS) is not built")
         if isinstance(relation_logits, dict):
+            if "group_01" in relation_logits:   # inference.py:93: three experts per group
+                return self._forward_vote(relation_logits, refine_logits, rel_pair_idxs, boxes, incre_idx_list)
             return self._forward_meet(relation_logits, refine_logits, rel_pair_idxs, boxes, incre_idx_list)
         rel = torch.cat(list(relation_logits), 0) if isinstance(relation_logits, (list, tuple)) else relation_logits
         obj = torch.cat(list(refine_logits), 0) if isinstance(refine_logits, (list, tuple)) else refine_logits
@@ -139,6 +143,67 @@ class PostProcessor(nn.Module):
         box.add_field("rel_pair_idxs", out["pairs"].to(torch.float32))  # torch.zeros(total, 2) in the reference (:381)
         box.add_field("pred_rel_scores", out["prob"])
         box.add_field("pred_rel_labels", out["labels"])                 # group-local labels, as the reference (:388)
+        return [box]
+
+
+    def _forward_vote(self, relation_logits, refine_logits, rel_pair_idxs, boxes, incre_idx_list):
+        if incre_idx_list is None:
+            raise ValueError("expert voting needs incre_idx_list (4th element of the predictor's return tuple)")
+        if len(boxes) != 1:
+            raise ValueError("the EXPERT_GROUP branch (inference.py:114-116) uses the first image only; call it with "
+                             "one image per batch, got %d" % len(boxes))
+        voting = str(self.cfg.ENSEMBLE_LEARNING.VOTING) if self.cfg is not None else "C"
+        if voting not in ("C", "U"):
+            raise ValueError("ENSEMBLE_LEARNING.VOTING must be 'C' or 'U', got %r" % voting)
+        if len(relation_logits) % 3:
+            raise ValueError("expected three expert heads per group, got %d heads" % len(relation_logits))
+        lib = native.load_library()
+        K = len(relation_logits) // 3
+        keys = ["group_%d%d" % (k, e + 1) for k in range(K) for e in range(3)]
+        device = relation_logits[keys[0]].device
+        if device.type != "cuda":
+            raise RuntimeError("veto_amd.PostProcessor runs only on a HIP device (got %s)" % device)
+        f32 = dict(device=device, dtype=torch.float32)
+        heads = [relation_logits[k].detach().to(**f32).contiguous() for k in keys]
+        obj = (refine_logits[0] if isinstance(refine_logits, (list, tuple)) else refine_logits).detach().to(**f32).contiguous()
+        pairs = rel_pair_idxs[0].reshape(-1, 2).to(device=device, dtype=torch.int64).contiguous()
+        n_obj, n_pair, n_rel = obj.shape[0], pairs.shape[0], len(incre_idx_list)
+        total = K * n_pair
+        out = {"obj_scores": torch.empty(n_obj, **f32), "obj_pred": torch.empty(n_obj, dtype=torch.int64, device=device),
+               "prob": torch.empty((total, n_rel), **f32), "pairs": torch.empty((total, 2), dtype=torch.int64, device=device),
+               "labels": torch.empty(total, dtype=torch.int64, device=device), "triple": torch.empty(total, **f32),
+               "kept": torch.zeros(1, dtype=torch.int32, device=device)}
+        need = lib.veto_postprocess_workspace_bytes(total, n_rel)
+        if self._workspace is None or self._workspace.numel() < need or self._workspace.device != device:
+            self._workspace = torch.empty(need, dtype=torch.uint8, device=device)
+        ptrs = (ctypes.c_void_p * (3 * K))(*[h.data_ptr() for h in heads])
+        widths = (ctypes.c_int32 * K)(*[heads[3 * k].shape[1] for k in range(K)])
+        incre = (ctypes.c_int32 * n_rel)(*[int(x) for x in incre_idx_list])
+        a = native.VetoPostVoteArgs()
+        a.struct_size = ctypes.sizeof(native.VetoPostVoteArgs)
+        a.n_obj, a.n_pair, a.n_groups, a.n_rel_cls, a.n_obj_cls = n_obj, n_pair, K, n_rel, obj.shape[1]
+        a.voting = 0 if voting == "C" else 1
+        a.expert_logits = ctypes.cast(ptrs, ctypes.c_void_p)
+        a.group_widths = ctypes.cast(widths, ctypes.c_void_p)
+        a.incre_idx_list = ctypes.cast(incre, ctypes.c_void_p)
+        a.obj_logits, a.rel_pairs = obj.data_ptr(), pairs.data_ptr()
+        a.obj_scores, a.obj_pred = out["obj_scores"].data_ptr(), out["obj_pred"].data_ptr()
+        a.rel_prob_sorted, a.rel_pairs_sorted = out["prob"].data_ptr(), out["pairs"].data_ptr()
+        a.rel_labels_sorted, a.triple_sorted = out["labels"].data_ptr(), out["triple"].data_ptr()
+        a.kept_count = out["kept"].data_ptr()
+        stream = torch.cuda.current_stream(device)
+        native.check(lib.veto_postprocess_vote(ctypes.c_void_p(stream.cuda_stream), ctypes.byref(a),
+                                               ctypes.c_void_p(self._workspace.data_ptr()), self._workspace.numel()))
+        for t in heads + [obj, pairs]:
+            t.record_stream(stream)
+        kept = int(out["kept"].item())   # the one device read-back: the result's row count is data dependent
+        self.last_triple_scores = [out["triple"][:kept]]
+        box = boxes[0]
+        box.add_field("pred_labels", out["obj_pred"])
+        box.add_field("pred_scores", out["obj_scores"])
+        box.add_field("rel_pair_idxs", out["pairs"][:kept].to(torch.float32))  # float, as the reference (:267)
+        box.add_field("pred_rel_scores", out["prob"][:kept])
+        box.add_field("pred_rel_labels", out["labels"][:kept])                 # group-local labels
         return [box]
 
 

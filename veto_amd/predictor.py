@@ -370,15 +370,22 @@ def class_balanced_weights(counts, num_cls, beta=0.999):
 class _EnsembleParams(_Holder):
     """Parameter tree of the reference's `Ensemble` (roi_relation_predictors.py:3661-3744)."""
 
-    def __init__(self, config, num_obj_cls, sizes, obj_classes):
+    def __init__(self, config, num_obj_cls, sizes, obj_classes, experts_per_group=1, expert_group=False):
         super().__init__()
         _build_trunk(self, config, num_obj_cls, with_embed2=False)
         vecs = _embedding_vectors(obj_classes, getattr(config, "GLOVE_DIR", ""), 200)
         with torch.no_grad():
             self.obj_embed.weight.copy_(vecs)
         dim = config.MODEL.ROI_RELATION_HEAD.VETOTRANSFORMER.T_INPUT_DIM
-        self.rel_out = nn.ModuleList(_xavier_linear(dim, g + 2) for g in sizes)
         self.rel_out_group = nn.ModuleList([])
+        if expert_group:
+            # :3717-3723: experts_per_group lists of K heads; `rel_out` stays bound to the LAST list, so the
+            # state dict holds it twice (rel_out.{k} and rel_out_group.{E-1}.{k} are the same tensors)
+            for _ in range(experts_per_group):
+                self.rel_out = nn.ModuleList(_xavier_linear(dim, g + 2) for g in sizes)
+                self.rel_out_group.append(self.rel_out)
+        else:
+            self.rel_out = nn.ModuleList(_xavier_linear(dim, g + 2) for g in sizes)
         self.CE_loss = nn.CrossEntropyLoss()
         self.criterion_loss = nn.CrossEntropyLoss()
 
@@ -391,19 +398,23 @@ class VETOPredictor_MEET(nn.Module, _NativeForward):
         statistics = _dataset_statistics(config)
         self.params = {"statistics": statistics, "obj_classes": statistics["obj_classes"],
                        "rel_classes": statistics["rel_classes"]}
-        if bool(config.ENSEMBLE_LEARNING.EXPERT_GROUP):
-            raise NotImplementedError("veto_amd: ENSEMBLE_LEARNING.EXPERT_GROUP=True (3 experts per group) is not "
-                                      "supported; configs/VETO_final.yaml:154 ships False")
         dataset = config.GLOBAL_SETTING.DATASET_CHOICE
         self.group_split_mode = config.GCL_SETTING.GROUP_SPLIT_MODE
         self.max_group_element_number_list = meet_tables.group_sizes(dataset, self.group_split_mode)
         self.incre_idx_list = meet_tables.incre_idx_list(self.max_group_element_number_list)
         self.num_groups = len(self.max_group_element_number_list)
-        self.experts_per_group = 1
+        # :3901-3903: three experts per group unless ENSEMBLE_LEARNING.EXPERT_GROUP is off
+        self.expert_group = bool(config.ENSEMBLE_LEARNING.EXPERT_GROUP)
+        self.experts_per_group = 3 if self.expert_group else 1
         self.num_obj_cls = len(self.params["obj_classes"])
         self.model = _EnsembleParams(config, self.num_obj_cls, self.max_group_element_number_list,
-                                     self.params["obj_classes"])
-        self._native_init(config, self.model, self.num_obj_cls, list(self.model.rel_out))
+                                     self.params["obj_classes"], self.experts_per_group, self.expert_group)
+        # head columns of the one fused GEMV: expert-major, then group (all heads read the same CLS row)
+        if self.expert_group:
+            heads = [h for lst in self.model.rel_out_group for h in lst]
+        else:
+            heads = list(self.model.rel_out)
+        self._native_init(config, self.model, self.num_obj_cls, heads)
 
     def forward(self, proposals, rel_pair_idxs, rel_labels, logger, roi_features=None,
                 roi_depth_features=None, rel_binarys=None):
@@ -422,8 +433,11 @@ class VETOPredictor_MEET(nn.Module, _NativeForward):
         rel, n_objs, n_pairs = self._run_native(proposals, rel_pair_idxs, roi_features, roi_depth_features,
                                                 labels, None, debug=getattr(self, "debug_outputs", False))
         rel_dists, col = {}, 0
-        for k, g in enumerate(self.max_group_element_number_list):
-            rel_dists["group_%d" % k] = rel[:, col:col + g + 2]
-            col += g + 2
+        for e in range(self.experts_per_group):
+            for k, g in enumerate(self.max_group_element_number_list):
+                # :3833-3841: 'group_<k><expert 1..3>' with EXPERT_GROUP, 'group_<k>' without
+                key = "group_%d%d" % (k, e + 1) if self.expert_group else "group_%d" % k
+                rel_dists[key] = rel[:, col:col + g + 2]
+                col += g + 2
         obj_dists = nn.functional.one_hot(dist_labels.to(rel.device), self.num_obj_cls).float().split(n_objs, dim=0)
         return obj_dists, rel_dists, {}, self.incre_idx_list, None, {}

@@ -133,15 +133,29 @@ def predictor_state_dict(seed, dim=576, layers=6, num_obj_cls=151, num_rel_cls=5
     return sd
 
 
-def meet_state_dict(seed, group_sizes, dim=576, layers=6, num_obj_cls=151):
-    """State dict of VETOPredictor_MEET (everything lives under `model.`)."""
+def meet_state_dict(seed, group_sizes, dim=576, layers=6, num_obj_cls=151, experts=0):
+    """State dict of VETOPredictor_MEET (everything lives under `model.`).  experts=3 gives the
+    ENSEMBLE_LEARNING.EXPERT_GROUP layout: `model.rel_out_group.{e}.{k}` for 3 experts x K groups, with
+    `model.rel_out.{k}` the same tensors as the LAST expert's (roi_relation_predictors.py:3717-3723
+    leaves `self.rel_out` bound to the last list it appended)."""
     sd = trunk_state_dict(seed, "model.", dim, layers, num_obj_cls)
     del sd["model.obj_embed2.weight"]  # Ensemble has no obj_embed2 (roi_relation_predictors.py:3676)
-    for k, g in enumerate(group_sizes):
-        name = "model.rel_out.%d" % k
+
+    def head(name, g):
         std = math.sqrt(2.0 / (dim + g + 2))
         sd[name + ".weight"] = normal(seed, name + ".weight", (g + 2, dim), 0.0, std)
         sd[name + ".bias"] = uniform(seed, name + ".bias", (g + 2,), -0.04, 0.04)
+
+    if experts:
+        for e in range(experts):
+            for k, g in enumerate(group_sizes):
+                head("model.rel_out_group.%d.%d" % (e, k), g)
+        for k in range(len(group_sizes)):
+            for part in (".weight", ".bias"):
+                sd["model.rel_out.%d%s" % (k, part)] = sd["model.rel_out_group.%d.%d%s" % (experts - 1, k, part)]
+    else:
+        for k, g in enumerate(group_sizes):
+            head("model.rel_out.%d" % k, g)
     return sd
 
 
