@@ -191,6 +191,34 @@ typedef struct veto_post_vote_args {
 /* workspace: veto_postprocess_workspace_bytes(n_groups * n_pair, n_rel_cls) */
 int veto_postprocess_vote(void* stream, const veto_post_vote_args_t* args, void* workspace, size_t workspace_bytes);
 
+/* ---- ROI feature extraction -------------------------------------------
+ * VETOFeatureExtractor.forward -> Pooler.forward with cat_all_levels=False
+ * (pysgg/modeling/roi_heads/box_head/roi_box_feature_extractors.py:75-121, pysgg/modeling/poolers.py:109-171)
+ * over the legacy ROIAlign of pysgg/csrc/cuda/ROIAlign_cuda.cu:65-125 (layers/roi_align.py:12-61):
+ * every ROI is pooled from ITS FPN level (LevelMapper, poolers.py:17-43) at that level's scale, the depth
+ * map with the fixed pooler of level 2 (poolers.py:144-153; level 0 when there is one level).  One launch. */
+typedef struct veto_roi_pool_args {
+  int32_t struct_size;
+  int32_t n_levels;               /* 1..4 */
+  int32_t n_img, n_roi;
+  int32_t channels;               /* of the pyramid maps (256) */
+  int32_t depth_channels;         /* of the depth map (256); ignored when depth_feat is NULL */
+  int32_t pooled;                 /* POOLER_RESOLUTION (8); 1..8 */
+  int32_t sampling_ratio;         /* POOLER_SAMPLING_RATIO (2); 1..4 (0 = adaptive is not built) */
+  const float* level_feat[4];     /* device [n_img, channels, level_h[l], level_w[l]], finest level first */
+  int32_t level_h[4];
+  int32_t level_w[4];
+  float level_scale[4];           /* POOLER_SCALES, e.g. 1/4, 1/8, 1/16, 1/32 */
+  const float* depth_feat;        /* device [n_img, depth_channels, depth_h, depth_w] or NULL */
+  int32_t depth_h, depth_w;
+  const float* rois;              /* device [n_roi, 5]: image index, x1, y1, x2, y2 (Pooler.convert_to_roi_format) */
+  float* out_rgb;                 /* out device [n_roi, channels, pooled, pooled]        -> roi_features */
+  float* out_depth;               /* out device [n_roi, depth_channels, pooled, pooled]  -> roi_depth_features */
+  int32_t* out_levels;            /* optional out device [n_roi]: the level each ROI was pooled from */
+} veto_roi_pool_args_t;
+
+int veto_roi_pool(void* stream, const veto_roi_pool_args_t* args);
+
 /* ---- measurement hooks (bench.py): per-kernel device time from hipEvents on `stream` ---------- */
 int veto_profile_enable(veto_handle_t h, int32_t on);
 /* Synchronises the recorded events; returns the number of distinct kernels. */

@@ -403,7 +403,7 @@ def test_relation_head_chain_against_oracle_chain():
     head.predictor = testing.make_predictor(cfg, sd, dev)
     head.eval()
     props = testing.make_proposals(batch, "predcls", dev)
-    _, result, losses = head(props, torch.from_numpy(batch["roi_features"]).to(dev),
+    _, result, losses = head.forward_pooled(props, torch.from_numpy(batch["roi_features"]).to(dev),
                              torch.from_numpy(batch["roi_depth_features"]).to(dev))
     torch.cuda.synchronize()
     assert losses == {}

@@ -1,0 +1,207 @@
+"""ROI feature extraction.
+
+The reference's ROIAlign cannot be executed in this image (its C++ extension does not compile against
+torch 2.10 and torchvision is absent), so the CPU restatement oracle/roi_align_oracle.py is pinned by
+ANALYTIC known answers here (CPU tests), and the HIP kernel is compared with it bit for bit (GPU tests)."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import roi_align_oracle as ro
+
+F = np.float32
+
+
+def _affine_map(B, C, H, W, seed=0):
+    """f[b, c, y, x] = a*y + b*x + c0 with small integer-ish coefficients (exactly representable)."""
+    rng = np.random.RandomState(seed)
+    a = rng.randint(-3, 4, size=(B, C, 1, 1)).astype(F) * F(0.25)
+    b = rng.randint(-3, 4, size=(B, C, 1, 1)).astype(F) * F(0.5)
+    c = rng.randint(-8, 9, size=(B, C, 1, 1)).astype(F)
+    yy = np.arange(H, dtype=F).reshape(1, 1, H, 1)
+    xx = np.arange(W, dtype=F).reshape(1, 1, 1, W)
+    return (a * yy + b * xx + c).astype(F), a, b, c
+
+
+# ----------------------------------------------------------------------------------------------------
+# oracle vs analytic known answers (CPU)
+# ----------------------------------------------------------------------------------------------------
+def test_affine_map_interior_bins_equal_the_map_at_the_bin_centre():
+    """Bilinear interpolation reproduces an affine function exactly, and the mean of the 2x2 sample
+    grid of a bin is the function at the bin centre: out[ph, pw] = f(y1*s + (ph+.5)*bin_h, x1*s + (pw+.5)*bin_w)
+    -- no -0.5 shift, no rounding of the scaled box (ROIAlign_cuda.cu:84-115)."""
+    feat, a, b, c = _affine_map(2, 5, 40, 60)
+    rois = np.array([[0, 16, 32, 144, 96], [1, 40.5, 20.25, 200.75, 120.5], [1, 8, 8, 24, 24]], dtype=F)
+    scale = 0.25
+    out = ro.roi_align(feat, rois, scale, pooled=8, sampling_ratio=2)
+    for r, roi in enumerate(rois):
+        bi = int(roi[0])
+        x1, y1, x2, y2 = [float(v) * scale for v in roi[1:]]
+        bw, bh = max(x2 - x1, 1.0) / 8, max(y2 - y1, 1.0) / 8
+        cy = y1 + (np.arange(8) + 0.5) * bh
+        cx = x1 + (np.arange(8) + 0.5) * bw
+        want = a[bi][:, :, :] * cy.reshape(1, 8, 1) + b[bi] * cx.reshape(1, 1, 8) + c[bi]
+        assert np.abs(out[r] - want).max() < 1e-4, r
+
+
+def test_constant_map_and_malformed_roi():
+    feat = np.full((1, 3, 10, 12), 7.5, dtype=F)
+    rois = np.array([[0, 4, 4, 30, 20], [0, 20, 20, 10, 10], [0, 5, 5, 5, 5]], dtype=F)  # 2nd/3rd: x2<x1, zero size -> 1x1
+    out = ro.roi_align(feat, rois, 0.25)
+    assert np.all(out == F(7.5))
+
+
+def test_hand_computed_border_and_out_of_map_samples():
+    """4x4 map, pooled 2, grid 1, scale 1 (one sample per bin, at the bin centre)."""
+    feat = np.arange(16, dtype=F).reshape(1, 1, 4, 4)
+    # ROI (x1,y1,x2,y2) = (1,1,3,3): bins 1x1, centres (1.5, 1.5), (1.5, 2.5), (2.5, 1.5), (2.5, 2.5)
+    out = ro.roi_align(feat, np.array([[0, 1, 1, 3, 3]], dtype=F), 1.0, pooled=2, sampling_ratio=1)
+    assert out.reshape(-1).tolist() == [7.5, 8.5, 11.5, 12.5]
+    # ROI (2,2,6,6): centres 3 and 5: 3 -> low >= H-1 snaps to the last row/col (value at index 3);
+    # 5 > 4 = H lies outside the map -> the sample contributes 0 (:26-29, :39-44)
+    out = ro.roi_align(feat, np.array([[0, 2, 2, 6, 6]], dtype=F), 1.0, pooled=2, sampling_ratio=1)
+    assert out.reshape(-1).tolist() == [15.0, 0.0, 0.0, 0.0]
+    # ROI (-3,-3,1,1): centres -2 (< -1: outside) and 0 (clamped to 0)
+    out = ro.roi_align(feat, np.array([[0, -3, -3, 1, 1]], dtype=F), 1.0, pooled=2, sampling_ratio=1)
+    assert out.reshape(-1).tolist() == [0.0, 0.0, 0.0, 0.0 + feat[0, 0, 0, 0]]
+    # a coordinate in [-1, 0] is clamped to 0, not dropped: ROI (-1.5,-1.5,0.5,0.5): centres -1 and 0
+    out = ro.roi_align(feat, np.array([[0, -1.5, -1.5, 0.5, 0.5]], dtype=F), 1.0, pooled=2, sampling_ratio=1)
+    assert out.reshape(-1).tolist() == [0.0, 0.0, 0.0, 0.0]   # all four samples read feat[0,0] = 0
+    feat2 = feat + F(1)
+    out = ro.roi_align(feat2, np.array([[0, -1.5, -1.5, 0.5, 0.5]], dtype=F), 1.0, pooled=2, sampling_ratio=1)
+    assert out.reshape(-1).tolist() == [1.0, 1.0, 1.0, 1.0]
+
+
+def test_level_mapper_boundaries():
+    """floor(4 + log2(sqrt(area)/224 + 1e-6)) clamped to [2, 5] - 2, area with the +1 convention:
+    a (w, h) box has x2 - x1 = w - 1.  sqrt(area) = 112 -> level 3 -> index 1; 224 -> 2; 448 -> 3."""
+    def box(w, h):
+        return [10.0, 20.0, 10.0 + w - 1, 20.0 + h - 1]
+    boxes = np.array([box(8, 8), box(111, 111), box(112, 112), box(223, 223), box(224, 224), box(447, 447),
+                      box(448, 448), box(2000, 2000), box(56, 224)], dtype=F)
+    assert ro.map_levels(boxes).tolist() == [0, 0, 1, 1, 2, 2, 3, 3, 1]    # 56x224 -> sqrt = 112 -> level 3
+    assert ro.box_area(np.array([[0, 0, 9, 4]], dtype=F)).tolist() == [50.0]
+
+
+def test_pooler_dispatch_uses_each_rois_own_level_and_fixed_depth_level():
+    rng = np.random.RandomState(3)
+    feats = [rng.randn(2, 4, 64 >> l, 96 >> l).astype(F) for l in range(4)]
+    depth = rng.randn(2, 3, 16, 24).astype(F)
+    boxes = [np.array([[10, 10, 40, 50], [0, 0, 300, 200]], dtype=F), np.array([[100, 60, 330, 250], [5, 5, 20, 20]], dtype=F)]
+    rgb, dep = ro.pooler_forward(feats, boxes, depth)
+    rois = ro.to_rois(boxes)
+    lv = ro.map_levels(np.concatenate(boxes))
+    assert lv.tolist() == [0, 2, 1, 0]      # sqrt(area) = 51.1, 246, 210, 16
+    scales = (0.25, 0.125, 0.0625, 0.03125)
+    for r in range(4):
+        assert np.array_equal(rgb[r], ro.roi_align(feats[lv[r]], rois[r:r + 1], scales[lv[r]])[0])
+    assert np.array_equal(dep, ro.roi_align(depth, rois, 0.0625))
+
+
+def test_roi_pool_abi_rejects_bad_arguments_without_a_gpu():
+    from veto_amd import native
+    lib = native.load_library()
+    a = native.VetoRoiPoolArgs()
+    assert lib.veto_roi_pool(None, ctypes.byref(a)) == -1 and b"size mismatch" in lib.veto_last_error()
+    a.struct_size = ctypes.sizeof(native.VetoRoiPoolArgs)
+    a.n_levels, a.n_img, a.n_roi, a.channels, a.pooled, a.sampling_ratio = 4, 1, 3, 256, 8, 0
+    assert lib.veto_roi_pool(None, ctypes.byref(a)) == -1 and b"adaptive" in lib.veto_last_error()
+    a.sampling_ratio, a.pooled = 2, 14
+    assert lib.veto_roi_pool(None, ctypes.byref(a)) == -1 and b"pooled" in lib.veto_last_error()
+    from veto_amd.poolers import Pooler
+    from veto_amd.structures import BoxList
+    p = Pooler((8, 8), (0.25, 0.125, 0.0625, 0.03125), 2)
+    with pytest.raises(RuntimeError, match="HIP device"):
+        p([torch.zeros(1, 4, 8 >> l, 8 >> l) for l in range(4)], [BoxList(torch.tensor([[0., 0., 8., 8.]]), (32, 32))])
+    with pytest.raises(NotImplementedError):
+        Pooler((8, 8), (0.25,), 2, cat_all_levels=True)
+
+
+# ----------------------------------------------------------------------------------------------------
+# HIP kernel vs oracle (GPU), bit for bit
+# ----------------------------------------------------------------------------------------------------
+def _random_boxes(rng, n, W, H):
+    xy = rng.uniform(-20, [W * 0.9, H * 0.9], size=(n, 2))
+    wh = np.exp(rng.uniform(np.log(2), np.log(max(W, H) * 1.2), size=(n, 2)))
+    b = np.concatenate([xy, xy + wh], 1).astype(F)
+    b[0] = [0, 0, W - 1, H - 1]            # the whole image
+    b[1] = [W - 3, H - 3, W + 40, H + 40]  # mostly outside
+    b[2] = [30.2, 40.7, 30.3, 40.8]        # sub-pixel -> forced to 1x1 on the map
+    b[3] = [50, 60, 40, 30]                # malformed (x2 < x1)
+    return b
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pooled,ratio", [(8, 2), (7, 2), (8, 1), (4, 4)])
+def test_hip_roi_align_single_level_bit_exact(pooled, ratio):
+    from veto_amd.poolers import ROIAlign
+    dev = torch.device("cuda:0")
+    rng = np.random.RandomState(pooled * 10 + ratio)
+    feat = rng.randn(2, 37, 50, 84).astype(F)
+    boxes = _random_boxes(rng, 23, 84 * 16, 50 * 16)
+    rois = np.concatenate([rng.randint(0, 2, size=(23, 1)).astype(F), boxes], 1)
+    got = ROIAlign((pooled, pooled), 1.0 / 16, ratio)(torch.from_numpy(feat).to(dev), torch.from_numpy(rois).to(dev)).cpu().numpy()
+    want = ro.roi_align(feat, rois, 1.0 / 16, pooled, ratio)
+    assert got.shape == want.shape == (23, 37, pooled, pooled)
+    assert np.array_equal(got, want), ((got != want).sum(), np.abs(got - want).max())
+
+
+@pytest.mark.gpu
+def test_hip_pooler_fpn_and_depth_bit_exact():
+    """VETOFeatureExtractor: 4 FPN levels + depth map, ROIs of all sizes -> (x_2d, d_2d, None, None)."""
+    from veto_amd import testing
+    from veto_amd.poolers import make_roi_box_feature_extractor
+    from veto_amd.structures import BoxList
+    dev = torch.device("cuda:0")
+    rng = np.random.RandomState(11)
+    W, H = 1024, 640
+    feats = [rng.randn(3, 256, H >> (2 + l), W >> (2 + l)).astype(F) for l in range(4)]
+    depth = rng.randn(3, 256, H >> 4, W >> 4).astype(F)
+    boxes = [_random_boxes(rng, n, W, H) for n in (9, 17, 5)]
+    cfg = testing.make_config(1, 8)
+    ext = make_roi_box_feature_extractor(cfg, 256, for_relation=True)
+    ext.pooler.keep_levels = True
+    props = [BoxList(torch.from_numpy(b), (W, H)).to(dev) for b in boxes]
+    x2d, d2d, x1d, d1d = ext([torch.from_numpy(f).to(dev) for f in feats], props, depth_features=torch.from_numpy(depth).to(dev))
+    assert x1d is None and d1d is None
+    want_rgb, want_dep = ro.pooler_forward(feats, boxes, depth)
+    lv = ro.map_levels(np.concatenate(boxes))
+    assert set(lv.tolist()) == {0, 1, 2, 3}
+    assert np.array_equal(ext.pooler.last_levels.cpu().numpy(), lv)
+    assert np.array_equal(x2d.cpu().numpy(), want_rgb)
+    assert np.array_equal(d2d.cpu().numpy(), want_dep)
+
+
+@pytest.mark.gpu
+def test_relation_head_from_feature_maps():
+    """ROIRelationHead.forward(features, proposals, targets, logger, depth_features) end to end on the device:
+    ROIAlign -> pairs -> predictor -> PostProcessor, against pooling with the oracle and feeding the same head."""
+    from veto_amd import synth, testing
+    from veto_amd.relation_head import VETORelationHead
+    dev = torch.device("cuda:0")
+    rng = np.random.RandomState(5)
+    W, H = 512, 384
+    feats = [rng.randn(2, 256, H >> (2 + l), W >> (2 + l)).astype(F) for l in range(4)]
+    depth = rng.randn(2, 256, H >> 4, W >> 4).astype(F)
+    num_objs = [6, 4]
+    batch = synth.synthetic_batch(13, 2, num_objs)
+    cfg = testing.make_config(2, 8)
+    head = VETORelationHead(cfg)
+    head.predictor = testing.make_predictor(cfg, synth.predictor_state_dict(3, layers=2), dev)
+    head.eval()
+    props = testing.make_proposals(batch, "predcls", dev)
+    roi, result, losses = head([torch.from_numpy(f).to(dev) for f in feats], props, None, None,
+                               depth_features=torch.from_numpy(depth).to(dev))
+    boxes, start = [], 0
+    for n in num_objs:
+        boxes.append(batch["boxes"][start:start + n])
+        start += n
+    want_rgb, want_dep = ro.pooler_forward(feats, boxes, depth)
+    assert np.array_equal(roi.cpu().numpy(), want_rgb)
+    props2 = testing.make_proposals(batch, "predcls", dev)
+    _, result2, _ = head.forward_pooled(props2, torch.from_numpy(want_rgb).to(dev), torch.from_numpy(want_dep).to(dev))
+    for a, b in zip(result, result2):
+        for f in ("rel_pair_idxs", "pred_rel_scores", "pred_rel_labels"):
+            assert torch.equal(a.get_field(f), b.get_field(f))

@@ -30,6 +30,7 @@ def default_config():
     rh.USE_GT_OBJECT_LABEL = True
     rh.POOLER_RESOLUTION = 8                      # VETO_final.yaml:57
     rh.MAX_PROPOSAL_PAIR = 2048
+    rh.FEATURE_EXTRACTOR_MINI = "VETOFeatureExtractor"   # VETO_final.yaml:71
     rh.CONTEXT_HIDDEN_DIM = 512
     rh.CONTEXT_POOLING_DIM = 4096
     vt = rh.VETOTRANSFORMER = CfgNode()
@@ -39,6 +40,12 @@ def default_config():
     vt.NHEADS = 6
     vt.EMB_DROPOUT = 0.35
     vt.T_DROPOUT = 0.35
+    bh = c.MODEL.ROI_BOX_HEAD = CfgNode()
+    bh.FEATURE_EXTRACTOR = "FPN2MLPFeatureExtractor"       # VETO_final.yaml:41 (the detector's own box head)
+    bh.POOLER_SCALES = (0.25, 0.125, 0.0625, 0.03125)      # VETO_final.yaml:39
+    bh.POOLER_SAMPLING_RATIO = 2                           # VETO_final.yaml:40
+    c.DATASETS = CfgNode()
+    c.DATASETS.USE_DEPTH = True
     c.GLOBAL_SETTING = CfgNode()
     c.GLOBAL_SETTING.DATASET_CHOICE = "VG"
     c.GLOBAL_SETTING.USE_BIAS = True
@@ -50,6 +57,7 @@ def default_config():
     c.ENSEMBLE_LEARNING.ENABLED = False
     c.ENSEMBLE_LEARNING.TYPE = ["group"]
     c.ENSEMBLE_LEARNING.EXPERT_GROUP = False      # VETO_final.yaml:154
+    c.ENSEMBLE_LEARNING.VOTING = "C"              # defaults.py:863
     c.TEST = CfgNode()
     c.TEST.RELATION = CfgNode()
     c.TEST.RELATION.LATER_NMS_PREDICTION_THRES = 0.3

@@ -131,4 +131,23 @@ hipError_t launch_postprocess_vote(PostArgs a, const VoteGroup* groups, int n_gr
 int postprocess_max_pairs_per_image();
 hipError_t launch_postprocess(const PostArgs& a, hipStream_t s);
 
+// ---- ROI feature extraction (roialign.hip) ----------------------------------------------------------
+struct RoiLevel {
+  const float* feat;             // [n_img, C, H, W]
+  int H, W;
+  float scale;
+};
+struct RoiPoolArgs {
+  RoiLevel lv[4];                // FPN levels of the RGB pyramid, finest first
+  RoiLevel depth;                // depth map (feat == nullptr: none)
+  int n_levels, k_min, k_max;    // LevelMapper range: -log2(first scale) .. -log2(last scale)
+  int n_roi, channels, depth_channels;
+  int pooled, sampling_ratio;
+  const float* rois;             // [n_roi, 5] (image index, x1, y1, x2, y2)
+  float* out_rgb;                // [n_roi, channels, pooled, pooled]
+  float* out_depth;              // [n_roi, depth_channels, pooled, pooled]
+  int32_t* out_levels;           // optional [n_roi]
+};
+hipError_t launch_roi_pool(const RoiPoolArgs& a, hipStream_t s);
+
 }  // namespace veto

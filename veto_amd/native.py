@@ -20,6 +20,7 @@ EXPORTS = [
     "veto_enumerate_pairs", "veto_profile_enable", "veto_profile_collect", "veto_profile_entry",
     "veto_profile_reset", "veto_debug_gemm", "veto_debug_gemm_workspace_bytes",
     "veto_postprocess", "veto_postprocess_workspace_bytes", "veto_postprocess_meet", "veto_postprocess_vote",
+    "veto_roi_pool",
 ]
 
 VETO_PRECISE, VETO_FAST = 0, 1
@@ -71,6 +72,15 @@ class VetoPostVoteArgs(Structure):
                                         "rel_labels_sorted", "triple_sorted", "kept_count")]
 
 
+class VetoRoiPoolArgs(Structure):
+    _fields_ = [(n, c_int32) for n in ("struct_size", "n_levels", "n_img", "n_roi", "channels", "depth_channels",
+                                       "pooled", "sampling_ratio")] + \
+               [("level_feat", c_void_p * 4), ("level_h", c_int32 * 4), ("level_w", c_int32 * 4),
+                ("level_scale", ctypes.c_float * 4), ("depth_feat", c_void_p), ("depth_h", c_int32),
+                ("depth_w", c_int32), ("rois", c_void_p), ("out_rgb", c_void_p), ("out_depth", c_void_p),
+                ("out_levels", c_void_p)]
+
+
 class VetoError(RuntimeError):
     pass
 
@@ -117,6 +127,7 @@ def load_library():
     lib.veto_postprocess.argtypes = [c_void_p, POINTER(VetoPostArgs), c_void_p, c_size_t]
     lib.veto_postprocess_meet.argtypes = [c_void_p, POINTER(VetoPostMeetArgs), c_void_p, c_size_t]
     lib.veto_postprocess_vote.argtypes = [c_void_p, POINTER(VetoPostVoteArgs), c_void_p, c_size_t]
+    lib.veto_roi_pool.argtypes = [c_void_p, POINTER(VetoRoiPoolArgs)]
     _LIB = lib
     return lib
 

@@ -6,8 +6,8 @@ test mode with GT boxes:
   :104-111  predcls: `predict_logits` overloaded with +-1000 one-hots of the GT labels
             (utils_motifs.py:92-107), `pred_scores` = 1, `pred_labels` = labels
   :134      rel_pair_idxs = samp_processor.prepare_test_pairs(device, proposals)
-  :140-141  ROI feature extraction (VETOFeatureExtractor / ROIAlign) -- NOT part of this module:
-            the pooled RGB / depth ROI maps are an input
+  :140-141  roi_features, d_2d, _, _ = box_feature_extractor(features, proposals, depth_features=...)
+            (VETOFeatureExtractor -> Pooler -> ROIAlign, veto_amd/poolers.py -> veto_roi_pool)
   :196-203  predictor(proposals, rel_pair_idxs, rel_labels, logger, roi_features=, roi_depth_features=)
   :229-230  object refine logits = the proposals' `predict_logits`
   :241-243  post_processor((relation_logits, obj_refine_logits), rel_pair_idxs, proposals, incre_idx_list=...)
@@ -17,6 +17,7 @@ from torch import nn
 
 from . import registry
 from .pairs import prepare_test_pairs
+from .poolers import make_roi_box_feature_extractor
 from .postprocess import make_roi_relation_post_processor
 
 
@@ -37,14 +38,25 @@ class VETORelationHead(nn.Module):
         if not rh.USE_GT_BOX:
             raise NotImplementedError("sgdet (detected boxes) is outside the built path")
         self.mode = "predcls" if rh.USE_GT_OBJECT_LABEL else "sgcls"
+        self.box_feature_extractor = make_roi_box_feature_extractor(cfg, in_channels, for_relation=True)  # :53
         self.predictor = registry.make_roi_relation_predictor(cfg, in_channels)
         self.post_processor = make_roi_relation_post_processor(cfg)
         self.num_obj_cls = self.predictor.num_obj_cls
         self.max_proposal_pairs = int(getattr(rh, "MAX_PROPOSAL_PAIR", 2048))
 
-    def forward(self, proposals, roi_features, roi_depth_features, logger=None):
-        """proposals: list[BoxList] on the HIP device; roi_features / roi_depth_features: [sum N, 256, 8, 8].
+    def forward(self, features, proposals, targets=None, logger=None, depth_features=None):
+        """The reference's signature (:90): features = list of FPN maps [B, 256, H_l, W_l], depth_features =
+        [B, 256, H/16, W/16], proposals = list[BoxList] (xyxy) on the HIP device.
         Returns (roi_features, result, {}) like the reference's test branch (:243)."""
+        if self.training:
+            raise NotImplementedError("veto_amd: the training branch (pair sampling, losses, backward) is not built")
+        if depth_features is None:
+            raise ValueError("the VETO predictors need depth_features (relation_head.py:141)")
+        roi_features, d_2d, _, _ = self.box_feature_extractor(features, proposals, depth_features=depth_features)
+        return self.forward_pooled(proposals, roi_features, d_2d, logger)
+
+    def forward_pooled(self, proposals, roi_features, roi_depth_features, logger=None):
+        """Same, from already pooled ROI maps [sum N, 256, 8, 8] (the rest of :104-243)."""
         if self.training:
             raise NotImplementedError("veto_amd: the training branch (pair sampling, losses, backward) is not built")
         device = roi_features.device

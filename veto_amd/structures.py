@@ -46,5 +46,12 @@ class BoxList:
             new.extra_fields[k] = v.to(device) if hasattr(v, "to") else v
         return new
 
+    def area(self):
+        """bounding_box.py:249-259: xyxy boxes use the +1 pixel convention."""
+        b = self.bbox
+        if self.mode == "xyxy":
+            return (b[:, 2] - b[:, 0] + 1) * (b[:, 3] - b[:, 1] + 1)
+        return b[:, 2] * b[:, 3]
+
     def __len__(self):
         return self.bbox.shape[0]
