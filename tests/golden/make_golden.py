@@ -330,15 +330,72 @@ def run_postprocessor_vote(cfg, BoxList, name, n, dataset, voting):
     print("%-24s expert voting %s: %d of %d rows kept" % (name, voting, out["rel_pair_idxs"].shape[0], len(sizes) * P_))
 
 
+SGG_EVAL_CASES = {"sggeval_predcls": (31, [6, 9, 12, 3, 15, 20, 2, 8], "predcls"),
+                  "sggeval_sgcls": (32, [6, 9, 12, 3, 15, 20, 2, 8], "sgcls")}
+
+
+def run_sgg_eval(cfg, BoxList, name):
+    """The reference's relation evaluators (sgg_eval.py) driven by its own per-image routine
+    (vg_eval.py:459-566 evaluate_relation_of_one_image) exactly as do_vg_evaluation does (:330-420), on
+    veto_amd.synth.synthetic_eval_images.  Stores the result_dict entries."""
+    import pysgg.data.datasets.evaluation.vg.vg_eval as ve
+    from pysgg.data.datasets.evaluation.vg.sgg_eval import (SGMeanRecall, SGNGMeanRecall, SGNoGraphConstraintRecall,
+                                                             SGPairAccuracy, SGRecall, SGZeroShotRecall)
+    seed, num_objs, mode = SGG_EVAL_CASES[name]
+    num_rel = 51
+    images, zeroshot = synth.synthetic_eval_images(seed, num_objs, mode, num_rel_cls=num_rel)
+    rd = {}
+    names = ["r%d" % i for i in range(num_rel)]
+    evaluator = {"eval_recall": SGRecall(rd), "eval_nog_recall": SGNoGraphConstraintRecall(rd),
+                 "eval_zeroshot_recall": SGZeroShotRecall(rd), "eval_pair_accuracy": SGPairAccuracy(rd),
+                 "eval_mean_recall": SGMeanRecall(rd, num_rel, names, print_detail=True),
+                 "eval_ng_mean_recall": SGNGMeanRecall(rd, num_rel, names, print_detail=True)}
+    for e in evaluator.values():
+        e.register_container(mode)
+    gc = {"zeroshot_triplet": zeroshot, "result_dict": rd, "mode": mode, "multiple_preds": False,
+          "num_rel_category": num_rel, "iou_thres": 0.5, "attribute_on": False, "num_attributes": 201}
+    for img in images:
+        gt = BoxList(torch.from_numpy(img["gt_boxes"]), (800, 600), mode="xyxy")
+        gt.add_field("relation_tuple", torch.from_numpy(img["gt_rels"]))
+        gt.add_field("labels", torch.from_numpy(img["gt_classes"]))
+        pr = BoxList(torch.from_numpy(img["pred_boxes"]), (800, 600), mode="xyxy")
+        pr.add_field("rel_pair_idxs", torch.from_numpy(img["pred_rel_inds"]))
+        pr.add_field("pred_rel_scores", torch.from_numpy(img["rel_scores"]))
+        pr.add_field("pred_labels", torch.from_numpy(img["pred_classes"]))
+        pr.add_field("pred_scores", torch.from_numpy(img["obj_scores"]))
+        ve.evaluate_relation_of_one_image(gt, pr, gc, evaluator)
+    evaluator["eval_mean_recall"].calculate_mean_recall(mode)
+    evaluator["eval_ng_mean_recall"].calculate_mean_recall(mode)
+    out = {"mode": mode, "seed": seed, "num_objs": np.array(num_objs), "num_rel": num_rel}
+    for key in ("recall", "recall_nogc", "zeroshot_recall", "accuracy_hit", "accuracy_count"):
+        for k in (20, 50, 100):
+            out["%s_%d" % (key, k)] = np.array(rd["%s_%s" % (mode, key)][k], dtype=np.float64)
+    for key in ("mean_recall", "ng_mean_recall"):
+        for k in (20, 50, 100):
+            out["%s_%d" % (key, k)] = np.array(rd["%s_%s" % (mode, key)][k], dtype=np.float64)
+            out["%s_list_%d" % (key, k)] = np.array(rd["%s_%s_list" % (mode, key)][k], dtype=np.float64)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print("%-24s %s R@20/50/100 = %s  mR@100 = %.4f  ngR@100 = %.4f" % (
+        name, mode, [round(float(np.mean(out["recall_%d" % k])), 4) for k in (20, 50, 100)],
+        float(out["mean_recall_100"]), float(np.mean(out["recall_nogc_100"]))))
+    print(evaluator["eval_recall"].generate_print_string(mode) + evaluator["eval_pair_accuracy"].generate_print_string(mode), end="")
+
+
 def main():
     torch.set_num_threads(8)
     P, cfg, BoxList = import_reference()
+    if os.environ.get("GOLDEN_ONLY") == "sggeval":   # regenerate only the evaluator fixtures
+        for name in SGG_EVAL_CASES:
+            run_sgg_eval(cfg, BoxList, name)
+        return
     if os.environ.get("GOLDEN_ONLY") == "experts":   # regenerate only the EXPERT_GROUP fixtures
         run_postprocessor_vote(cfg, BoxList, "postvote_vg_c_n10", 10, "VG", "C")
         run_postprocessor_vote(cfg, BoxList, "postvote_vg_u_n10", 10, "VG", "U")
         run_postprocessor_vote(cfg, BoxList, "postvote_gqa_c_n7", 7, "GQA", "C")
         run_case(P, cfg, BoxList, "meetx_n10_l4h8", "predcls", 4, 8, [10], meet=True, experts=True)
         return
+    for name in SGG_EVAL_CASES:
+        run_sgg_eval(cfg, BoxList, name)
     run_postprocessor_vote(cfg, BoxList, "postvote_vg_c_n10", 10, "VG", "C")
     run_postprocessor_vote(cfg, BoxList, "postvote_vg_u_n10", 10, "VG", "U")
     run_postprocessor_vote(cfg, BoxList, "postvote_gqa_c_n7", 7, "GQA", "C")

@@ -185,3 +185,72 @@ def synthetic_batch(seed, num_images, num_objs, num_obj_cls=151, channels=256, r
         "pred_labels": pred_labels, "predict_logits": predict_logits,
         "roi_features": rgb, "roi_depth_features": depth,
     }
+
+
+# ---------------------------------------------------------------------------
+# Evaluation inputs: ground truth + sorted predictions per image.
+# ---------------------------------------------------------------------------
+
+def synthetic_eval_images(seed, num_objs, mode="predcls", num_rel_cls=51, num_obj_cls=21):
+    """Per image: GT boxes / classes / relation tuples and a PostProcessor-shaped prediction (pairs sorted by
+    triple score, [P, num_rel_cls] probabilities, object labels / scores).  Division-only arithmetic (no
+    libm), so the arrays are bit-portable.  Near-duplicate boxes with equal classes make some predictions
+    match a GT relation through a DIFFERENT box index (IoU >= 0.5), and a fraction of the GT predicates is
+    boosted so that recall is neither 0 nor 1.  Also returns a zero-shot triplet table [Z, 3]
+    (subject class, object class, predicate) that holds part of the GT triplets."""
+    images, zs_rows = [], []
+    for i, n in enumerate(num_objs):
+        tag = "eval.%d." % i
+        xy = uniform(seed, tag + "xy", (n, 2), 0.0, 300.0)
+        wh = uniform(seed, tag + "wh", (n, 2), 30.0, 160.0)
+        boxes = np.concatenate([xy, xy + wh], 1).astype(np.float32)
+        classes = integers(seed, tag + "cls", (n,), 1, num_obj_cls)
+        dup = uniform01(seed, tag + "dup", n)
+        src = integers(seed, tag + "dupsrc", (n,), 0, max(n, 1))
+        jit = uniform(seed, tag + "jit", (n, 4), -6.0, 6.0)
+        for k in range(1, n):                     # ~30 %: a jittered copy of an earlier box, same class
+            if dup[k] < 0.3:
+                j = int(src[k]) % k
+                boxes[k] = boxes[j] + jit[k]
+                classes[k] = classes[j]
+        pairs = np.array([(a, b) for a in range(n) for b in range(n) if a != b], dtype=np.int64).reshape(-1, 2)
+        P = len(pairs)
+        n_gt = int(min(P, 3 + integers(seed, tag + "ngt", (1,), 0, 22)[0] + (40 if n >= 15 else 0)))
+        order = np.argsort(uniform01(seed, tag + "gtsel", P), kind="stable")[:n_gt]
+        u = uniform01(seed, tag + "gtpred", n_gt)
+        gt_pred = (1 + np.floor((u * u * np.sqrt(u)) * (num_rel_cls - 1))).astype(np.int64)   # skewed towards the head classes
+        gt_rels = np.concatenate([pairs[order], gt_pred[:, None]], 1)
+        if n_gt > 2:                              # a repeated pair with another predicate
+            extra = gt_rels[:1].copy()
+            extra[0, 2] = 1 + (extra[0, 2] % (num_rel_cls - 1))
+            gt_rels = np.concatenate([gt_rels, extra], 0)
+        w = uniform01(seed, tag + "w", P * num_rel_cls).reshape(P, num_rel_cls)
+        w = w * w * w
+        boost = uniform01(seed, tag + "boost", len(gt_rels))
+        row_of = {(int(a), int(b)): r for r, (a, b) in enumerate(pairs)}
+        for g, (s, o, r) in enumerate(gt_rels):
+            if boost[g] < 0.65:
+                w[row_of[(int(s), int(o))], int(r)] += 1.0 + 2.0 * boost[g]
+        rel_scores = (w / w.sum(1, keepdims=True)).astype(np.float32)
+        if mode == "predcls":
+            pred_classes = classes.copy()
+            obj_scores = np.ones(n, dtype=np.float32)
+        else:
+            flip = uniform01(seed, tag + "flip", n) < 0.2
+            alt = integers(seed, tag + "alt", (n,), 1, num_obj_cls)
+            pred_classes = np.where(flip, alt, classes)
+            obj_scores = uniform(seed, tag + "objs", (n,), 0.3, 1.0)
+        triple = rel_scores[:, 1:].max(1) * obj_scores[pairs[:, 0]] * obj_scores[pairs[:, 1]]
+        srt = np.argsort(-triple, kind="stable")
+        images.append({
+            "gt_rels": gt_rels.astype(np.int64), "gt_classes": classes.astype(np.int64), "gt_boxes": boxes,
+            "pred_rel_inds": pairs[srt], "rel_scores": rel_scores[srt], "pred_classes": pred_classes.astype(np.int64),
+            "pred_boxes": boxes.copy(), "obj_scores": obj_scores,
+        })
+        zsel = uniform01(seed, tag + "zs", len(gt_rels)) < 0.35
+        for (s, o, r) in gt_rels[zsel]:
+            zs_rows.append((classes[s], classes[o], r))
+    filler = integers(seed, "eval.zs_filler", (40, 3), 1, num_obj_cls)
+    filler[:, 2] = 1 + filler[:, 2] % (num_rel_cls - 1)
+    zeroshot = np.concatenate([np.array(zs_rows, dtype=np.int64).reshape(-1, 3), filler.astype(np.int64)], 0)
+    return images, zeroshot
