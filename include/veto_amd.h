@@ -219,6 +219,48 @@ typedef struct veto_roi_pool_args {
 
 int veto_roi_pool(void* stream, const veto_roi_pool_args_t* args);
 
+/* ---- relation evaluators -----------------------------------------------
+ * evaluate_relation_of_one_image (pysgg/data/datasets/evaluation/vg/vg_eval.py:459-566) over the evaluator
+ * classes of sgg_eval.py for the GT-box modes: SGRecall (:121-187), SGNoGraphConstraintRecall (:195-255),
+ * SGZeroShotRecall (:263-313), SGPairAccuracy (:322-369), SGMeanRecall (:377-466), SGNGMeanRecall (:470-546),
+ * and their accumulation over the data set, K = 20 / 50 / 100.  Images are concatenated; the *_off arrays
+ * are exclusive prefix sums.  For predcls pass the GT classes / boxes as the predicted ones and obj_scores = 1
+ * (vg_eval.py:517-520).  Images without GT relations or without predictions contribute nothing (:474, :544). */
+typedef struct veto_sgg_eval_args {
+  int32_t struct_size;
+  int32_t n_img;
+  int32_t n_rel_cls;               /* 51 */
+  int32_t n_zeroshot;
+  float iou_thres;                 /* TEST.RELATION.IOU_THRESHOLD (0.5) */
+  int32_t reserved0;
+  const int32_t* gt_offset;        /* device [n_img + 1] GT relations */
+  const int32_t* obj_offset;       /* device [n_img + 1] objects */
+  const int32_t* pair_offset;      /* device [n_img + 1] predicted pairs */
+  const int64_t* gt_rels;          /* device [sum G, 3]: subject, object (image-local), predicate  ('relation_tuple') */
+  const int64_t* gt_classes;       /* device [sum N]  ('labels') */
+  const float* gt_boxes;           /* device [sum N, 4] xyxy */
+  const int64_t* pred_pairs;       /* device [sum P, 2] in ranking order  ('rel_pair_idxs') */
+  const float* rel_scores;         /* device [sum P, n_rel_cls]           ('pred_rel_scores') */
+  const int64_t* pred_classes;     /* device [sum N]  ('pred_labels') */
+  const float* pred_boxes;         /* device [sum N, 4] */
+  const float* obj_scores;         /* device [sum N]  ('pred_scores') */
+  const int64_t* zeroshot;         /* device [n_zeroshot, 3]: subject class, object class, predicate */
+  int32_t* gc_rank;                /* out device [sum G]: index of the first matching prediction, 0x3fffffff = none */
+  int32_t* ng_rank;                /* out device [sum G]: the same in the no-graph-constraint top-100 list */
+  int32_t* acc_rank;               /* out device [sum G]: the same, counted among the predictions on GT pairs */
+  int32_t* zeroshot_flag;          /* out device [sum G] */
+  int32_t* ng_rows;                /* out device [n_img, 100]: pair index of the i-th no-graph-constraint entry */
+  int32_t* ng_cols;                /* out device [n_img, 100]: its predicate */
+  int32_t* ng_count;               /* out device [n_img]: entries in that list (min(100, P * (n_rel_cls - 1))) */
+  double* metrics;                 /* out device [18 + 6 * (n_rel_cls - 1) + 2]: R@20/50/100, ngR, zR, A, mR, ng-mR,
+                                      per-class recall lists [2 kinds][3 K][n_rel_cls - 1], images evaluated,
+                                      images with a zero-shot relation */
+} veto_sgg_eval_args_t;
+
+size_t veto_sgg_eval_workspace_bytes(int32_t n_img, int32_t n_pair_total, int32_t n_gt_total, int32_t n_rel_cls);
+int veto_sgg_eval(void* stream, const veto_sgg_eval_args_t* args, int32_t n_pair_total, int32_t n_gt_total,
+                  void* workspace, size_t workspace_bytes);
+
 /* ---- measurement hooks (bench.py): per-kernel device time from hipEvents on `stream` ---------- */
 int veto_profile_enable(veto_handle_t h, int32_t on);
 /* Synchronises the recorded events; returns the number of distinct kernels. */

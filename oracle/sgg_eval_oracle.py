@@ -21,7 +21,7 @@ built on _triplet (:44-75), _compute_pred_matches (:78-118), intersect_2d / args
 import numpy as np
 
 KS = (20, 50, 100)
-NO_MATCH = 1 << 30
+NO_MATCH = 0x3fffffff
 
 
 def box_iou(a, b):

@@ -150,4 +150,32 @@ struct RoiPoolArgs {
 };
 hipError_t launch_roi_pool(const RoiPoolArgs& a, hipStream_t s);
 
+// ---- relation evaluators (sgg_eval.hip) ---------------------------------------------------------------
+struct SggEvalArgs {
+  int n_img, n_rel_cls, n_zeroshot;
+  float iou_thres;
+  const int32_t* gt_off;         // [n_img + 1] prefix sum of GT relations
+  const int32_t* obj_off;        // [n_img + 1] prefix sum of objects
+  const int32_t* pair_off;       // [n_img + 1] prefix sum of predicted pairs
+  const int64_t* gt_rels;        // [sum G, 3] (subject, object, predicate), image-local indices
+  const int64_t* gt_classes;     // [sum N]
+  const float* gt_boxes;         // [sum N, 4] xyxy
+  const int64_t* pred_pairs;     // [sum P, 2], in ranking order per image
+  const float* rel_scores;       // [sum P, n_rel_cls]
+  const int64_t* pred_classes;   // [sum N]
+  const float* pred_boxes;       // [sum N, 4]
+  const float* obj_scores;       // [sum N]
+  const int64_t* zeroshot;       // [n_zeroshot, 3] (subject class, object class, predicate)
+  int32_t *gc_rank, *ng_rank, *acc_rank, *zeroshot_flag;   // out [sum G]
+  int32_t *ng_rows, *ng_cols;    // out [n_img, 100]
+  int32_t* ng_count;             // out [n_img]
+  double* metrics;               // out [18 + 6 * (n_rel_cls - 1) + 2]
+  int32_t *label_tmp, *flag_tmp, *flag_before;             // workspace [sum P]
+  float* pair_score;             // workspace [sum P]
+  uint32_t* row_key;             // workspace [sum P]: sortable key of the row's largest cell
+  int32_t* acc_first;            // workspace [sum G]
+  int32_t* cls_table;            // workspace [n_img, 7, n_rel_cls]
+};
+hipError_t launch_sgg_eval(const SggEvalArgs& a, hipStream_t s);
+
 }  // namespace veto

@@ -659,6 +659,46 @@ int veto_roi_pool(void* stream, const veto_roi_pool_args_t* a) {
   return VETO_OK;
 }
 
+size_t veto_sgg_eval_workspace_bytes(int32_t n_img, int32_t n_pair_total, int32_t n_gt_total, int32_t n_rel_cls) {
+  if (n_img <= 0 || n_pair_total < 0 || n_gt_total < 0 || n_rel_cls < 2) return 0;
+  return 5 * align_up((size_t)n_pair_total * 4 + 4, 256) + align_up((size_t)n_gt_total * 4 + 4, 256) +
+         align_up((size_t)n_img * 7 * n_rel_cls * 4, 256);
+}
+
+int veto_sgg_eval(void* stream, const veto_sgg_eval_args_t* a, int32_t n_pair_total, int32_t n_gt_total, void* workspace,
+                  size_t workspace_bytes) {
+  if (!a || !workspace) return fail(VETO_ERR_INVALID, "null argument");
+  if (a->struct_size != (int32_t)sizeof(veto_sgg_eval_args_t)) return fail(VETO_ERR_INVALID, "veto_sgg_eval_args_t size mismatch");
+  if (a->n_img <= 0 || a->n_rel_cls < 2 || a->n_rel_cls > 4096 || a->n_zeroshot < 0 || n_pair_total < 0 || n_gt_total < 0)
+    return fail(VETO_ERR_INVALID, "bad sizes");
+  if (!(a->iou_thres >= 0.f && a->iou_thres <= 1.f)) return fail(VETO_ERR_INVALID, "iou_thres must be in [0, 1]");
+  if (!a->gt_offset || !a->obj_offset || !a->pair_offset || !a->gt_rels || !a->gt_classes || !a->gt_boxes || !a->pred_pairs ||
+      !a->rel_scores || !a->pred_classes || !a->pred_boxes || !a->obj_scores || (a->n_zeroshot > 0 && !a->zeroshot) ||
+      !a->gc_rank || !a->ng_rank || !a->acc_rank || !a->zeroshot_flag || !a->ng_rows || !a->ng_cols || !a->ng_count || !a->metrics)
+    return fail(VETO_ERR_INVALID, "missing pointer");
+  if (workspace_bytes < veto_sgg_eval_workspace_bytes(a->n_img, n_pair_total, n_gt_total, a->n_rel_cls))
+    return fail(VETO_ERR_WORKSPACE, "workspace too small");
+  SggEvalArgs p{};
+  p.n_img = a->n_img; p.n_rel_cls = a->n_rel_cls; p.n_zeroshot = a->n_zeroshot; p.iou_thres = a->iou_thres;
+  p.gt_off = a->gt_offset; p.obj_off = a->obj_offset; p.pair_off = a->pair_offset;
+  p.gt_rels = a->gt_rels; p.gt_classes = a->gt_classes; p.gt_boxes = a->gt_boxes;
+  p.pred_pairs = a->pred_pairs; p.rel_scores = a->rel_scores; p.pred_classes = a->pred_classes;
+  p.pred_boxes = a->pred_boxes; p.obj_scores = a->obj_scores; p.zeroshot = a->zeroshot;
+  p.gc_rank = a->gc_rank; p.ng_rank = a->ng_rank; p.acc_rank = a->acc_rank; p.zeroshot_flag = a->zeroshot_flag;
+  p.ng_rows = a->ng_rows; p.ng_cols = a->ng_cols; p.ng_count = a->ng_count; p.metrics = a->metrics;
+  char* base = (char*)workspace;
+  const size_t per_pair = align_up((size_t)n_pair_total * 4 + 4, 256);
+  p.label_tmp = (int32_t*)base; base += per_pair;
+  p.flag_tmp = (int32_t*)base; base += per_pair;
+  p.flag_before = (int32_t*)base; base += per_pair;
+  p.pair_score = (float*)base; base += per_pair;
+  p.row_key = (uint32_t*)base; base += per_pair;
+  p.acc_first = (int32_t*)base; base += align_up((size_t)n_gt_total * 4 + 4, 256);
+  p.cls_table = (int32_t*)base;
+  HIP_TRY(launch_sgg_eval(p, (hipStream_t)stream));
+  return VETO_OK;
+}
+
 int veto_profile_enable(veto_handle_t h, int32_t on) {
   if (!h) return fail(VETO_ERR_INVALID, "null handle");
   h->prof_on = on != 0;

@@ -20,7 +20,7 @@ EXPORTS = [
     "veto_enumerate_pairs", "veto_profile_enable", "veto_profile_collect", "veto_profile_entry",
     "veto_profile_reset", "veto_debug_gemm", "veto_debug_gemm_workspace_bytes",
     "veto_postprocess", "veto_postprocess_workspace_bytes", "veto_postprocess_meet", "veto_postprocess_vote",
-    "veto_roi_pool",
+    "veto_roi_pool", "veto_sgg_eval", "veto_sgg_eval_workspace_bytes",
 ]
 
 VETO_PRECISE, VETO_FAST = 0, 1
@@ -81,6 +81,15 @@ class VetoRoiPoolArgs(Structure):
                 ("out_levels", c_void_p)]
 
 
+class VetoSggEvalArgs(Structure):
+    _fields_ = [("struct_size", c_int32), ("n_img", c_int32), ("n_rel_cls", c_int32), ("n_zeroshot", c_int32),
+                ("iou_thres", ctypes.c_float), ("reserved0", c_int32)] + \
+               [(n, c_void_p) for n in ("gt_offset", "obj_offset", "pair_offset", "gt_rels", "gt_classes", "gt_boxes",
+                                        "pred_pairs", "rel_scores", "pred_classes", "pred_boxes", "obj_scores", "zeroshot",
+                                        "gc_rank", "ng_rank", "acc_rank", "zeroshot_flag", "ng_rows", "ng_cols", "ng_count",
+                                        "metrics")]
+
+
 class VetoError(RuntimeError):
     pass
 
@@ -128,6 +137,9 @@ def load_library():
     lib.veto_postprocess_meet.argtypes = [c_void_p, POINTER(VetoPostMeetArgs), c_void_p, c_size_t]
     lib.veto_postprocess_vote.argtypes = [c_void_p, POINTER(VetoPostVoteArgs), c_void_p, c_size_t]
     lib.veto_roi_pool.argtypes = [c_void_p, POINTER(VetoRoiPoolArgs)]
+    lib.veto_sgg_eval_workspace_bytes.argtypes = [c_int32, c_int32, c_int32, c_int32]
+    lib.veto_sgg_eval_workspace_bytes.restype = c_size_t
+    lib.veto_sgg_eval.argtypes = [c_void_p, POINTER(VetoSggEvalArgs), c_int32, c_int32, c_void_p, c_size_t]
     _LIB = lib
     return lib
 
