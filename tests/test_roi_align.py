@@ -205,3 +205,63 @@ def test_relation_head_from_feature_maps():
     for a, b in zip(result, result2):
         for f in ("rel_pair_idxs", "pred_rel_scores", "pred_rel_labels"):
             assert torch.equal(a.get_field(f), b.get_field(f))
+
+
+@pytest.mark.gpu
+def test_device_eval_chain_feature_maps_to_recall():
+    """The whole test-time chain of the relation head stays on the device: FPN / depth maps -> ROIAlign -> pair
+    enumeration -> predictor -> PostProcessor -> SGG evaluators, against the same chain through the oracles
+    (ROI pooling bit-exact, logits within 1e-3, so the recall numbers agree unless a near-tie flips a rank)."""
+    from oracle import sgg_eval_oracle as so
+    from oracle import veto_oracle as vo
+    from veto_amd import synth, testing
+    from veto_amd.evaluation import SGGEvaluator
+    from veto_amd.relation_head import VETORelationHead
+    dev = torch.device("cuda:0")
+    rng = np.random.RandomState(9)
+    W, H = 512, 384
+    feats = [(0.5 * rng.randn(3, 256, H >> (2 + l), W >> (2 + l))).astype(F) for l in range(4)]
+    depth = (0.5 * rng.randn(3, 256, H >> 4, W >> 4)).astype(F)
+    num_objs = [7, 5, 9]
+    batch = synth.synthetic_batch(21, 3, num_objs)
+    sd = synth.predictor_state_dict(4, layers=2)
+    cfg = testing.make_config(2, 8)
+    head = VETORelationHead(cfg)
+    head.predictor = testing.make_predictor(cfg, sd, dev)
+    head.eval()
+    props = testing.make_proposals(batch, "predcls", dev)
+    _, result, _ = head([torch.from_numpy(f).to(dev) for f in feats], props, None, None, depth_features=torch.from_numpy(depth).to(dev))
+    # ground truth: a few relations per image whose predicate is what the ORACLE chain ranks first for that pair
+    boxes, start = [], 0
+    for n in num_objs:
+        boxes.append(batch["boxes"][start:start + n])
+        start += n
+    rgb, dep = ro.pooler_forward(feats, boxes, depth)
+    obatch = dict(batch, roi_features=rgb, roi_depth_features=dep)
+    logits, _, _ = vo.forward(sd, vo.OracleConfig(layers=2, heads=8), obatch)
+    pairs = [vo.enumerate_test_pairs(n) for n in num_objs]
+    onehot = np.full((sum(num_objs), 151), -1000.0, dtype=np.float32)
+    onehot[np.arange(sum(num_objs)), batch["labels"]] = 1000.0
+    ref_post = vo.postprocess(logits.numpy(), onehot, pairs, num_objs)
+    gts, ref_images, start = [], [], 0
+    for i, (n, r) in enumerate(zip(num_objs, ref_post)):
+        top = r["rel_pair_idxs"].numpy()[[0, 3, 11, 17]]
+        lab = r["pred_rel_labels"].numpy()[[0, 3, 11, 17]]
+        gt_rels = np.concatenate([top, lab[:, None]], 1)
+        gt_rels[3, 2] = 1 + gt_rels[3, 2] % 50            # one relation the model gets wrong
+        labels = batch["labels"][start:start + n]
+        gts.append((gt_rels, labels, boxes[i]))
+        ref_images.append({"gt_rels": gt_rels, "gt_classes": labels, "gt_boxes": boxes[i], "pred_rel_inds": r["rel_pair_idxs"].numpy(),
+                           "rel_scores": r["pred_rel_scores"].numpy(), "pred_classes": labels, "pred_boxes": boxes[i],
+                           "obj_scores": np.ones(n, dtype=F)})
+        start += n
+    zeroshot = np.array([[1, 1, 1]], dtype=np.int64)
+    dev_images = [{"gt_rels": g[0], "gt_classes": g[1], "gt_boxes": g[2], "pred_rel_inds": r.get_field("rel_pair_idxs"),
+                   "rel_scores": r.get_field("pred_rel_scores"), "pred_classes": r.get_field("pred_labels"),
+                   "pred_boxes": r.bbox, "obj_scores": r.get_field("pred_scores")} for g, r in zip(gts, result)]
+    got = SGGEvaluator("predcls", 51, zeroshot, device=dev).evaluate(dev_images)
+    want = so.evaluate(ref_images, "predcls", zeroshot, 51)
+    assert abs(got["recall"][100] - 0.75) < 1e-9 and abs(want["recall"][100] - 0.75) < 1e-9   # 3 of 4 GT relations per image
+    for k in (20, 50, 100):
+        assert abs(got["recall"][k] - want["recall"][k]) <= 1.0 / 12 + 1e-9
+        assert abs(got["mean_recall"][k] - want["mean_recall"][k]) <= 0.05
