@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256) void roi_pool_kernel(RoiPoolArgs a) {
   const float count = (float)(G * G);
   const size_t plane_sz = (size_t)L.H * L.W;
   float* out = (depth ? a.out_depth : a.out_rgb) + (size_t)r * C * P * P;
-#pragma unroll 2
+#pragma unroll 4
   for (int c = c0 + wv; c < c0 + kSlab && c < C; c += 4) {
     const float* plane = L.feat + ((size_t)b * C + c) * plane_sz;
     float v[G * G][4];
