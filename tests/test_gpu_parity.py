@@ -470,3 +470,29 @@ def test_plain_gemm_variant_matches_persistent_variant(tmp_path):
     assert np.array_equal(res["ps"], res["plain"])
     g, _, _ = load_golden("predcls_n36_l4h8")
     assert np.abs(res["plain"] - g["rel_dists"]).max() <= LOGIT_TOL
+
+
+def test_large_image_with_pair_cap_against_oracle():
+    """One image with 64 objects in sgcls: 4032 candidate pairs, cut to MAX_PROPOSAL_PAIR = 2048 by score product
+    (sampling.py:41-45); the selected pairs (whatever order the device sort gives to ties) go through the
+    predictor and must match the oracle on exactly those pairs."""
+    from oracle import veto_oracle as vo
+    from veto_amd import synth, testing
+    from veto_amd.pairs import prepare_test_pairs
+    dev = _dev()
+    sd = synth.predictor_state_dict(6, layers=2)
+    batch = synth.synthetic_batch(19, 1, [64])
+    cfg = testing.make_config(2, 8, "sgcls")
+    model = testing.make_predictor(cfg, sd, dev)
+    props = testing.make_proposals(batch, "sgcls", dev)
+    props[0].add_field("pred_scores", torch.from_numpy(synth.uniform(19, "cap.scores", (64,), 0.05, 1.0)).to(dev))
+    pairs = prepare_test_pairs(dev, props)
+    assert pairs[0].shape == (2048, 2) and (pairs[0][:, 0] != pairs[0][:, 1]).all()
+    q = props[0].get_field("pred_scores")
+    kept = (q[pairs[0][:, 0]] * q[pairs[0][:, 1]]).min().item()
+    allp = torch.nonzero(torch.ones(64, 64, device=dev) - torch.eye(64, device=dev))
+    assert ((q[allp[:, 0]] * q[allp[:, 1]]) > kept).sum().item() <= 2048      # nothing better was left out
+    out, _ = _run(model, batch, "sgcls", dev, pairs=pairs)
+    ref, _, _ = vo.forward(sd, vo.OracleConfig(layers=2, heads=8, mode="sgcls"), batch, rel_pair_idxs=[pairs[0].cpu().numpy()])
+    err = (torch.cat(list(out[1])).cpu() - ref).abs().max().item()
+    assert err <= LOGIT_TOL, err
