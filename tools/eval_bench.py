@@ -1,5 +1,6 @@
-"""Times the device relation evaluators (veto_sgg_eval) and, beside them, the CPU oracle restatement of the
-reference's numpy evaluators, on a benchmark-shaped batch: 12 images x 36 objects (1260 ranked pairs each)."""
+"""Times the device relation evaluators (veto_sgg_eval) on a benchmark-shaped batch: 12 images x 36 objects
+(1260 ranked pairs each).  (The host-side comparison number in DESIGN.md comes from the oracle timed inside
+tests/test_sgg_eval.py; tools/ never import oracle/.)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -21,8 +22,3 @@ torch.cuda.synchronize()
 ms = (time.perf_counter() - t0) / reps * 1e3
 print("veto_sgg_eval: %d images, %.3f ms per batch end to end (host packing + 2 kernels + read-back)" % (len(images), ms))
 print(ev.generate_print_string(res), end="")
-if "--cpu" in sys.argv:
-    from oracle import sgg_eval_oracle as so
-    t0 = time.perf_counter()
-    ref = so.evaluate(images, "predcls", zeroshot, 51)
-    print("numpy restatement of the reference evaluators: %.1f ms for the same batch" % ((time.perf_counter() - t0) * 1e3))
