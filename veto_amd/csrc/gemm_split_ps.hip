@@ -44,6 +44,10 @@ constexpr int kDumpOff = 3 * kABytes + 2 * kWBytes;
 constexpr int kPrefSteps = BN * 4 / 128;      // 6: 128-byte lines per residual row of a tile
 constexpr int CPA = BM / 8 / NLOAD;           // 8 A chunks (8 rows x 128 B) per loader wave and stage
 constexpr int CPWL = BN / 8 / NLOAD;          // 6 W chunks
+#ifndef VETO_GEMM_EPI_T
+#define VETO_GEMM_EPI_T 1
+#endif
+constexpr bool kEpiT = VETO_GEMM_EPI_T;       // epilogue lane transposition (A/B knob; results identical)
 
 __device__ __forceinline__ void glds16(const char* src, char* lds_dst) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
@@ -275,35 +279,52 @@ __global__ __launch_bounds__(64 * (NCONS + NLOAD), 3) void gemm_split_ps_kernel(
       ACC(a_bar, t1, t0); ACC(a_cmp, t2, t1);
     }
 
-    // epilogue: lane holds C[row lane&15 of m-tile][4 consecutive columns]; stores are not waited for.
-    // EPI_RESID: the residual reads of row group m+1 are issued BEFORE the stores of group m (vmcnt
-    // counts loads and stores in issue order, so a load issued after a store would have to wait for
-    // it; and c may alias resid, which stops the compiler from hoisting the loads by itself).
+    // epilogue.  The MFMA leaves lane l with C[row l&15 of the 16-row group][4 consecutive columns of chunk
+    // l>>4]: four neighbouring lanes hold four DIFFERENT rows, so a 16-byte store per lane reaches memory as
+    // 64 separate 16-byte pieces.  kEpiT: a ds_bpermute per value (lane 4r+q takes the value of lane 16q+r)
+    // turns that into lane = (row r = l>>2, chunk q = l&3): every quad of lanes writes 64 contiguous bytes of
+    // one row, and the residual is read the same way.  Values and the order of the additions are unchanged.
+    // Stores are not waited for.  EPI_RESID: the residual reads of row group m+1 are issued BEFORE the
+    // stores of group m (vmcnt counts loads and stores in issue order, so a load issued after a store would
+    // have to wait for it; and c may alias resid, which stops the compiler from hoisting the loads by itself).
+    const int er = kEpiT ? lane >> 2 : lane & 15;   // row inside a 16-row group
+    const int eq = kEpiT ? lane & 3 : lane >> 4;    // 16-byte chunk inside a 16-column group
+    const int perm_addr = ((eq << 4) + er) << 2;    // byte address of the source lane for ds_bpermute
     f32x4 bias_v[6];
 #pragma unroll
     for (int n = 0; n < 6; ++n)
-      bias_v[n] = g.bias ? *(const f32x4*)(g.bias + tile_n * BN + wn * 96 + n * 16 + (lane >> 4) * 4)
+      bias_v[n] = g.bias ? *(const f32x4*)(g.bias + tile_n * BN + wn * 96 + n * 16 + eq * 4)
                          : f32x4{0.f, 0.f, 0.f, 0.f};
-    const int row0 = tile_m * BM + wm * 64 + (lane & 15);
-    const int col0 = tile_n * BN + wn * 96 + (lane >> 4) * 4;
-    f32x4 res[2][6];
-    auto load_res = [&](int m, f32x4 (&r)[6]) {
-      int row = row0 + m * 16;
+    const int row0 = tile_m * BM + wm * 64 + er;
+    const int col0 = tile_n * BN + wn * 96 + eq * 4;
+    // the epilogue walks 8 units of (16-row group m, half h of the 6 column groups); the residual of unit
+    // u+1 is in flight while unit u is stored (two buffers of 3 x 4 registers next to the 96 accumulators)
+    f32x4 res[2][3];
+    auto load_res = [&](int u, f32x4 (&r)[3]) {
+      int row = row0 + (u >> 1) * 16;
       if (row >= g.M) row = g.M - 1;  // clamp: the value is never stored
 #pragma unroll
-      for (int n = 0; n < 6; ++n) r[n] = *(const f32x4*)(g.resid + (size_t)row * g.ldr + col0 + n * 16);
+      for (int j = 0; j < 3; ++j) r[j] = *(const f32x4*)(g.resid + (size_t)row * g.ldr + col0 + ((u & 1) * 3 + j) * 16);
     };
     if (EPI == EPI_RESID) load_res(0, res[0]);
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
-      if (EPI == EPI_RESID && m < 3) load_res(m + 1, res[(m + 1) & 1]);
+    for (int u = 0; u < 8; ++u) {
+      const int m = u >> 1;
+      if (EPI == EPI_RESID && u < 7) load_res(u + 1, res[(u + 1) & 1]);
       const int row = row0 + m * 16;
-      if (row < g.M) {
 #pragma unroll
-        for (int n = 0; n < 6; ++n) {
+      for (int j = 0; j < 3; ++j) {
+        const int n = (u & 1) * 3 + j;
+        f32x4 t = acc[n][m];
+        if (kEpiT) {   // executed by every lane: rows past M hold values other lanes need
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            t[e] = __int_as_float(__builtin_amdgcn_ds_bpermute(perm_addr, __float_as_int(acc[n][m][e])));
+        }
+        if (row < g.M) {
           const int col = col0 + n * 16;
-          f32x4 v = acc[n][m] + bias_v[n];
-          if (EPI == EPI_RESID) v += res[m & 1][n];
+          f32x4 v = t + bias_v[n];
+          if (EPI == EPI_RESID) v += res[u & 1][j];
           if (EPI == EPI_GELU_SPLIT) {
             bf16x4 hi, lo;
 #pragma unroll
