@@ -53,7 +53,10 @@ class SGGEvaluator:
     def evaluate(self, images):
         dev, lib = self.device, native.load_library()
         i64, f32, i32 = torch.int64, torch.float32, torch.int32
-        cat = lambda key, dtype, shape: torch.cat([_t(im[key], dtype, dev).reshape(shape) for im in images], 0).contiguous()
+        def cat(key, dtype, shape):
+            t = torch.cat([_t(im[key], dtype, dev).reshape(shape) for im in images], 0).contiguous()
+            # an all-empty field still needs a valid device pointer for the ABI's argument check
+            return t if t.numel() else torch.zeros((1,) + tuple(abs(d) for d in shape[1:]), dtype=dtype, device=dev)
         gt_rels = cat("gt_rels", i64, (-1, 3))
         gt_classes, gt_boxes = cat("gt_classes", i64, (-1,)), cat("gt_boxes", f32, (-1, 4))
         pred_pairs, rel_scores = cat("pred_rel_inds", i64, (-1, 2)), cat("rel_scores", f32, (-1, self.num_rel))
@@ -65,9 +68,10 @@ class SGGEvaluator:
             obj_scores = cat("obj_scores", f32, (-1,))
             if pred_boxes.shape[0] != gt_boxes.shape[0]:
                 raise ValueError("sgcls: the number of predicted boxes must equal the number of GT boxes")
-        n_g = [int(np.asarray(im["gt_rels"].cpu() if isinstance(im["gt_rels"], torch.Tensor) else im["gt_rels"]).reshape(-1, 3).shape[0]) for im in images]
+        rows = lambda x, width: int(x.numel() // width) if isinstance(x, torch.Tensor) else int(np.asarray(x).size // width)
+        n_g = [rows(im["gt_rels"], 3) for im in images]
         n_o = [int(len(im["gt_classes"])) for im in images]
-        n_p = [int(np.asarray(im["pred_rel_inds"].cpu() if isinstance(im["pred_rel_inds"], torch.Tensor) else im["pred_rel_inds"]).reshape(-1, 2).shape[0]) for im in images]
+        n_p = [rows(im["pred_rel_inds"], 2) for im in images]
         off = lambda xs: torch.tensor([0] + list(np.cumsum(xs)), dtype=i32, device=dev)
         gt_off, obj_off, pair_off = off(n_g), off(n_o), off(n_p)
         n_img, sum_g, sum_p, C = len(images), sum(n_g), sum(n_p), self.num_rel
