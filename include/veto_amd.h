@@ -219,6 +219,15 @@ typedef struct veto_roi_pool_args {
 
 int veto_roi_pool(void* stream, const veto_roi_pool_args_t* args);
 
+/* Backward of veto_roi_pool (pysgg/csrc/cuda/ROIAlign_cuda.cu:178-262 RoIAlignBackwardFeature behind
+ * layers/roi_align.py:27-44): `args` describes the forward call (shapes, scales, rois; its feature / output
+ * pointers are not read), grad_rgb / grad_depth are the gradients of the two pooled tensors, level_grad[l] /
+ * depth_grad receive the map gradients (same shapes as the maps; ZERO-INITIALISED BY THE CALLER, accumulated
+ * with atomic adds, so the summation order -- not the result up to rounding -- varies from run to run).
+ * grad_depth / depth_grad may be NULL. */
+int veto_roi_pool_backward(void* stream, const veto_roi_pool_args_t* args, const float* grad_rgb, const float* grad_depth,
+                           float* const* level_grad, float* depth_grad);
+
 /* ---- relation evaluators -----------------------------------------------
  * evaluate_relation_of_one_image (pysgg/data/datasets/evaluation/vg/vg_eval.py:459-566) over the evaluator
  * classes of sgg_eval.py for the GT-box modes: SGRecall (:121-187), SGNoGraphConstraintRecall (:195-255),

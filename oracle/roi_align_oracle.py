@@ -1,7 +1,7 @@
 """CPU restatement of the ROI feature extraction next to the VETO hot path.
 
 TEST INFRASTRUCTURE ONLY: imported by tests/ and nothing else; the product path is
-veto_amd/csrc/roialign.hip behind veto_roi_align / veto_roi_pool_fpn.
+veto_amd/csrc/roialign.hip behind veto_roi_pool / veto_roi_pool_backward.
 
 PARITY UNPINNED against executed reference code: the reference's ROIAlign lives in its C++/CUDA
 extension (pysgg/csrc/cpu/ROIAlign_cpu.cpp, pysgg/csrc/cuda/ROIAlign_cuda.cu), which does not compile
@@ -11,7 +11,8 @@ pysgg/modeling/poolers.py imports torchvision, which is absent.  What pins this 
   * it restates the published legacy ("aligned=False") ROIAlign line by line (citations below);
   * analytic known answers in tests/test_roi_align.py: on an affine feature map f(y, x) = a*y + b*x + c
     bilinear sampling is exact, so every interior bin must equal f at the bin centre; constant maps,
-    hand-computed border / out-of-map samples, and the FPN level boundaries of the LevelMapper formula.
+    hand-computed border / out-of-map samples, and the FPN level boundaries of the LevelMapper formula;
+  * the backward restatement is checked to be the exact adjoint of the forward (ROIAlign is linear in the map).
 
 All arithmetic is float32 in the reference's operation order (numpy does not fuse multiply-adds),
 so the HIP kernel, which uses explicitly rounded mul/add, is compared bit for bit.
@@ -94,6 +95,41 @@ def roi_align(feat, rois, spatial_scale, pooled=8, sampling_ratio=2):
                         acc = acc + val          # :115
                 out[r, :, ph, pw] = acc / count  # :118
     return out
+
+
+def roi_align_backward(grad_out, rois, spatial_scale, feat_shape, pooled=8, sampling_ratio=2):
+    """RoIAlignBackwardFeature (ROIAlign_cuda.cu:178-262): every output gradient goes to the 4 taps of each of
+    its samples as top_diff * w / count (:236-243).  The reference accumulates with float32 atomics in arbitrary
+    order; here the products are float32 as there and the accumulation is float64 (the order-free value)."""
+    grad_out = np.asarray(grad_out, dtype=F)
+    rois = np.asarray(rois, dtype=F)
+    B, C, H, W = feat_shape
+    grad = np.zeros((B, C, H, W), dtype=np.float64)
+    scale = F(spatial_scale)
+    for r in range(rois.shape[0]):
+        b = int(rois[r, 0])
+        x1, y1, x2, y2 = (F(rois[r, 1] * scale), F(rois[r, 2] * scale), F(rois[r, 3] * scale), F(rois[r, 4] * scale))
+        roi_w = max(F(x2 - x1), F(1.0))
+        roi_h = max(F(y2 - y1), F(1.0))
+        bin_h, bin_w = F(roi_h / F(pooled)), F(roi_w / F(pooled))
+        gh = gw = sampling_ratio
+        count = F(gh * gw)
+        vy, ylo, yhi, ly, hy = _axis_samples(y1, bin_h, pooled, gh, H)
+        vx, xlo, xhi, lx, hx = _axis_samples(x1, bin_w, pooled, gw, W)
+        for ph in range(pooled):
+            for pw in range(pooled):
+                g = grad_out[r, :, ph, pw]
+                for iy in range(gh):
+                    ky = ph * gh + iy
+                    for ix in range(gw):
+                        kx = pw * gw + ix
+                        if not (vy[ky] and vx[kx]):
+                            continue
+                        w = (F(hy[ky] * hx[kx]), F(hy[ky] * lx[kx]), F(ly[ky] * hx[kx]), F(ly[ky] * lx[kx]))
+                        taps = ((ylo[ky], xlo[kx]), (ylo[ky], xhi[kx]), (yhi[ky], xlo[kx]), (yhi[ky], xhi[kx]))
+                        for wk, (yy, xx) in zip(w, taps):
+                            grad[b, :, yy, xx] += (g * wk / count).astype(np.float64)
+    return grad
 
 
 def box_area(boxes):

@@ -265,3 +265,52 @@ def test_device_eval_chain_feature_maps_to_recall():
     for k in (20, 50, 100):
         assert abs(got["recall"][k] - want["recall"][k]) <= 1.0 / 12 + 1e-9
         assert abs(got["mean_recall"][k] - want["mean_recall"][k]) <= 0.05
+
+
+def test_oracle_backward_is_the_adjoint_of_the_forward():
+    """ROIAlign is linear in the feature map, so <roi_align(f), g> == <f, roi_align_backward(g)> for all f, g."""
+    rng = np.random.RandomState(2)
+    feat = rng.randn(2, 3, 12, 17).astype(F)
+    rois = np.array([[0, 10, 8, 120, 90], [1, -20, 30, 60, 200], [1, 100, 100, 100.5, 100.5], [0, 200, 150, 400, 300]], dtype=F)
+    gout = rng.randn(4, 3, 8, 8).astype(F)
+    out = ro.roi_align(feat, rois, 1.0 / 16)
+    gin = ro.roi_align_backward(gout, rois, 1.0 / 16, feat.shape)
+    lhs = float((out.astype(np.float64) * gout).sum())
+    rhs = float((feat.astype(np.float64) * gin).sum())
+    assert abs(lhs - rhs) <= 1e-4 * max(1.0, abs(lhs))
+
+
+@pytest.mark.gpu
+def test_hip_roi_pool_backward_matches_oracle_and_autograd():
+    """veto_roi_pool_backward through torch autograd: 4 FPN levels + depth, gradients of a random cotangent vs
+    the oracle scatter (atomic accumulation order differs: 1e-5), plus the adjoint identity on the device."""
+    from veto_amd import testing
+    from veto_amd.poolers import make_roi_box_feature_extractor
+    from veto_amd.structures import BoxList
+    dev = torch.device("cuda:0")
+    rng = np.random.RandomState(12)
+    W, H = 512, 320
+    feats = [rng.randn(2, 256, H >> (2 + l), W >> (2 + l)).astype(F) for l in range(4)]
+    depth = rng.randn(2, 256, H >> 4, W >> 4).astype(F)
+    boxes = [_random_boxes(rng, n, W, H) for n in (8, 11)]
+    ext = make_roi_box_feature_extractor(testing.make_config(1, 8), 256, for_relation=True)
+    props = [BoxList(torch.from_numpy(b), (W, H)).to(dev) for b in boxes]
+    tf = [torch.from_numpy(f).to(dev).requires_grad_(True) for f in feats]
+    td = torch.from_numpy(depth).to(dev).requires_grad_(True)
+    x2d, d2d, _, _ = ext(tf, props, depth_features=td)
+    g_rgb = rng.randn(*x2d.shape).astype(F)
+    g_dep = rng.randn(*d2d.shape).astype(F)
+    ((x2d * torch.from_numpy(g_rgb).to(dev)).sum() + (d2d * torch.from_numpy(g_dep).to(dev)).sum()).backward()
+    rois = ro.to_rois(boxes)
+    lv = ro.map_levels(np.concatenate(boxes))
+    scales = (0.25, 0.125, 0.0625, 0.03125)
+    for l in range(4):
+        idx = np.nonzero(lv == l)[0]
+        want = ro.roi_align_backward(g_rgb[idx], rois[idx], scales[l], feats[l].shape) if len(idx) else np.zeros(feats[l].shape)
+        got = tf[l].grad.cpu().numpy()
+        assert np.abs(got - want).max() <= 1e-5 * max(1.0, np.abs(want).max()), l
+    want_d = ro.roi_align_backward(g_dep, rois, 0.0625, depth.shape)
+    assert np.abs(td.grad.cpu().numpy() - want_d).max() <= 1e-5 * max(1.0, np.abs(want_d).max())
+    lhs = float((x2d.detach().double() * torch.from_numpy(g_rgb).to(dev).double()).sum())
+    rhs = float(sum((t.detach().double() * t.grad.double()).sum() for t in tf))
+    assert abs(lhs - rhs) <= 1e-4 * max(1.0, abs(lhs))

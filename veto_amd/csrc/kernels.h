@@ -147,8 +147,14 @@ struct RoiPoolArgs {
   float* out_rgb;                // [n_roi, channels, pooled, pooled]
   float* out_depth;              // [n_roi, depth_channels, pooled, pooled]
   int32_t* out_levels;           // optional [n_roi]
+  // backward only: gradients of the pooled outputs in, gradients of the maps out (accumulated atomically)
+  const float* gout_rgb;         // [n_roi, channels, pooled, pooled]
+  const float* gout_depth;       // [n_roi, depth_channels, pooled, pooled] or nullptr
+  float* lv_grad[4];             // per level, same shape as lv[l].feat, zero-initialised by the caller
+  float* depth_grad;
 };
 hipError_t launch_roi_pool(const RoiPoolArgs& a, hipStream_t s);
+hipError_t launch_roi_pool_backward(const RoiPoolArgs& a, hipStream_t s);
 
 // ---- relation evaluators (sgg_eval.hip) ---------------------------------------------------------------
 struct SggEvalArgs {

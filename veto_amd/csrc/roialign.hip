@@ -139,6 +139,82 @@ __global__ __launch_bounds__(256) void roi_pool_kernel(RoiPoolArgs a) {
   }
 }
 
+// Backward (ROIAlign_cuda.cu:178-262): every output gradient is spread over the 4 taps of each of its G x G
+// samples as top_diff * w / count, accumulated into the map gradient with atomic adds (several ROIs and bins
+// touch the same pixel).  Same mapping and the same LDS sample table as the forward kernel.
+template <int G>
+__global__ __launch_bounds__(256) void roi_pool_backward_kernel(RoiPoolArgs a) {
+  __shared__ AxisTable ty, tx;
+  __shared__ int s_level;
+  const int r = blockIdx.x, tid = threadIdx.x;
+  const bool depth = blockIdx.z == 1;
+  const float* roi = a.rois + (size_t)r * 5;
+  const int C = depth ? a.depth_channels : a.channels;
+  const int c0 = blockIdx.y * kSlab;
+  if (c0 >= C) return;
+  if (tid == 0) {
+    int lvl = 0;
+    if (a.n_levels > 1) {
+      const float area = ((roi[3] - roi[1]) + 1.f) * ((roi[4] - roi[2]) + 1.f);
+      const float s = sqrtf(area);
+      float t = floorf(4.f + log2f(s / 224.f + 1e-6f));
+      t = fminf(fmaxf(t, (float)a.k_min), (float)a.k_max);
+      lvl = (int)t - a.k_min;
+    }
+    s_level = lvl;
+  }
+  __syncthreads();
+  const RoiLevel L = depth ? a.depth : a.lv[s_level];
+  float* grad_map = depth ? a.depth_grad : a.lv_grad[s_level];
+  const int P = a.pooled, n_axis = P * G;
+  if (tid < 2 * n_axis) {
+    const bool is_y = tid < n_axis;
+    const int k = is_y ? tid : tid - n_axis;
+    const float lo_c = (is_y ? roi[2] : roi[1]) * L.scale;
+    const float hi_c = (is_y ? roi[4] : roi[3]) * L.scale;
+    const float len = fmaxf(hi_c - lo_c, 1.0f);
+    const float bin = len / (float)P;
+    axis_entry(is_y ? ty : tx, k, lo_c, bin, k / G, k % G, G, is_y ? L.H : L.W);
+  }
+  __syncthreads();
+  const int b = (int)roi[0];
+  const int bin_id = tid & 63, wv = tid >> 6;
+  const int ph = bin_id / P, pw = bin_id % P;
+  if (bin_id >= P * P) return;
+  int off[G * G][4];
+  float wgt[G * G][4];
+  bool ok[G * G];
+#pragma unroll
+  for (int iy = 0; iy < G; ++iy)
+#pragma unroll
+    for (int ix = 0; ix < G; ++ix) {
+      const int ky = ph * G + iy, kx = pw * G + ix, q = iy * G + ix;
+      ok[q] = ty.valid[ky] && tx.valid[kx];
+      const float hy = ty.h[ky], ly = ty.l[ky], hx = tx.h[kx], lx = tx.l[kx];
+      off[q][0] = ty.lo[ky] * L.W + tx.lo[kx];
+      off[q][1] = ty.lo[ky] * L.W + tx.hi[kx];
+      off[q][2] = ty.hi[ky] * L.W + tx.lo[kx];
+      off[q][3] = ty.hi[ky] * L.W + tx.hi[kx];
+      wgt[q][0] = hy * hx;
+      wgt[q][1] = hy * lx;
+      wgt[q][2] = ly * hx;
+      wgt[q][3] = ly * lx;
+    }
+  const float count = (float)(G * G);
+  const size_t plane_sz = (size_t)L.H * L.W;
+  const float* gout = (depth ? a.gout_depth : a.gout_rgb) + (size_t)r * C * P * P;
+  for (int c = c0 + wv; c < c0 + kSlab && c < C; c += 4) {
+    float* plane = grad_map + ((size_t)b * C + c) * plane_sz;
+    const float g = gout[(size_t)c * P * P + bin_id];
+#pragma unroll
+    for (int q = 0; q < G * G; ++q)
+      if (ok[q]) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) atomicAdd(plane + off[q][t], g * wgt[q][t] / count);   // :240-243
+      }
+  }
+}
+
 }  // namespace
 
 hipError_t launch_roi_pool(const RoiPoolArgs& a, hipStream_t s) {
@@ -150,6 +226,21 @@ hipError_t launch_roi_pool(const RoiPoolArgs& a, hipStream_t s) {
     case 2: VETO_LAUNCH(roi_pool_kernel<2>, grid, dim3(256), 0, s, a); break;
     case 3: VETO_LAUNCH(roi_pool_kernel<3>, grid, dim3(256), 0, s, a); break;
     case 4: VETO_LAUNCH(roi_pool_kernel<4>, grid, dim3(256), 0, s, a); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_roi_pool_backward(const RoiPoolArgs& a, hipStream_t s) {
+  if (a.pooled < 1 || a.pooled > 8 || a.sampling_ratio < 1 || a.sampling_ratio > 4) return hipErrorInvalidValue;
+  const bool with_depth = a.depth.feat && a.gout_depth && a.depth_grad;
+  const int cmax = with_depth && a.depth_channels > a.channels ? a.depth_channels : a.channels;
+  dim3 grid(a.n_roi, (cmax + kSlab - 1) / kSlab, with_depth ? 2 : 1);
+  switch (a.sampling_ratio) {
+    case 1: VETO_LAUNCH(roi_pool_backward_kernel<1>, grid, dim3(256), 0, s, a); break;
+    case 2: VETO_LAUNCH(roi_pool_backward_kernel<2>, grid, dim3(256), 0, s, a); break;
+    case 3: VETO_LAUNCH(roi_pool_backward_kernel<3>, grid, dim3(256), 0, s, a); break;
+    case 4: VETO_LAUNCH(roi_pool_backward_kernel<4>, grid, dim3(256), 0, s, a); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();

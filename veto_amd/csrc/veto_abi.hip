@@ -626,7 +626,8 @@ int veto_postprocess_vote(void* stream, const veto_post_vote_args_t* a, void* wo
   return VETO_OK;
 }
 
-int veto_roi_pool(void* stream, const veto_roi_pool_args_t* a) {
+// shared argument check / conversion of veto_roi_pool and veto_roi_pool_backward
+static int roi_pool_args(const veto_roi_pool_args_t* a, bool forward, RoiPoolArgs* out) {
   if (!a) return fail(VETO_ERR_INVALID, "null argument");
   if (a->struct_size != (int32_t)sizeof(veto_roi_pool_args_t)) return fail(VETO_ERR_INVALID, "veto_roi_pool_args_t size mismatch");
   if (a->n_levels < 1 || a->n_levels > 4) return fail(VETO_ERR_INVALID, "n_levels must be 1..4, got %d", a->n_levels);
@@ -634,12 +635,13 @@ int veto_roi_pool(void* stream, const veto_roi_pool_args_t* a) {
   if (a->pooled < 1 || a->pooled > 8) return fail(VETO_ERR_INVALID, "pooled must be 1..8, got %d", a->pooled);
   if (a->sampling_ratio < 1 || a->sampling_ratio > 4)
     return fail(VETO_ERR_INVALID, "sampling_ratio must be 1..4 (adaptive sampling is not built), got %d", a->sampling_ratio);
-  if (!a->rois || !a->out_rgb) return fail(VETO_ERR_INVALID, "missing pointer");
-  if (a->depth_feat && (!a->out_depth || a->depth_channels <= 0 || a->depth_h <= 0 || a->depth_w <= 0))
+  if (!a->rois || (forward && !a->out_rgb)) return fail(VETO_ERR_INVALID, "missing pointer");
+  const bool has_depth = forward ? a->depth_feat != nullptr : a->depth_h > 0;
+  if (has_depth && ((forward && !a->out_depth) || a->depth_channels <= 0 || a->depth_h <= 0 || a->depth_w <= 0))
     return fail(VETO_ERR_INVALID, "depth map given without out_depth / sizes");
   RoiPoolArgs p{};
   for (int l = 0; l < a->n_levels; ++l) {
-    if (!a->level_feat[l] || a->level_h[l] <= 0 || a->level_w[l] <= 0 || !(a->level_scale[l] > 0.f))
+    if ((forward && !a->level_feat[l]) || a->level_h[l] <= 0 || a->level_w[l] <= 0 || !(a->level_scale[l] > 0.f))
       return fail(VETO_ERR_INVALID, "bad pyramid level %d", l);
     p.lv[l] = RoiLevel{a->level_feat[l], a->level_h[l], a->level_w[l], a->level_scale[l]};
   }
@@ -647,15 +649,42 @@ int veto_roi_pool(void* stream, const veto_roi_pool_args_t* a) {
   // poolers.py:86-88: the level range follows from the first and last scale
   p.k_min = (int)lroundf(-log2f(a->level_scale[0]));
   p.k_max = (int)lroundf(-log2f(a->level_scale[a->n_levels - 1]));
-  if (a->depth_feat) {
+  if (has_depth) {
     const int dl = a->n_levels > 1 ? 2 : 0;  // poolers.py:146-149
     if (dl >= a->n_levels) return fail(VETO_ERR_INVALID, "the depth pooler is level 2; need at least 3 levels or exactly 1");
     p.depth = RoiLevel{a->depth_feat, a->depth_h, a->depth_w, a->level_scale[dl]};
   }
-  p.n_roi = a->n_roi; p.channels = a->channels; p.depth_channels = a->depth_feat ? a->depth_channels : 0;
+  p.n_roi = a->n_roi; p.channels = a->channels; p.depth_channels = has_depth ? a->depth_channels : 0;
   p.pooled = a->pooled; p.sampling_ratio = a->sampling_ratio;
   p.rois = a->rois; p.out_rgb = a->out_rgb; p.out_depth = a->out_depth; p.out_levels = a->out_levels;
+  *out = p;
+  return VETO_OK;
+}
+
+int veto_roi_pool(void* stream, const veto_roi_pool_args_t* a) {
+  RoiPoolArgs p{};
+  const int rc = roi_pool_args(a, true, &p);
+  if (rc != VETO_OK) return rc;
   HIP_TRY(launch_roi_pool(p, (hipStream_t)stream));
+  return VETO_OK;
+}
+
+int veto_roi_pool_backward(void* stream, const veto_roi_pool_args_t* a, const float* grad_rgb, const float* grad_depth,
+                           float* const* level_grad, float* depth_grad) {
+  RoiPoolArgs p{};
+  const int rc = roi_pool_args(a, false, &p);
+  if (rc != VETO_OK) return rc;
+  if (!grad_rgb || !level_grad) return fail(VETO_ERR_INVALID, "missing gradient pointer");
+  for (int l = 0; l < p.n_levels; ++l) {
+    if (!level_grad[l]) return fail(VETO_ERR_INVALID, "level_grad[%d] is null", l);
+    p.lv_grad[l] = level_grad[l];
+  }
+  if ((grad_depth != nullptr) != (depth_grad != nullptr)) return fail(VETO_ERR_INVALID, "grad_depth and depth_grad go together");
+  if (grad_depth && p.depth.H <= 0) return fail(VETO_ERR_INVALID, "depth gradient without depth sizes in args");
+  if (grad_depth) p.depth.feat = grad_depth;   // only its non-null-ness and the sizes are used
+  else p.depth.feat = nullptr;
+  p.gout_rgb = grad_rgb; p.gout_depth = grad_depth; p.depth_grad = depth_grad;
+  HIP_TRY(launch_roi_pool_backward(p, (hipStream_t)stream));
   return VETO_OK;
 }
 

@@ -20,7 +20,7 @@ EXPORTS = [
     "veto_enumerate_pairs", "veto_profile_enable", "veto_profile_collect", "veto_profile_entry",
     "veto_profile_reset", "veto_debug_gemm", "veto_debug_gemm_workspace_bytes",
     "veto_postprocess", "veto_postprocess_workspace_bytes", "veto_postprocess_meet", "veto_postprocess_vote",
-    "veto_roi_pool", "veto_sgg_eval", "veto_sgg_eval_workspace_bytes",
+    "veto_roi_pool", "veto_roi_pool_backward", "veto_sgg_eval", "veto_sgg_eval_workspace_bytes",
 ]
 
 VETO_PRECISE, VETO_FAST = 0, 1
@@ -137,6 +137,7 @@ def load_library():
     lib.veto_postprocess_meet.argtypes = [c_void_p, POINTER(VetoPostMeetArgs), c_void_p, c_size_t]
     lib.veto_postprocess_vote.argtypes = [c_void_p, POINTER(VetoPostVoteArgs), c_void_p, c_size_t]
     lib.veto_roi_pool.argtypes = [c_void_p, POINTER(VetoRoiPoolArgs)]
+    lib.veto_roi_pool_backward.argtypes = [c_void_p, POINTER(VetoRoiPoolArgs), c_void_p, c_void_p, POINTER(c_void_p), c_void_p]
     lib.veto_sgg_eval_workspace_bytes.argtypes = [c_int32, c_int32, c_int32, c_int32]
     lib.veto_sgg_eval_workspace_bytes.restype = c_size_t
     lib.veto_sgg_eval.argtypes = [c_void_p, POINTER(VetoSggEvalArgs), c_int32, c_int32, c_void_p, c_size_t]
