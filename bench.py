@@ -134,6 +134,11 @@ def main():
         dom = max(gemms, key=lambda k: gemms[k]["ms_per_step"])
         achieved = gemms[dom]["tflops"]
         f_ref = flops_per_pair(args.layers, args.heads)
+        passes = 3 if args.precision == "precise" else 1
+        hbm_gbps = {k: round(prof[k]["bytes_per_launch"] / (kern[k]["avg_ms"] * 1e-3) / 1e9, 1)
+                    for k in ("attention", "attention_cls", "layernorm") if k in prof and prof[k]["bytes_per_launch"]}
+        gather_bytes = float(n_pairs) * 19 * 576 * 8
+        gather_gbps = gather_bytes / (kern["assemble_tokens"]["avg_ms"] * 1e-3) / 1e9
         traffic = None
         try:  # PMC-derived HBM bytes per launch of the dominant kernel at THIS workload (profiles/r01_traffic.json)
             tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
@@ -156,6 +161,16 @@ def main():
                          "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic,
                          "note": "achieved = algorithmic 2*M*N*K of one launch / its mean hipEvent duration; the "
                                  "precise mode issues 3 bf16 MFMA passes per algorithmic FLOP"},
+            # north_star: "HBM GB/s on the gather and MFMA utilisation on the attention GEMMs"
+            "gather": {"bound": "hbm", "kernel": "assemble_tokens", "achieved": gather_gbps, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                       "frac": gather_gbps / PEAK_HBM_GBS,
+                       "note": "pair gather + token assembly: algorithmic bytes = the [pairs, 19, 576] fp32 stream plus its LayerNorm'ed "
+                               "split-bf16 copy (8 B per element written); the per-object tables it reads stay in L2"},
+            "hbm_kernels_gbps": hbm_gbps,
+            "mfma_issued": {"kernel": dom, "passes_per_flop": passes, "issued_tflops": achieved * passes,
+                            "frac_of_bf16_peak": achieved * passes / PEAK_BF16_TFLOPS,
+                            "note": "matrix-pipe rate actually issued by the dominant GEMM; SQ_VALU_MFMA_BUSY_CYCLES from the PMC pass "
+                                    "is in profiles/ (busy fraction of kernel cycles)"},
             "whole_path": {"ref_flops_per_pair": f_ref, "tflops_ref_equivalent": value * f_ref / 1e12,
                            "frac_of_bf16_peak": value * f_ref / 1e12 / PEAK_BF16_TFLOPS / world},
             "kernels_ms_per_step": {k: round(v["ms_per_step"], 4) for k, v in sorted(kern.items(), key=lambda kv: -kv[1]["ms_per_step"])},
