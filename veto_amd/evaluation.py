@@ -17,6 +17,7 @@ import numpy as np
 import torch
 
 from . import native
+from .predictor import cached_offsets
 
 KS = (20, 50, 100)
 NO_MATCH = 0x3fffffff
@@ -72,8 +73,8 @@ class SGGEvaluator:
         n_g = [rows(im["gt_rels"], 3) for im in images]
         n_o = [int(len(im["gt_classes"])) for im in images]
         n_p = [rows(im["pred_rel_inds"], 2) for im in images]
-        off = lambda xs: torch.tensor([0] + list(np.cumsum(xs)), dtype=i32, device=dev)
-        gt_off, obj_off, pair_off = off(n_g), off(n_o), off(n_p)
+        obj_off, pair_off = cached_offsets(n_o, n_p, dev)
+        gt_off = cached_offsets(n_g, n_g, dev)[0]
         n_img, sum_g, sum_p, C = len(images), sum(n_g), sum(n_p), self.num_rel
         out = {k: torch.empty(max(sum_g, 1), dtype=i32, device=dev) for k in ("gc_rank", "ng_rank", "acc_rank", "zeroshot_flag")}
         ng_rows = torch.zeros((n_img, 100), dtype=i32, device=dev)

@@ -18,6 +18,7 @@ import torch
 from torch import nn
 
 from . import native
+from .predictor import cached_offsets
 
 
 class PostProcessor(nn.Module):
@@ -55,9 +56,7 @@ class PostProcessor(nn.Module):
         if rel.shape[0] != n_pair or obj.shape[0] != n_obj:
             raise ValueError("logit rows (%d, %d) do not match pairs/objects (%d, %d)" % (rel.shape[0], obj.shape[0], n_pair, n_obj))
         pairs = torch.cat([p.reshape(-1, 2) for p in rel_pair_idxs], 0).to(device=device, dtype=torch.int64).contiguous()
-        cs = lambda xs: [0] + [sum(xs[:i + 1]) for i in range(len(xs))]
-        obj_off = torch.tensor(cs(n_objs), dtype=torch.int32, device=device)
-        pair_off = torch.tensor(cs(n_pairs), dtype=torch.int32, device=device)
+        obj_off, pair_off = cached_offsets(n_objs, n_pairs, device)   # no host-blocking H2D copy in the steady state
         out = {
             "obj_scores": torch.empty(n_obj, **f32), "obj_pred": torch.empty(n_obj, dtype=torch.int64, device=device),
             "prob": torch.empty((n_pair, rel.shape[1]), **f32),

@@ -165,6 +165,22 @@ def _build_trunk(m, config, num_obj_cls, with_embed2):
 _TRUNK_KEYS = None
 
 
+_OFFSET_CACHE = {}
+
+
+def cached_offsets(n_objs, n_pairs, device):
+    """Per-image exclusive prefix sums (objects, pairs) as int32 device tensors.  torch.tensor(list, device=...) is a
+    synchronous pageable H2D copy that stalls the host behind all queued GPU work, so batch shapes seen before (the
+    common case in an eval loop) re-use their tensors.  Shared by the predictor, the PostProcessor and the evaluator."""
+    key = (tuple(n_objs), tuple(n_pairs), str(device))
+    hit = _OFFSET_CACHE.get(key)
+    if hit is None:
+        if len(_OFFSET_CACHE) >= 256:
+            _OFFSET_CACHE.clear()
+        hit = _OFFSET_CACHE[key] = _offset_tensors(tuple(n_objs), tuple(n_pairs), device)
+    return hit
+
+
 class _NativeForward:
     """Shared device-side plumbing: engine lifetime, weight upload, workspace, one C-ABI forward."""
 
@@ -223,17 +239,7 @@ class _NativeForward:
         return self._engine
 
     def _offsets(self, n_objs, n_pairs, device):
-        """Per-image prefix sums as device tensors.  torch.tensor(list, device=...) is a synchronous
-        pageable H2D copy that stalls the host behind all queued GPU work, so batch shapes seen before
-        (the common case in an eval loop) re-use their tensors."""
-        cache = self.__dict__.setdefault("_offset_cache", {})
-        key = (n_objs, n_pairs, str(device))
-        hit = cache.get(key)
-        if hit is None:
-            if len(cache) >= 256:
-                cache.clear()
-            hit = cache[key] = _offset_tensors(n_objs, n_pairs, device)
-        return hit
+        return cached_offsets(n_objs, n_pairs, device)
 
     def _run_native(self, proposals, rel_pair_idxs, roi_features, roi_depth_features, labels, logits,
                     debug=False):

@@ -60,12 +60,15 @@ class VETORelationHead(nn.Module):
         if self.training:
             raise NotImplementedError("veto_amd: the training branch (pair sampling, losses, backward) is not built")
         device = roi_features.device
-        if self.mode == "predcls":
-            for p in proposals:
-                labels = p.get_field("labels")
-                p.add_field("predict_logits", to_onehot(labels, self.num_obj_cls))
-                p.add_field("pred_scores", torch.ones(len(labels), device=device))
-                p.add_field("pred_labels", labels.to(device))
+        if self.mode == "predcls":   # :104-111, one batched one-hot instead of one per image
+            n_objs = [len(p) for p in proposals]
+            labels = torch.cat([p.get_field("labels") for p in proposals]).to(device)
+            onehot = to_onehot(labels, self.num_obj_cls).split(n_objs)
+            ones = torch.ones(labels.shape[0], device=device).split(n_objs)
+            for p, oh, sc, lab in zip(proposals, onehot, ones, labels.split(n_objs)):
+                p.add_field("predict_logits", oh)
+                p.add_field("pred_scores", sc)
+                p.add_field("pred_labels", lab)
         rel_pair_idxs = prepare_test_pairs(device, proposals, self.max_proposal_pairs)
         obj_dists, relation_logits, add_losses, incre_idx_list, _, _ = self.predictor(
             proposals, rel_pair_idxs, None, logger, roi_features=roi_features, roi_depth_features=roi_depth_features)
