@@ -283,6 +283,12 @@ int veto_debug_gemm(void* stream, const float* a, const float* w, const float* b
                     int32_t n, int32_t k, int32_t precision, void* workspace, size_t workspace_bytes);
 size_t veto_debug_gemm_workspace_bytes(int32_t m, int32_t n, int32_t k);
 
+/* ---- test hook: dw[N,K] = dy[M,N]^T . x[M,K], the weight-gradient GEMM (reduction over the M rows) through the
+ * production split-bf16 kernel in its split-K / atomic-add form.  k must be a multiple of 192; k_splits 0 = auto. */
+int veto_debug_wgrad(void* stream, const float* dy, const float* x, float* dw, int32_t m, int32_t n, int32_t k,
+                     int32_t k_splits, void* workspace, size_t workspace_bytes);
+size_t veto_debug_wgrad_workspace_bytes(int32_t m, int32_t n, int32_t k, int32_t k_splits);
+
 #ifdef __cplusplus
 }
 #endif

@@ -496,3 +496,23 @@ def test_large_image_with_pair_cap_against_oracle():
     ref, _, _ = vo.forward(sd, vo.OracleConfig(layers=2, heads=8, mode="sgcls"), batch, rel_pair_idxs=[pairs[0].cpu().numpy()])
     err = (torch.cat(list(out[1])).cpu() - ref).abs().max().item()
     assert err <= LOGIT_TOL, err
+
+
+@pytest.mark.parametrize("m,n,k,ks", [(1000, 100, 192, 1), (5000, 576, 576, 0), (40000, 1728, 576, 0), (9999, 1152, 384, 7)])
+def test_wgrad_gemm_against_fp64(m, n, k, ks):
+    """dw = dy^T . x (reduction over the rows) through the split-K / atomic form of the production GEMM and the
+    transposing split kernel: the weight-gradient shape of every Linear layer."""
+    from veto_amd import native
+    dev = _dev()
+    lib = native.load_library()
+    g = torch.Generator(device="cpu").manual_seed(m + n + k)
+    dy = torch.randn(m, n, generator=g).to(dev)
+    x = torch.randn(m, k, generator=g).to(dev)
+    ref = dy.double().t() @ x.double()
+    ws = torch.empty(lib.veto_debug_wgrad_workspace_bytes(m, n, k, ks), dtype=torch.uint8, device=dev)
+    dw = torch.full((n, k), float("nan"), device=dev)
+    native.check(lib.veto_debug_wgrad(None, dy.data_ptr(), x.data_ptr(), dw.data_ptr(), m, n, k, ks, ws.data_ptr(), ws.numel()))
+    torch.cuda.synchronize()
+    scale = (dy.abs().double().t() @ x.abs().double()).clamp_min(1e-6)
+    rel = ((dw.double() - ref).abs() / scale).max().item()
+    assert rel < 2e-5, (m, n, k, ks, rel)

@@ -84,9 +84,11 @@ __global__ __launch_bounds__(64 * (NCONS + NLOAD), 3) void gemm_split_ps_kernel(
   const int lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int b = blockIdx.x;
-  const int ntiles = g.tiles_m * g.tiles_n;
+  const int ksp = EPI == EPI_ATOMIC && g.k_splits > 1 ? g.k_splits : 1;
+  const int out_tiles = g.tiles_m * g.tiles_n;
+  const int ntiles = out_tiles * ksp;        // split-K: (k range, output tile), output tile fastest
   const int K = g.K;
-  const int nk = K / BK;
+  const int nk = K / BK / ksp;               // k-steps per tile
   // tile of round `it` for this workgroup; gridDim.x is a multiple of 8 (launcher)
   const int per_xcd = gridDim.x >> 3;
   auto tile_of = [&](int it) { return (it * 8 + (b & 7)) * per_xcd + (b >> 3); };
@@ -112,21 +114,25 @@ __global__ __launch_bounds__(64 * (NCONS + NLOAD), 3) void gemm_split_ps_kernel(
       return (const char*)(base + (size_t)row * ld) + slot * 16;
     };
     auto setupA = [&](int tile) {
+      const int k0 = (tile / out_tiles) * nk;   // first k-step of this tile's range
+      tile %= out_tiles;
       const int tile_m = tile / g.tiles_n;
 #pragma unroll
       for (int i = 0; i < CPA; ++i) {
         const int c = lw + NLOAD * i;
         int row = tile_m * BM + c * 8 + rr;
         if (g.lda != 2 * K && row >= g.M) row = g.M - 1;  // strided (unpadded) A rows
-        srcA[i] = src_of(g.a, g.lda, row, c);
+        srcA[i] = src_of(g.a, g.lda, row, c) + (size_t)k0 * 128;
       }
     };
     auto setupW = [&](int tile) {
+      const int k0 = (tile / out_tiles) * nk;
+      tile %= out_tiles;
       const int tile_n = tile % g.tiles_n;
 #pragma unroll
       for (int i = 0; i < CPWL; ++i) {
         const int c = lw + NLOAD * i;
-        srcW[i] = src_of(g.w, 2 * K, tile_n * BN + c * 8 + rr, c);
+        srcW[i] = src_of(g.w, 2 * K, tile_n * BN + c * 8 + rr, c) + (size_t)k0 * 128;
       }
     };
     // cursors of the next A stage / W stage to issue (the stream of stages crosses tile boundaries)
@@ -156,7 +162,7 @@ __global__ __launch_bounds__(64 * (NCONS + NLOAD), 3) void gemm_split_ps_kernel(
     // for a store-only epilogue).  During the last 6 k-steps of a tile the loader waves touch one
     // 128-byte line per lane of that tile (4-byte LDS-DMA into a dump area) so that it is L2 / MALL
     // resident when the consumers ask for it.  Pure prefetch: results do not depend on it.
-    auto prefetch_resid = [&](int tile, int j) {
+    auto prefetch_resid = [&](int tile, int j) {   // EPI_RESID only: never split-K
       const int tile_n = tile % g.tiles_n, tile_m = tile / g.tiles_n;
       int row = tile_m * BM + lw * 64 + lane;
       if (row >= g.M) row = g.M - 1;
@@ -215,7 +221,7 @@ __global__ __launch_bounds__(64 * (NCONS + NLOAD), 3) void gemm_split_ps_kernel(
   STAMP(t_begin);
   int s = 0, s3 = 0;  // stage counter and s % 3
   for (int it = 0; it < my_tiles; ++it) {
-    const int tile = tile_of(it);
+    const int tile = tile_of(it) % out_tiles;
     const int tile_n = tile % g.tiles_n, tile_m = tile / g.tiles_n;
     f32x4 acc[6][4];
 #pragma unroll
@@ -337,6 +343,10 @@ __global__ __launch_bounds__(64 * (NCONS + NLOAD), 3) void gemm_split_ps_kernel(
             __bf16* dst = g.c_split + (size_t)row * g.ldc + split_index(col);
             *(bf16x4*)dst = hi;
             *(bf16x4*)(dst + 32) = lo;
+          } else if (EPI == EPI_ATOMIC) {
+            float* dstc = g.c + (size_t)row * g.ldc + col;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) unsafeAtomicAdd(dstc + e, v[e]);
           } else {
             *(f32x4*)(g.c + (size_t)row * g.ldc + col) = v;
           }
@@ -360,6 +370,7 @@ hipError_t launch_ps_terms(GemmArgs g, int epi, int nblocks, hipStream_t s) {
     case EPI_F32: VETO_LAUNCH((gemm_split_ps_kernel<NTERMS, EPI_F32>), grid, block, 0, s, g); break;
     case EPI_RESID: VETO_LAUNCH((gemm_split_ps_kernel<NTERMS, EPI_RESID>), grid, block, 0, s, g); break;
     case EPI_GELU_SPLIT: VETO_LAUNCH((gemm_split_ps_kernel<NTERMS, EPI_GELU_SPLIT>), grid, block, 0, s, g); break;
+    case EPI_ATOMIC: VETO_LAUNCH((gemm_split_ps_kernel<NTERMS, EPI_ATOMIC>), grid, block, 0, s, g); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
@@ -379,7 +390,9 @@ hipError_t launch_gemm_split_ps(GemmArgs g, int epi, int precision, hipStream_t 
     num_cu = prop.multiProcessorCount / 8 * 8;
     if (num_cu < 8) num_cu = 8;
   }
-  const int ntiles = g.tiles_m * g.tiles_n;
+  const int ksp = epi == EPI_ATOMIC && g.k_splits > 1 ? g.k_splits : 1;
+  if ((g.K / BK) % ksp != 0) return hipErrorInvalidValue;
+  const int ntiles = g.tiles_m * g.tiles_n * ksp;
   int nblocks = num_cu;  // one persistent workgroup per CU (LDS: 112 KiB each)
   if (ntiles < nblocks) nblocks = (ntiles + 7) / 8 * 8;
   hipError_t rc = precision == 0 ? launch_ps_terms<3>(g, epi, nblocks, s) : launch_ps_terms<1>(g, epi, nblocks, s);

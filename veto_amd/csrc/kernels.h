@@ -4,7 +4,7 @@
 
 namespace veto {
 
-enum Epi { EPI_F32 = 0, EPI_RESID = 1, EPI_GELU_SPLIT = 2 };
+enum Epi { EPI_F32 = 0, EPI_RESID = 1, EPI_GELU_SPLIT = 2, EPI_ATOMIC = 3 };
 
 // C[M,N] = A[M,K] . W[N,K]^T with A and W in the split-row format (common.h): rows of 2K bf16.
 struct GemmArgs {
@@ -18,6 +18,8 @@ struct GemmArgs {
   long lda;            // A row stride in bf16 elements (0 = 2K)
   long ldr;
   long ldc;
+  int k_splits;          // EPI_ATOMIC: the reduction K is cut into this many equal ranges (K/32 % k_splits == 0), each a
+                         // tile of its own that ADDS into c with fp32 atomics (c zero-initialised); 0/1 = one range
   int tiles_m, tiles_n;  // filled by the launcher
   int stagger;           // persistent kernel: start-phase stagger in units of s_sleep(127) (speed only)
 };
@@ -30,6 +32,9 @@ hipError_t launch_gemm_split_ps(GemmArgs g, int epi, int precision, hipStream_t 
 // ---- weight preparation (once per weight upload) ---------------------------------------------
 // src [rows, K] fp32 -> dst [rows, 2K] split rows
 hipError_t launch_split_rows(const float* src, __bf16* dst, size_t rows, int K, hipStream_t s);
+// src [M, ld] fp32 (N columns used) -> dst [N, 2*Mp] split rows of the TRANSPOSE, Mp = M rounded up to 32*mult
+// (zero padded): the operand layout of a GEMM that reduces over M (weight gradients)
+hipError_t launch_transpose_split(const float* src, long ld, int M, int N, __bf16* dst, int Mp, hipStream_t s);
 // W_cat [1152, 2*2048] split rows + bias_cat [1152] from proj_d [512,2048], proj_v [64,2048]
 hipError_t launch_build_patch_weight(const float* wd, const float* bd, const float* wv, const float* bv,
                                      __bf16* dst, float* bias_cat, hipStream_t s);

@@ -37,6 +37,35 @@ __global__ void split_rows_kernel(const float* __restrict__ src, __bf16* __restr
   }
 }
 
+// fp32 [M, ld] -> split rows of the transpose [N, 2*Mp]: a 32 (m) x 64 (n) tile goes through LDS; every output
+// row n receives one whole 32-k block, [8 x 4 hi | 8 x 4 lo] bf16 = 128 contiguous bytes, as 16-byte pieces.
+__global__ __launch_bounds__(256) void transpose_split_kernel(const float* __restrict__ src, long ld, int M, int N,
+                                                              __bf16* __restrict__ dst, int Mp) {
+  __shared__ float t[32][65];
+  const int m0 = blockIdx.x * 32, n0 = blockIdx.y * 64, tid = threadIdx.x;
+  const int tx = tid & 63, ty = tid >> 6;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int m = m0 + ty * 8 + i, n = n0 + tx;
+    t[ty * 8 + i][tx] = (m < M && n < N) ? src[(size_t)m * ld + n] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const int id = tid + 256 * r, nl = id >> 3, piece = id & 7;
+    if (n0 + nl >= N) continue;
+    bf16x8 out;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      __bf16 h, l;
+      split_bf16(t[8 * (piece & 3) + e][nl], h, l);
+      out[e] = piece < 4 ? h : l;
+    }
+    __bf16* d = dst + (size_t)(n0 + nl) * (2 * (size_t)Mp) + (size_t)(m0 >> 5) * 64 + (piece < 4 ? 8 * piece : 32 + 8 * (piece - 4));
+    *(bf16x8*)d = out;
+  }
+}
+
 // proj(cat(subj, obj)) is linear, so it splits into a subject and an object partial product per
 // OBJECT (restructuring (a)).  Row j of the combined weight is one column of
 // the per-object table: [subj: depth 0..511 | rgb 512..575 | obj: depth 576..1087 | rgb 1088..1151];
@@ -333,6 +362,12 @@ hipError_t launch_split_rows(const float* src, __bf16* dst, size_t rows, int K, 
   const size_t n = rows * (size_t)K;
   const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
   VETO_LAUNCH(split_rows_kernel, dim3(blocks), dim3(256), 0, s, src, dst, n, K);
+  return hipGetLastError();
+}
+
+hipError_t launch_transpose_split(const float* src, long ld, int M, int N, __bf16* dst, int Mp, hipStream_t s) {
+  if (Mp % 32 != 0 || Mp < M) return hipErrorInvalidValue;
+  VETO_LAUNCH(transpose_split_kernel, dim3(Mp / 32, (N + 63) / 64), dim3(256), 0, s, src, ld, M, N, dst, Mp);
   return hipGetLastError();
 }
 

@@ -798,4 +798,47 @@ int veto_debug_gemm(void* stream, const float* a, const float* w, const float* b
   return VETO_OK;
 }
 
+// dw[N,K] = dy[M,N]^T . x[M,K]: the weight-gradient shape (reduction over the M rows).  Both operands are
+// transposed into split rows ([N, 2*Mp] and [K, 2*Mp]) and the persistent GEMM runs split-K with atomic adds.
+static int wgrad_splits(int n, int k, int m, int k_splits) {
+  if (k_splits > 0) return k_splits;
+  const int out_tiles = ((n + 255) / 256) * (k / 192);
+  int ks = 2 * 256 / out_tiles;                         // just under 2 full rounds of the 256 persistent workgroups
+  const int max_ks = (m + 32 * 64 - 1) / (32 * 64);     // at least 64 k-steps per tile
+  if (ks > max_ks) ks = max_ks;
+  return ks < 1 ? 1 : ks;
+}
+
+static size_t wgrad_mp(int m, int ks) { return ((size_t)m + 32 * (size_t)ks - 1) / (32 * (size_t)ks) * 32 * (size_t)ks; }
+
+size_t veto_debug_wgrad_workspace_bytes(int32_t m, int32_t n, int32_t k, int32_t k_splits) {
+  if (m <= 0 || n <= 0 || k <= 0) return 0;
+  const size_t mp = wgrad_mp(m, wgrad_splits(n, k, m, k_splits));
+  return align_up((size_t)gemm_rows_padded(n) * mp * 4, 256) + align_up((size_t)k * mp * 4, 256);
+}
+
+int veto_debug_wgrad(void* stream, const float* dy, const float* x, float* dw, int32_t m, int32_t n, int32_t k,
+                     int32_t k_splits, void* workspace, size_t workspace_bytes) {
+  if (!dy || !x || !dw || !workspace) return fail(VETO_ERR_INVALID, "null argument");
+  if (m <= 0 || n <= 0 || k <= 0 || k % 192 != 0) return fail(VETO_ERR_INVALID, "k must be a positive multiple of 192");
+  if (workspace_bytes < veto_debug_wgrad_workspace_bytes(m, n, k, k_splits)) return fail(VETO_ERR_WORKSPACE, "workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  const int ks = wgrad_splits(n, k, m, k_splits);
+  const size_t mp = wgrad_mp(m, ks);
+  char* base = (char*)workspace;
+  const size_t a_bytes = align_up((size_t)gemm_rows_padded(n) * mp * 4, 256);
+  __bf16* a_s = (__bf16*)base;
+  __bf16* w_s = (__bf16*)(base + a_bytes);
+  HIP_TRY(hipMemsetAsync(base, 0, a_bytes, s));   // rows n..padded stay zero
+  HIP_TRY(launch_transpose_split(dy, n, m, n, a_s, (int)mp, s));
+  HIP_TRY(launch_transpose_split(x, k, m, k, w_s, (int)mp, s));
+  HIP_TRY(hipMemsetAsync(dw, 0, (size_t)n * k * 4, s));
+  GemmArgs g{};
+  g.a = a_s; g.w = w_s; g.c = dw;
+  g.M = n; g.N = k; g.K = (int)mp; g.ldc = k; g.k_splits = ks;
+  hipError_t e = launch_gemm_split(g, EPI_ATOMIC, 0, s);
+  if (e != hipSuccess) return fail(e == hipErrorInvalidValue ? VETO_ERR_INVALID : VETO_ERR_HIP, "wgrad gemm launch failed: %s", hipGetErrorString(e));
+  return VETO_OK;
+}
+
 }  // extern "C"
