@@ -330,6 +330,72 @@ def run_postprocessor_vote(cfg, BoxList, name, n, dataset, voting):
     print("%-24s expert voting %s: %d of %d rows kept" % (name, voting, out["rel_pair_idxs"].shape[0], len(sizes) * P_))
 
 
+def run_train_losses(P, cfg, BoxList, name, meet, beta_loss=False, dataset="VG"):
+    """Training-mode forward of the reference predictor (dropout off, so it is deterministic) on a small batch with
+    random relation labels: stores the classifier logits it produced (forward hooks on the rel_out modules), the
+    labels, and the losses it returned.  MEET: also the expert sampling (`cur_chosen_matrix`), which the reference
+    draws from Python's `random` (seeded with 1, tools/relation_train_net.py:44-50), and its sample_rate_matrix."""
+    import random
+    n_obj, n_rel = configure(P, cfg, "predcls", 2, 8, "VETOPredictor_MEET" if meet else "VETOPredictor", dataset)
+    cfg.ENSEMBLE_LEARNING.EXPERT_GROUP = False
+    cfg.GLOBAL_SETTING.BETA_LOSS = False
+    torch.manual_seed(0)
+    num_objs = [7, 5, 9]
+    if meet:
+        model = P.VETOPredictor_MEET(cfg, 512)
+        groups = list(model.max_group_element_number_list)
+        sd = synth.meet_state_dict(0, groups, layers=2, num_obj_cls=n_obj)
+    else:
+        model = P.VETOPredictor(cfg, 512)
+        sd = synth.predictor_state_dict(0, layers=2, num_obj_cls=n_obj, num_rel_cls=n_rel)
+    load_sd(model, sd)
+    model.train()
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    batch = synth.synthetic_batch(7, len(num_objs), num_objs, num_obj_cls=n_obj)
+    props = make_proposals(BoxList, batch, "predcls")
+    pairs = test_pairs(num_objs)
+    P_tot = sum(len(p) for p in pairs)
+    u = synth.uniform01(9, "train.labels", P_tot)
+    labels = np.where(u < 0.55, 0, 1 + np.floor((u - 0.55) / 0.45 * (n_rel - 1))).astype(np.int64)   # ~55 % background
+    labels = np.minimum(labels, n_rel - 1)
+    rel_labels = torch.from_numpy(labels)
+    captured = {}
+    heads = list(model.model.rel_out) if meet else [model.rel_out]
+    hooks = [h.register_forward_hook(lambda mod, i, o, k=k: captured.__setitem__(k, o.detach().clone())) for k, h in enumerate(heads)]
+    if beta_loss:   # roi_relation_predictors.py:4057-4066 with the counts of pred_counts.pkl (the path there is absolute)
+        import pickle
+        with open(os.path.join(REF, "pred_counts.pkl"), "rb") as f:
+            counts = np.asarray(pickle.load(f), dtype=np.float64)
+        counts[::-1].sort()
+        w = (1.0 - 0.999) / (1 - (0.999 ** counts))
+        w *= float(n_rel) / np.sum(w)
+        model.criterion_loss_rel = torch.nn.CrossEntropyLoss(weight=torch.FloatTensor(w))
+    random.seed(1)
+    res = model(props, pairs, list(rel_labels.split([len(p) for p in pairs])), None,
+                roi_features=torch.from_numpy(batch["roi_features"]), roi_depth_features=torch.from_numpy(batch["roi_depth_features"]))
+    for h in hooks:
+        h.remove()
+    out = {"labels": labels, "meet": int(meet), "dataset": dataset, "beta_loss": int(beta_loss), "num_objs": np.array(num_objs)}
+    for k, v in captured.items():
+        out["logits_%d" % k] = v.numpy()
+    for k, v in res[2].items():
+        out["loss_" + k] = np.array(float(v.item()), dtype=np.float64)
+    if beta_loss:
+        out["class_weights"] = w.astype(np.float32)
+    if meet:
+        chosen = res[4][0]          # expert_dist[0] is cur_chosen_matrix itself (appended by reference)
+        for k, rows in enumerate(chosen):
+            out["chosen_%d" % k] = np.array(rows, dtype=np.int64)
+        out["sample_rate_matrix"] = np.array(model.sample_rate_matrix, dtype=np.float64)
+        out["incre_idx_list"] = np.array(model.incre_idx_list)
+        out["group_sizes"] = np.array(groups)
+        out["random_after"] = np.array([random.random()], dtype=np.float64)   # the next draw: pins how much was consumed
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print("%-24s losses %s" % (name, {k: round(float(v.item()), 5) for k, v in res[2].items()}))
+
+
 SGG_EVAL_CASES = {"sggeval_predcls": (31, [6, 9, 12, 3, 15, 20, 2, 8], "predcls"),
                   "sggeval_sgcls": (32, [6, 9, 12, 3, 15, 20, 2, 8], "sgcls")}
 
@@ -384,6 +450,12 @@ def run_sgg_eval(cfg, BoxList, name):
 def main():
     torch.set_num_threads(8)
     P, cfg, BoxList = import_reference()
+    if os.environ.get("GOLDEN_ONLY") == "train":   # regenerate only the training-loss fixtures
+        run_train_losses(P, cfg, BoxList, "train_vanilla", meet=False)
+        run_train_losses(P, cfg, BoxList, "train_vanilla_beta", meet=False, beta_loss=True)
+        run_train_losses(P, cfg, BoxList, "train_meet_vg", meet=True)
+        run_train_losses(P, cfg, BoxList, "train_meet_gqa", meet=True, dataset="GQA")
+        return
     if os.environ.get("GOLDEN_ONLY") == "sggeval":   # regenerate only the evaluator fixtures
         for name in SGG_EVAL_CASES:
             run_sgg_eval(cfg, BoxList, name)
@@ -394,6 +466,10 @@ def main():
         run_postprocessor_vote(cfg, BoxList, "postvote_gqa_c_n7", 7, "GQA", "C")
         run_case(P, cfg, BoxList, "meetx_n10_l4h8", "predcls", 4, 8, [10], meet=True, experts=True)
         return
+    run_train_losses(P, cfg, BoxList, "train_vanilla", meet=False)
+    run_train_losses(P, cfg, BoxList, "train_vanilla_beta", meet=False, beta_loss=True)
+    run_train_losses(P, cfg, BoxList, "train_meet_vg", meet=True)
+    run_train_losses(P, cfg, BoxList, "train_meet_gqa", meet=True, dataset="GQA")
     for name in SGG_EVAL_CASES:
         run_sgg_eval(cfg, BoxList, name)
     run_postprocessor_vote(cfg, BoxList, "postvote_vg_c_n10", 10, "VG", "C")

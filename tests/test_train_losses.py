@@ -1,0 +1,102 @@
+"""Training-time losses and MEET expert sampling (partial): the oracle restatement is
+pinned to what the reference predictor produced in training mode (tests/golden/train_*.npz); the HIP kernels are
+compared with both."""
+import os
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN_DIR
+from oracle import train_oracle as to
+from veto_amd import meet_tables
+
+CASES_VANILLA = ["train_vanilla", "train_vanilla_beta"]
+CASES_MEET = ["train_meet_vg", "train_meet_gqa"]
+
+
+def _load(name):
+    return dict(np.load(os.path.join(GOLDEN_DIR, name + ".npz")))
+
+
+def _words_after_seed(seed, n):
+    """n raw MT19937 words of Python's `random` after random.seed(seed), through numpy's identical generator."""
+    random.seed(seed)
+    st = random.getstate()
+    bg = np.random.MT19937()
+    bg.state = {"bit_generator": "MT19937", "state": {"key": np.array(st[1][:624], dtype=np.uint32), "pos": st[1][624]}}
+    return bg.random_raw(n).astype(np.uint32), st
+
+
+@pytest.mark.parametrize("name", CASES_VANILLA)
+def test_oracle_weighted_ce_matches_reference_loss(name):
+    g = _load(name)
+    w = g["class_weights"] if int(g["beta_loss"]) else None
+    loss, grad = to.weighted_ce(g["logits_0"], g["labels"], w)
+    assert abs(loss - float(g["loss_rel_loss"])) < 2e-6
+    z = torch.from_numpy(g["logits_0"]).double().requires_grad_(True)
+    crit = torch.nn.CrossEntropyLoss(weight=torch.from_numpy(w).double() if w is not None else None)
+    crit(z, torch.from_numpy(g["labels"])).backward()
+    assert np.abs(grad - z.grad.numpy()).max() < 1e-12
+    if w is not None:   # the BETA_LOSS weights themselves (roi_relation_predictors.py:4058-4066)
+        from oracle import veto_oracle as vo
+        counts = np.loadtxt(os.path.join(GOLDEN_DIR, "pred_counts.txt"))
+        assert np.allclose(vo.class_balanced_weights(counts), w, rtol=1e-6)
+
+
+@pytest.mark.parametrize("name", CASES_MEET)
+def test_oracle_meet_sampling_and_group_losses_match_reference(name):
+    g = _load(name)
+    sizes = [int(x) for x in g["group_sizes"]]
+    incre = [int(x) for x in g["incre_idx_list"]]
+    assert meet_tables.incre_idx_list(sizes) == incre
+    srm = meet_tables.sample_rate_matrix(str(g["dataset"]), sizes)
+    assert np.array_equal(np.array(srm), g["sample_rate_matrix"])
+    words, st = _words_after_seed(1, 4 * len(g["labels"]) + 64)
+    stream = to.PyRandomStream(words)
+    chosen = to.meet_sampling(g["labels"], incre, srm, len(sizes), stream)
+    for k in range(len(sizes)):
+        assert np.array_equal(np.array(chosen[k], dtype=np.int64), g["chosen_%d" % k]), k
+    # the stream position is exactly where Python's generator stood afterwards: the next random() agrees
+    assert stream.random() == float(g["random_after"][0])
+    for k in range(len(sizes)):
+        lab = to.meet_group_labels(g["labels"], chosen[k], incre, k)
+        loss, _ = to.weighted_ce(g["logits_%d" % k][chosen[k]], lab)
+        assert abs(loss - float(g["loss_group_%d_CE_loss" % k])) < 2e-6, k
+
+
+# ----------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", CASES_VANILLA)
+def test_hip_ce_loss_matches_reference_and_autograd(name):
+    from veto_amd.losses import relation_ce_loss
+    g = _load(name)
+    dev = torch.device("cuda:0")
+    w = torch.from_numpy(g["class_weights"]).to(dev) if int(g["beta_loss"]) else None
+    logits = torch.from_numpy(g["logits_0"]).to(dev)
+    labels = torch.from_numpy(g["labels"]).to(dev)
+    loss, grad = relation_ce_loss(logits, labels, weight=w, want_grad=True)
+    assert abs(float(loss) - float(g["loss_rel_loss"])) < 5e-6
+    _, ref_grad = to.weighted_ce(g["logits_0"], g["labels"], g["class_weights"] if w is not None else None)
+    assert np.abs(grad.cpu().numpy() - ref_grad).max() < 1e-7
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", CASES_MEET)
+def test_hip_meet_sampling_and_group_losses_match_reference(name):
+    from veto_amd.losses import MeetTrainingSampler, relation_ce_loss
+    g = _load(name)
+    dev = torch.device("cuda:0")
+    sizes = [int(x) for x in g["group_sizes"]]
+    sampler = MeetTrainingSampler(str(g["dataset"]), sizes, device=dev)
+    labels = torch.from_numpy(g["labels"]).to(dev)
+    random.seed(1)
+    chosen, group_labels = sampler.sample(labels)
+    assert random.random() == float(g["random_after"][0])      # Python's generator was advanced by exactly what was used
+    incre = [int(x) for x in g["incre_idx_list"]]
+    for k in range(len(sizes)):
+        assert np.array_equal(chosen[k].cpu().numpy(), g["chosen_%d" % k]), k
+        assert np.array_equal(group_labels[k].cpu().numpy(), to.meet_group_labels(g["labels"], g["chosen_%d" % k], incre, k))
+        loss, _ = relation_ce_loss(torch.from_numpy(g["logits_%d" % k]).to(dev), group_labels[k], rows=chosen[k])
+        assert abs(float(loss) - float(g["loss_group_%d_CE_loss" % k])) < 5e-6, k
