@@ -283,6 +283,26 @@ int veto_debug_gemm(void* stream, const float* a, const float* w, const float* b
                     int32_t n, int32_t k, int32_t precision, void* workspace, size_t workspace_bytes);
 size_t veto_debug_gemm_workspace_bytes(int32_t m, int32_t n, int32_t k);
 
+/* ---- training losses and MEET expert sampling (partial) -------------------------
+ * veto_ce_loss: nn.CrossEntropyLoss(weight)(logits[rows], labels), mean reduction -- the relation loss of
+ * VETOPredictor.forward (roi_relation_predictors.py:4133, BETA_LOSS weights :4057-4068) and, on a row subset with
+ * group-local labels, the per-group losses of Ensemble.forward (:3842-3846).  Writes the loss (device float) and,
+ * if grad is non-NULL, d loss / d logits for the selected rows [n, n_cls]. */
+size_t veto_ce_loss_workspace_bytes(int32_t n);
+int veto_ce_loss(void* stream, const float* logits, int64_t ld, const int64_t* labels, const float* weight,
+                 const int64_t* rows, int32_t n, int32_t n_cls, float* loss, float* grad, void* workspace,
+                 size_t workspace_bytes);
+
+/* veto_meet_sample: the expert sampling loop of VETOPredictor_MEET.forward in training (:3940-3969,
+ * ZERO_LABEL_PADDING_MODE 'rand_insert') followed by the per-group label remap of Ensemble.forward (:3812-3821).
+ * `words` are the next raw 32-bit outputs of Python's `random` generator (MT19937), consumed exactly as
+ * random.randint / random.random would; *words_used tells the host how far to advance its generator (-1: block too
+ * short).  sample_rates is the [n_groups, n_cls] matrix of extra_function_utils.py:185-257 in double precision. */
+int veto_meet_sample(void* stream, const int64_t* labels, int32_t n, const uint32_t* words, int32_t n_words,
+                     const int32_t* incre_idx_list, const int32_t* pos_in_group, const int32_t* group_size,
+                     const double* sample_rates, int32_t n_groups, int32_t n_cls, int64_t* chosen,
+                     int64_t* group_labels, int32_t* counts, int32_t* words_used);
+
 /* ---- test hook: dw[N,K] = dy[M,N]^T . x[M,K], the weight-gradient GEMM (reduction over the M rows) through the
  * production split-bf16 kernel in its split-K / atomic-add form.  k must be a multiple of 192; k_splits 0 = auto. */
 int veto_debug_wgrad(void* stream, const float* dy, const float* x, float* dw, int32_t m, int32_t n, int32_t k,

@@ -189,4 +189,34 @@ struct SggEvalArgs {
 };
 hipError_t launch_sgg_eval(const SggEvalArgs& a, hipStream_t s);
 
+// ---- training losses / MEET sampling (losses.hip) ----------------------------------------------------------
+struct CeLossArgs {
+  const float* logits;           // row r at logits + r*ld
+  long ld;
+  const int64_t* labels;         // [n], aligned with the selected rows
+  const float* weight;           // [C] or nullptr
+  const int64_t* rows;           // [n] row indices into logits, or nullptr = rows 0..n-1
+  int n, C;
+  float *lse, *nll_w, *w_row;    // workspace [n] each
+  float* inv_wsum;               // workspace [1]
+  float* loss;                   // out [1]
+  float* grad;                   // optional out [n, C]
+};
+hipError_t launch_ce_loss(const CeLossArgs& a, hipStream_t s);
+
+struct MeetSampleArgs {
+  const int64_t* labels;         // [n] relation labels
+  int n, n_groups, n_cls, n_words;
+  const uint32_t* words;         // [n_words] raw MT19937 outputs of Python's random, in order
+  const int32_t* incre;          // [n_cls] 1-based group of each class
+  const int32_t* pos_in_group;   // [n_cls] 1-based position of the class inside its group
+  const int32_t* group_size;     // [n_groups]
+  const double* rates;           // [n_groups, n_cls] sample_rate_matrix
+  int64_t* chosen;               // out [n_groups, n] row indices per group (first counts[k] valid)
+  int64_t* group_labels;         // out [n_groups, n] remapped labels of those rows
+  int32_t* counts;               // out [n_groups]
+  int32_t* words_used;           // out [1]; -1 = the word block was too short
+};
+hipError_t launch_meet_sample(const MeetSampleArgs& a, hipStream_t s);
+
 }  // namespace veto

@@ -798,6 +798,40 @@ int veto_debug_gemm(void* stream, const float* a, const float* w, const float* b
   return VETO_OK;
 }
 
+size_t veto_ce_loss_workspace_bytes(int32_t n) { return n > 0 ? 3 * align_up((size_t)n * 4, 256) + 256 : 0; }
+
+int veto_ce_loss(void* stream, const float* logits, int64_t ld, const int64_t* labels, const float* weight,
+                 const int64_t* rows, int32_t n, int32_t n_cls, float* loss, float* grad, void* workspace,
+                 size_t workspace_bytes) {
+  if (!logits || !labels || !loss || !workspace) return fail(VETO_ERR_INVALID, "null argument");
+  if (n <= 0 || n_cls < 2 || ld < n_cls) return fail(VETO_ERR_INVALID, "bad sizes (n %d, n_cls %d, ld %lld)", n, n_cls, (long long)ld);
+  if (workspace_bytes < veto_ce_loss_workspace_bytes(n)) return fail(VETO_ERR_WORKSPACE, "workspace too small");
+  CeLossArgs a{};
+  a.logits = logits; a.ld = ld; a.labels = labels; a.weight = weight; a.rows = rows; a.n = n; a.C = n_cls;
+  char* base = (char*)workspace;
+  const size_t per = align_up((size_t)n * 4, 256);
+  a.lse = (float*)base; a.nll_w = (float*)(base + per); a.w_row = (float*)(base + 2 * per); a.inv_wsum = (float*)(base + 3 * per);
+  a.loss = loss; a.grad = grad;
+  HIP_TRY(launch_ce_loss(a, (hipStream_t)stream));
+  return VETO_OK;
+}
+
+int veto_meet_sample(void* stream, const int64_t* labels, int32_t n, const uint32_t* words, int32_t n_words,
+                     const int32_t* incre_idx_list, const int32_t* pos_in_group, const int32_t* group_size,
+                     const double* sample_rates, int32_t n_groups, int32_t n_cls, int64_t* chosen,
+                     int64_t* group_labels, int32_t* counts, int32_t* words_used) {
+  if (!labels || !words || !incre_idx_list || !pos_in_group || !group_size || !sample_rates || !chosen || !group_labels ||
+      !counts || !words_used)
+    return fail(VETO_ERR_INVALID, "null argument");
+  if (n <= 0 || n_words <= 0 || n_groups < 1 || n_groups > 64 || n_cls < 2) return fail(VETO_ERR_INVALID, "bad sizes");
+  MeetSampleArgs a{};
+  a.labels = labels; a.n = n; a.n_groups = n_groups; a.n_cls = n_cls; a.n_words = n_words; a.words = words;
+  a.incre = incre_idx_list; a.pos_in_group = pos_in_group; a.group_size = group_size; a.rates = sample_rates;
+  a.chosen = chosen; a.group_labels = group_labels; a.counts = counts; a.words_used = words_used;
+  HIP_TRY(launch_meet_sample(a, (hipStream_t)stream));
+  return VETO_OK;
+}
+
 // dw[N,K] = dy[M,N]^T . x[M,K]: the weight-gradient shape (reduction over the M rows).  Both operands are
 // transposed into split rows ([N, 2*Mp] and [K, 2*Mp]) and the persistent GEMM runs split-K with atomic adds.
 static int wgrad_splits(int n, int k, int m, int k_splits) {
