@@ -75,6 +75,10 @@ typedef struct veto_inputs {
   const int64_t* rel_pairs;   /* device [n_pair, 2] image-local (subj, obj), images concatenated */
   const int32_t* img_obj_offset;   /* device [n_img + 1] exclusive prefix sum of objects per image */
   const int32_t* img_pair_offset;  /* device [n_img + 1] exclusive prefix sum of pairs per image */
+  float* bn_batch_stats;      /* NULL: BatchNorm1d(4) of pos_embed in eval mode (running statistics).  Non-NULL device [12]:
+                                 TRAINING-mode BatchNorm (roi_relation_predictors.py:4042-4047, module.train()): the four box
+                                 features are normalised with the statistics of THIS batch, which are also written here as
+                                 mean[4], biased variance[4], unbiased variance[4] for the caller's running-statistics update */
 } veto_inputs_t;
 
 /* Optional extra outputs (all may be NULL); used by the parity tests. */

@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
 def test_struct_sizes_match_the_header_layout():
     # 13 int32 fields; 4 ints + 3 ptrs + 2 ints + 5 ptrs; 2 ints + 4 ptrs
     assert ctypes.sizeof(native.VetoConfig) == 52
-    assert ctypes.sizeof(native.VetoInputs) == 16 + 3 * 8 + 8 + 5 * 8
+    assert ctypes.sizeof(native.VetoInputs) == 16 + 3 * 8 + 8 + 6 * 8
     assert ctypes.sizeof(native.VetoDebugOutputs) == 8 + 4 * 8
     assert ctypes.sizeof(native.VetoPostMeetArgs) == 6 * 4 + 11 * 8
     assert ctypes.sizeof(native.VetoPostVoteArgs) == 8 * 4 + 12 * 8

@@ -100,3 +100,84 @@ def test_hip_meet_sampling_and_group_losses_match_reference(name):
         assert np.array_equal(group_labels[k].cpu().numpy(), to.meet_group_labels(g["labels"], g["chosen_%d" % k], incre, k))
         loss, _ = relation_ce_loss(torch.from_numpy(g["logits_%d" % k]).to(dev), group_labels[k], rows=chosen[k])
         assert abs(float(loss) - float(g["loss_group_%d_CE_loss" % k])) < 5e-6, k
+
+
+def _train_setup(name, meet, dev):
+    from veto_amd import synth, testing
+    g = _load(name)
+    dataset = str(g["dataset"])
+    n_obj_cls = 151 if dataset == "VG" else 201
+    num_objs = [int(x) for x in g["num_objs"]]
+    cfg = testing.make_config(2, 8, "predcls", meet, dataset)
+    cfg.VETO_AMD.TRAIN_FORWARD_ONLY = True
+    if int(g["beta_loss"]):
+        cfg.GLOBAL_SETTING.BETA_LOSS = True
+        cfg.GLOBAL_SETTING.REL_COUNTS = np.loadtxt(os.path.join(GOLDEN_DIR, "pred_counts.txt")).tolist()
+    if meet:
+        sd = synth.meet_state_dict(0, [int(x) for x in g["group_sizes"]], layers=2, num_obj_cls=n_obj_cls)
+    else:
+        sd = synth.predictor_state_dict(0, layers=2, num_obj_cls=n_obj_cls, num_rel_cls=51 if dataset == "VG" else 101)
+    if int(g["beta_loss"]):
+        sd.pop("criterion_loss_rel.weight")       # the synthetic checkpoint stores all-ones class weights
+    model = testing.make_predictor(cfg, sd, dev)
+    model.train()
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    batch = synth.synthetic_batch(7, len(num_objs), num_objs, num_obj_cls=n_obj_cls)
+    return g, model, batch, num_objs
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", CASES_VANILLA + CASES_MEET)
+def test_training_mode_forward_reproduces_reference_losses(name):
+    """The predictor in .train() (forward + losses only, VETO_AMD.TRAIN_FORWARD_ONLY, dropout off): BatchNorm on batch
+    statistics, relation loss / MEET group losses as the reference returned them for the same weights, inputs, labels
+    and Python random seed; the BatchNorm running statistics move the way nn.BatchNorm1d(momentum=0.001) moves them."""
+    from veto_amd import testing
+    from veto_amd.pairs import prepare_test_pairs
+    dev = torch.device("cuda:0")
+    meet = name in CASES_MEET
+    g, model, batch, num_objs = _train_setup(name, meet, dev)
+    props = testing.make_proposals(batch, "predcls", dev)
+    pairs = prepare_test_pairs(dev, props)
+    rel_labels = list(torch.from_numpy(g["labels"]).to(dev).split([int(p.shape[0]) for p in pairs]))
+    bn = (model.model if meet else model).pos_embed[0]
+    rm0, rv0, nb0 = bn.running_mean.clone(), bn.running_var.clone(), int(bn.num_batches_tracked)
+    random.seed(1)
+    out = model(props, pairs, rel_labels, None, roi_features=torch.from_numpy(batch["roi_features"]).to(dev),
+                roi_depth_features=torch.from_numpy(batch["roi_depth_features"]).to(dev))
+    assert out[0] is None and out[1] is None
+    for key, val in out[2].items():
+        ref = float(g["loss_" + key])
+        assert abs(float(val) - ref) < 2e-4 * max(1.0, abs(ref)), (key, float(val), ref)
+    assert set(out[2]) == {k[5:] for k in g if k.startswith("loss_")}
+    if meet:
+        assert random.random() == float(g["random_after"][0])
+        for k in range(len(g["group_sizes"])):
+            assert np.array_equal(out[4][0][k].cpu().numpy(), g["chosen_%d" % k])
+    # running statistics: (1 - m) * old + m * batch statistic (unbiased variance), m = 0.001
+    boxes = torch.from_numpy(batch["boxes"]).double()
+    wh = boxes[:, 2:] - boxes[:, :2] + 1
+    feat = torch.cat([boxes[:, :2] + 0.5 * wh, wh], 1)
+    assert torch.allclose(bn.running_mean.cpu().double(), 0.999 * rm0.cpu().double() + 0.001 * feat.mean(0), rtol=1e-5)
+    assert torch.allclose(bn.running_var.cpu().double(), 0.999 * rv0.cpu().double() + 0.001 * feat.var(0, unbiased=True), rtol=1e-5)
+    assert int(bn.num_batches_tracked) == nb0 + 1
+
+
+@pytest.mark.gpu
+def test_training_mode_stays_refused_without_the_flag_and_with_dropout():
+    from veto_amd import synth, testing
+    dev = torch.device("cuda:0")
+    cfg = testing.make_config(1, 8)
+    model = testing.make_predictor(cfg, synth.predictor_state_dict(0, layers=1), dev).train()
+    batch = synth.synthetic_batch(7, 1, [3])
+    props = testing.make_proposals(batch, "predcls", dev)
+    args = (props, [torch.tensor([[0, 1], [1, 0]], device=dev)], [torch.tensor([1, 0], device=dev)], None)
+    kw = dict(roi_features=torch.from_numpy(batch["roi_features"]).to(dev), roi_depth_features=torch.from_numpy(batch["roi_depth_features"]).to(dev))
+    with pytest.raises(NotImplementedError, match="not built"):
+        model(*args, **kw)
+    cfg.VETO_AMD.TRAIN_FORWARD_ONLY = True
+    model = testing.make_predictor(cfg, synth.predictor_state_dict(0, layers=1), dev).train()
+    with pytest.raises(NotImplementedError, match="dropout"):
+        model(*args, **kw)

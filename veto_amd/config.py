@@ -66,4 +66,5 @@ def default_config():
     c.VETO_AMD = CfgNode()
     c.VETO_AMD.PRECISION = "precise"              # "precise" (3-term split bf16) | "fast" (bf16)
     c.VETO_AMD.MAX_CHUNK_PAIRS = 0
+    c.VETO_AMD.TRAIN_FORWARD_ONLY = False         # True: .train() runs the forward + losses (no backward exists yet)
     return c

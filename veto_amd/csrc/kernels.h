@@ -60,6 +60,9 @@ struct ObjPrepArgs {
   int n_obj;
 };
 hipError_t launch_obj_prep(const ObjPrepArgs& a, hipStream_t s);
+// training-mode BatchNorm1d(4) statistics of the box features center_xywh(boxes): out[0..3] mean, [4..7] biased
+// variance (what the batch is normalised with), [8..11] unbiased variance (what running_var is updated with)
+hipError_t launch_bn_batch_stats(const float* boxes, int box_mode, int n_obj, float* out, hipStream_t s);
 // rgb/depth [n_obj, 256, 8, 8] -> patch rows [n_obj*16, 2*2048] split rows (depth features first)
 hipError_t launch_patchify(const float* depth, const float* rgb, __bf16* dst, int n_obj, hipStream_t s);
 

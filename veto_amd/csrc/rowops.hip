@@ -107,6 +107,43 @@ __global__ void transpose_head_kernel(const float* __restrict__ src, float* __re
 // ------------------------------------------------------------------------------------------------
 // per-object stage
 // ------------------------------------------------------------------------------------------------
+// Batch statistics of the four box features (centre x, centre y, w, h; same formula as obj_prep_kernel) for
+// BatchNorm1d(4) in training mode: one workgroup, two passes (mean, then centred squares) in double precision.
+__global__ __launch_bounds__(256) void bn_batch_stats_kernel(const float* __restrict__ boxes, int box_mode, int n_obj,
+                                                             float* __restrict__ out) {
+  __shared__ double s_acc[256][4];
+  __shared__ double s_mean[4];
+  const int tid = threadIdx.x;
+  auto feat = [&](int n, double (&v)[4]) {
+    const float* b = boxes + (size_t)n * 4;
+    float w, h;
+    if (box_mode == 0) { w = b[2] - b[0] + 1.f; h = b[3] - b[1] + 1.f; } else { w = b[2]; h = b[3]; }
+    v[0] = b[0] + 0.5f * w; v[1] = b[1] + 0.5f * h; v[2] = w; v[3] = h;
+  };
+  for (int pass = 0; pass < 2; ++pass) {
+    double acc[4] = {0, 0, 0, 0};
+    for (int n = tid; n < n_obj; n += 256) {
+      double v[4];
+      feat(n, v);
+      for (int k = 0; k < 4; ++k) { const double d = pass == 0 ? v[k] : v[k] - s_mean[k]; acc[k] += pass == 0 ? d : d * d; }
+    }
+    for (int k = 0; k < 4; ++k) s_acc[tid][k] = acc[k];
+    __syncthreads();
+    if (tid < 4) {
+      double t = 0;
+      for (int i = 0; i < 256; ++i) t += s_acc[i][tid];
+      if (pass == 0) {
+        s_mean[tid] = t / n_obj;
+        out[tid] = (float)s_mean[tid];
+      } else {
+        out[4 + tid] = (float)(t / n_obj);
+        out[8 + tid] = (float)(n_obj > 1 ? t / (n_obj - 1) : t);
+      }
+    }
+    __syncthreads();
+  }
+}
+
 __global__ __launch_bounds__(256) void obj_prep_kernel(ObjPrepArgs a) {
   __shared__ float s_box[4];
   __shared__ float s_pos[kPosDim];
@@ -384,6 +421,11 @@ hipError_t launch_transpose_pair_proj(const float* src, float* dst, int kin, hip
 
 hipError_t launch_transpose_head(const float* src, float* dst, int n_out, hipStream_t s) {
   VETO_LAUNCH(transpose_head_kernel, dim3(kDim), dim3(128), 0, s, src, dst, n_out);
+  return hipGetLastError();
+}
+
+hipError_t launch_bn_batch_stats(const float* boxes, int box_mode, int n_obj, float* out, hipStream_t s) {
+  VETO_LAUNCH(bn_batch_stats_kernel, dim3(1), dim3(256), 0, s, boxes, box_mode, n_obj, out);
   return hipGetLastError();
 }
 

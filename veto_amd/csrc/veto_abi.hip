@@ -392,6 +392,10 @@ int veto_forward(veto_handle_t h, void* stream, const veto_inputs_t* in, void* w
     a.embed = h->p("obj_embed.weight"); a.num_obj_cls = h->cfg.num_obj_cls; a.embed_dim = h->cfg.embed_dim;
     a.bn_w = h->p("pos_embed.0.weight"); a.bn_b = h->p("pos_embed.0.bias");
     a.bn_mean = h->p("pos_embed.0.running_mean"); a.bn_var = h->p("pos_embed.0.running_var");
+    if (in->bn_batch_stats) {   // training-mode BatchNorm: this batch's statistics (biased variance)
+      HIP_TRY(launch_bn_batch_stats(in->boxes, in->box_mode, n_obj, in->bn_batch_stats, s));
+      a.bn_mean = in->bn_batch_stats; a.bn_var = in->bn_batch_stats + 4;
+    }
     a.pos_w = h->p("pos_embed.1.weight"); a.pos_b = h->p("pos_embed.1.bias");
     a.loc_wt = h->loc_wt; a.loc_b = h->p("location_projection.0.bias");
     a.cls_wt = h->cls_wt; a.cls_b = h->p("class_projection.0.bias");

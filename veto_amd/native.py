@@ -39,7 +39,7 @@ class VetoInputs(Structure):
         ("roi_rgb", c_void_p), ("roi_depth", c_void_p), ("boxes", c_void_p),
         ("box_mode", c_int32), ("reserved0", c_int32),
         ("obj_labels", c_void_p), ("obj_logits", c_void_p), ("rel_pairs", c_void_p),
-        ("img_obj_offset", c_void_p), ("img_pair_offset", c_void_p),
+        ("img_obj_offset", c_void_p), ("img_pair_offset", c_void_p), ("bn_batch_stats", c_void_p),
     ]
 
 

@@ -241,8 +241,32 @@ class _NativeForward:
     def _offsets(self, n_objs, n_pairs, device):
         return cached_offsets(n_objs, n_pairs, device)
 
+    def _check_train_forward(self, config_flag):
+        """Training mode runs only as a FORWARD + LOSS pass (no backward exists yet), only when asked for
+        (VETO_AMD.TRAIN_FORWARD_ONLY) and only without dropout (dropout masks are not built)."""
+        if not config_flag:
+            raise NotImplementedError(_TRAIN_MSG)
+        live = [n for n, m in self._trunk.named_modules() if isinstance(m, nn.Dropout) and m.p > 0]
+        if live:
+            raise NotImplementedError("veto_amd: the training-mode forward exists without dropout only; these modules have "
+                                      "p > 0: %s" % ", ".join(live[:6]))
+
+    def _run_native_train(self, proposals, rel_pair_idxs, roi_features, roi_depth_features, labels, logits):
+        """Forward in training mode: BatchNorm1d(4) of pos_embed on batch statistics (and its running statistics
+        updated the way nn.BatchNorm1d(momentum=0.001) does, roi_relation_predictors.py:4042-4047)."""
+        device = roi_features.device
+        stats = torch.empty(12, dtype=torch.float32, device=device)
+        out = self._run_native(proposals, rel_pair_idxs, roi_features, roi_depth_features, labels, logits, bn_batch_stats=stats)
+        bn = self._trunk.pos_embed[0]
+        with torch.no_grad():
+            m = bn.momentum
+            bn.running_mean.mul_(1 - m).add_(stats[0:4].to(bn.running_mean.device), alpha=m)
+            bn.running_var.mul_(1 - m).add_(stats[8:12].to(bn.running_var.device), alpha=m)
+            bn.num_batches_tracked += 1
+        return out
+
     def _run_native(self, proposals, rel_pair_idxs, roi_features, roi_depth_features, labels, logits,
-                    debug=False):
+                    debug=False, bn_batch_stats=None):
         device = roi_features.device
         eng = self._ensure_engine(device)
         n_objs = [len(p) for p in proposals]
@@ -277,6 +301,7 @@ class _NativeForward:
         inp.obj_logits = lg.data_ptr() if lg is not None else None
         inp.rel_pairs = pairs.data_ptr()
         inp.img_obj_offset, inp.img_pair_offset = obj_off.data_ptr(), pair_off.data_ptr()
+        inp.bn_batch_stats = bn_batch_stats.data_ptr() if bn_batch_stats is not None else None
         dbg, extras = None, None
         if debug:
             extras = {"subj_inds": torch.empty(n_pair, dtype=torch.int64, device=device),
@@ -340,11 +365,12 @@ class VETOPredictor(nn.Module, _NativeForward):
         self.criterion_loss_rel = nn.CrossEntropyLoss(weight=weights)
         self.criterion_loss = nn.CrossEntropyLoss()
         self._native_init(config, self, self.num_obj_cls, [self.rel_out])
+        self._train_forward_only = bool(getattr(getattr(config, "VETO_AMD", None), "TRAIN_FORWARD_ONLY", False))
 
     def forward(self, proposals, rel_pair_idxs, rel_labels, logger, roi_features=None,
                 roi_depth_features=None, rel_binarys=None):
         if self.training:
-            raise NotImplementedError(_TRAIN_MSG)
+            self._check_train_forward(self._train_forward_only)
         if self.mode == "predcls":
             labels = _cat_field(proposals, "labels").long()
             logits = None
@@ -353,6 +379,16 @@ class VETOPredictor(nn.Module, _NativeForward):
             logits = _cat_field(proposals, "predict_logits").detach()
             obj_label_for_dist = _cat_field(proposals, "pred_labels").detach().long()
             labels = None
+        if self.training:   # :4127-4136: losses only; forward-only here (the losses carry no autograd graph)
+            from .losses import relation_ce_loss
+            rel, _, _ = self._run_native_train(proposals, rel_pair_idxs, roi_features, roi_depth_features, labels, logits)
+            add_losses = {}
+            if self.mode != "predcls":
+                fg = _cat_field(proposals, "labels").long()
+                add_losses["obj_loss"] = relation_ce_loss(logits.to(rel.device), fg)[0][0]
+            w = self.criterion_loss_rel.weight
+            add_losses["rel_loss"] = relation_ce_loss(rel, torch.cat(list(rel_labels), 0), weight=w)[0][0]
+            return None, None, add_losses, None, None, None
         rel, n_objs, n_pairs = self._run_native(proposals, rel_pair_idxs, roi_features, roi_depth_features,
                                                 labels, logits, debug=getattr(self, "debug_outputs", False))
         obj_dists = nn.functional.one_hot(obj_label_for_dist.to(rel.device), self.num_obj_cls).float()
@@ -421,11 +457,16 @@ class VETOPredictor_MEET(nn.Module, _NativeForward):
         else:
             heads = list(self.model.rel_out)
         self._native_init(config, self.model, self.num_obj_cls, heads)
+        self._train_forward_only = bool(getattr(getattr(config, "VETO_AMD", None), "TRAIN_FORWARD_ONLY", False))
+        self._dataset, self._sampler = dataset, None
+        self._zero_label_padding_mode = str(config.GCL_SETTING.ZERO_LABEL_PADDING_MODE)
 
     def forward(self, proposals, rel_pair_idxs, rel_labels, logger, roi_features=None,
                 roi_depth_features=None, rel_binarys=None):
         if self.training:
-            raise NotImplementedError(_TRAIN_MSG)
+            self._check_train_forward(self._train_forward_only)
+            if self.expert_group:
+                raise NotImplementedError("veto_amd: the training-mode forward of the EXPERT_GROUP heads is not built")
         if self.mode == "predcls":
             labels = _cat_field(proposals, "labels").long()
             dist_labels = labels
@@ -436,6 +477,22 @@ class VETOPredictor_MEET(nn.Module, _NativeForward):
             dist_labels = _cat_field(proposals, "pred_labels").detach().long()
             # obj_dists[:, 1:].max(1)[1] + 1 over a one-hot (:3776-3784): the label itself, or 1 for label 0
             labels = torch.where(dist_labels > 0, dist_labels, torch.ones_like(dist_labels))
+        if self.training:
+            # :3930-3969 expert sampling, :3806-3846 group label remap + per-group CE; forward-only (no autograd graph)
+            from .losses import MeetTrainingSampler, relation_ce_loss
+            rel, _, _ = self._run_native_train(proposals, rel_pair_idxs, roi_features, roi_depth_features, labels, None)
+            if self._sampler is None or self._sampler.device != rel.device:
+                self._sampler = MeetTrainingSampler(self._dataset, self.max_group_element_number_list, device=rel.device,
+                                                    zero_label_padding_mode=self._zero_label_padding_mode)
+            chosen, group_labels = self._sampler.sample(torch.cat(list(rel_labels), 0))
+            add_losses, col = {}, 0
+            for k, g in enumerate(self.max_group_element_number_list):
+                add_losses["group_%d_CE_loss" % k] = relation_ce_loss(rel[:, col:col + g + 2], group_labels[k], rows=chosen[k])[0][0]
+                col += g + 2
+            if self.mode != "predcls":   # :3823-3827
+                obj_logits = _cat_field(proposals, "predict_logits").detach()
+                add_losses["obj_loss"] = relation_ce_loss(obj_logits.to(rel.device), _cat_field(proposals, "labels").long())[0][0]
+            return None, None, add_losses, self.incre_idx_list, [chosen], None
         rel, n_objs, n_pairs = self._run_native(proposals, rel_pair_idxs, roi_features, roi_depth_features,
                                                 labels, None, debug=getattr(self, "debug_outputs", False))
         rel_dists, col = {}, 0
