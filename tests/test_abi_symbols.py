@@ -65,3 +65,17 @@ def test_create_rejects_bad_configs_without_a_gpu():
         assert needle in lib.veto_last_error(), (bad, lib.veto_last_error())
     assert lib.veto_workspace_bytes(None, 10, 90) == 0
     assert lib.veto_debug_gemm_workspace_bytes(256, 192, 32) == 2 * 256 * 32 * 2 + 2 * 192 * 32 * 2
+
+
+def test_public_header_is_plain_c(tmp_path):
+    """include/veto_amd.h is the drop-in boundary: it must compile as C99 (no C++-isms, no torch types)."""
+    import os
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    src = tmp_path / "hdr.c"
+    src.write_text('#include "veto_amd.h"\nint main(void) { veto_config_t c; c.struct_size = (int32_t)sizeof(c); return c.struct_size == 0; }\n')
+    inc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include")
+    subprocess.run([gcc, "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-fsyntax-only", "-I", inc, str(src)], check=True)
