@@ -4,6 +4,8 @@ import ctypes
 import os
 import re
 
+import pytest
+
 from veto_amd import native
 
 HEADER = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "veto_amd.h")
