@@ -222,4 +222,16 @@ struct MeetSampleArgs {
 };
 hipError_t launch_meet_sample(const MeetSampleArgs& a, hipStream_t s);
 
+// ---- backward building blocks (backward.hip) -----------------------------------------------------------------
+// qkv, dqkv: [n_pair*19, 1728]; dout: [n_pair*19, 576] (gradient of the attention output before the out projection)
+hipError_t launch_attention_backward(const float* qkv, const float* dout, float* dqkv, int n_pair, int heads, hipStream_t s);
+// dx = LayerNorm backward of dy w.r.t. x (+ dres if given); dgamma_dbeta [2, 576]; partial: workspace of
+// layernorm_backward_partial_floats(rows) floats
+size_t layernorm_backward_partial_floats(int rows);
+hipError_t launch_layernorm_backward(const float* x, const float* dy, const float* gamma, const float* dres, float* dx,
+                                     float* dgamma_dbeta, float* partial, int rows, hipStream_t s);
+// out[c] = sum_r dy[r][c]; partial: workspace [n_chunks, n_cols]
+hipError_t launch_column_sums(const float* dy, long ld, int rows, int n_cols, float* out, float* partial, int n_chunks, hipStream_t s);
+hipError_t launch_gelu_backward(const float* pre, const float* dh, float* dpre, size_t n, hipStream_t s);
+
 }  // namespace veto

@@ -879,4 +879,35 @@ int veto_debug_wgrad(void* stream, const float* dy, const float* x, float* dw, i
   return VETO_OK;
 }
 
+int veto_debug_attention_backward(void* stream, const float* qkv, const float* dout, float* dqkv, int32_t n_pair, int32_t heads) {
+  if (!qkv || !dout || !dqkv || n_pair <= 0) return fail(VETO_ERR_INVALID, "bad argument");
+  hipError_t e = launch_attention_backward(qkv, dout, dqkv, n_pair, heads, (hipStream_t)stream);
+  if (e != hipSuccess) return fail(e == hipErrorInvalidValue ? VETO_ERR_INVALID : VETO_ERR_HIP, "attention backward: %s (heads must give a head width of 72, 96 or 144)", hipGetErrorString(e));
+  return VETO_OK;
+}
+
+size_t veto_debug_layernorm_backward_workspace_bytes(int32_t rows) { return rows > 0 ? layernorm_backward_partial_floats(rows) * 4 : 0; }
+
+int veto_debug_layernorm_backward(void* stream, const float* x, const float* dy, const float* gamma, const float* dres,
+                                  float* dx, float* dgamma_dbeta, int32_t rows, void* workspace, size_t workspace_bytes) {
+  if (!x || !dy || !gamma || !dx || !dgamma_dbeta || !workspace || rows <= 0) return fail(VETO_ERR_INVALID, "bad argument");
+  if (workspace_bytes < veto_debug_layernorm_backward_workspace_bytes(rows)) return fail(VETO_ERR_WORKSPACE, "workspace too small");
+  HIP_TRY(launch_layernorm_backward(x, dy, gamma, dres, dx, dgamma_dbeta, (float*)workspace, rows, (hipStream_t)stream));
+  return VETO_OK;
+}
+
+int veto_debug_gelu_backward(void* stream, const float* pre, const float* dh, float* dpre, size_t n) {
+  if (!pre || !dh || !dpre || n == 0 || n % 4 != 0) return fail(VETO_ERR_INVALID, "bad argument (n must be a positive multiple of 4)");
+  HIP_TRY(launch_gelu_backward(pre, dh, dpre, n, (hipStream_t)stream));
+  return VETO_OK;
+}
+
+int veto_debug_column_sums(void* stream, const float* dy, int64_t ld, int32_t rows, int32_t n_cols, float* out, void* workspace,
+                           size_t workspace_bytes) {
+  if (!dy || !out || !workspace || rows <= 0 || n_cols <= 0 || ld < n_cols) return fail(VETO_ERR_INVALID, "bad argument");
+  if (workspace_bytes < (size_t)64 * n_cols * 4) return fail(VETO_ERR_WORKSPACE, "workspace too small (64 * n_cols floats)");
+  HIP_TRY(launch_column_sums(dy, ld, rows, n_cols, out, (float*)workspace, 64, (hipStream_t)stream));
+  return VETO_OK;
+}
+
 }  // extern "C"

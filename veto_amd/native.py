@@ -20,6 +20,8 @@ EXPORTS = [
     "veto_enumerate_pairs", "veto_profile_enable", "veto_profile_collect", "veto_profile_entry",
     "veto_profile_reset", "veto_debug_gemm", "veto_debug_gemm_workspace_bytes",
     "veto_postprocess", "veto_postprocess_workspace_bytes", "veto_postprocess_meet", "veto_postprocess_vote",
+    "veto_debug_attention_backward", "veto_debug_layernorm_backward", "veto_debug_layernorm_backward_workspace_bytes",
+    "veto_debug_gelu_backward", "veto_debug_column_sums",
     "veto_debug_wgrad", "veto_debug_wgrad_workspace_bytes", "veto_ce_loss", "veto_ce_loss_workspace_bytes", "veto_meet_sample",
     "veto_roi_pool", "veto_roi_pool_backward", "veto_sgg_eval", "veto_sgg_eval_workspace_bytes",
 ]
@@ -137,6 +139,13 @@ def load_library():
     lib.veto_postprocess.argtypes = [c_void_p, POINTER(VetoPostArgs), c_void_p, c_size_t]
     lib.veto_postprocess_meet.argtypes = [c_void_p, POINTER(VetoPostMeetArgs), c_void_p, c_size_t]
     lib.veto_postprocess_vote.argtypes = [c_void_p, POINTER(VetoPostVoteArgs), c_void_p, c_size_t]
+    lib.veto_debug_attention_backward.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32]
+    lib.veto_debug_layernorm_backward_workspace_bytes.argtypes = [c_int32]
+    lib.veto_debug_layernorm_backward_workspace_bytes.restype = c_size_t
+    lib.veto_debug_layernorm_backward.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32,
+                                                  c_void_p, c_size_t]
+    lib.veto_debug_gelu_backward.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t]
+    lib.veto_debug_column_sums.argtypes = [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_size_t]
     lib.veto_ce_loss_workspace_bytes.argtypes = [c_int32]
     lib.veto_ce_loss_workspace_bytes.restype = c_size_t
     lib.veto_ce_loss.argtypes = [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p,
