@@ -307,6 +307,23 @@ int veto_meet_sample(void* stream, const int64_t* labels, int32_t n, const uint3
                      const double* sample_rates, int32_t n_groups, int32_t n_cls, int64_t* chosen,
                      int64_t* group_labels, int32_t* counts, int32_t* words_used);
 
+/* ---- training path: forward that keeps the activations + backward --------------
+ * The backward of VETOPredictor.forward's computation graph (roi_relation_predictors.py:4074-4133, model_veto.py)
+ * w.r.t. every parameter, for hard object labels (predcls, MEET), precise mode, WITHOUT dropout (the caller must have
+ * dropout off).  veto_forward_train runs all pairs in one pass, every layer on all 19 tokens, BatchNorm on batch
+ * statistics (in->bn_batch_stats is mandatory), and leaves the activations in `workspace`
+ * (veto_train_workspace_bytes, ~28 KB per token row and layer); veto_backward takes d loss / d logits
+ * [n_pair, num_out] and writes d loss / d parameter for every state-dict tensor into `grads`, a flat float buffer of
+ * veto_grad_floats(h) elements in which tensor i starts at veto_weight_offset(h, i) (buffers such as running
+ * statistics get zeros).  Both calls must see the same inputs and workspace. */
+size_t veto_train_workspace_bytes(veto_handle_t h, int32_t n_obj, int32_t n_pair);
+size_t veto_grad_floats(veto_handle_t h);
+int veto_weight_offset(veto_handle_t h, int index, size_t* offset_floats);
+int veto_forward_train(veto_handle_t h, void* stream, const veto_inputs_t* in, void* workspace, size_t workspace_bytes,
+                       float* out_logits);
+int veto_backward(veto_handle_t h, void* stream, const veto_inputs_t* in, void* workspace, size_t workspace_bytes,
+                  const float* dlogits, float* grads);
+
 /* ---- test hook: dw[N,K] = dy[M,N]^T . x[M,K], the weight-gradient GEMM (reduction over the M rows) through the
  * production split-bf16 kernel in its split-K / atomic-add form.  k must be a multiple of 192; k_splits 0 = auto. */
 int veto_debug_wgrad(void* stream, const float* dy, const float* x, float* dw, int32_t m, int32_t n, int32_t k,

@@ -378,6 +378,17 @@ def run_train_losses(P, cfg, BoxList, name, meet, beta_loss=False, dataset="VG")
     for h in hooks:
         h.remove()
     out = {"labels": labels, "meet": int(meet), "dataset": dataset, "beta_loss": int(beta_loss), "num_objs": np.array(num_objs)}
+    # gradients of the summed losses w.r.t. every parameter (the reference's training loop sums the loss dict,
+    # engine/trainer + tools/relation_train_net.py:297): stored as norm + a strided sample (full tensor when small)
+    sum(res[2].values()).backward()
+    for pname, prm in model.named_parameters():
+        if prm.grad is None:
+            continue
+        gflat = prm.grad.detach().reshape(-1).numpy()
+        step = max(1, gflat.size // 512)
+        out["gradnorm_" + pname] = np.array(float(np.linalg.norm(gflat.astype(np.float64))))
+        out["gradsample_" + pname] = gflat[::step].copy()
+        out["gradstep_" + pname] = np.array(step)
     for k, v in captured.items():
         out["logits_%d" % k] = v.numpy()
     for k, v in res[2].items():

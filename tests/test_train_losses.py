@@ -102,14 +102,14 @@ def test_hip_meet_sampling_and_group_losses_match_reference(name):
         assert abs(float(loss) - float(g["loss_group_%d_CE_loss" % k])) < 5e-6, k
 
 
-def _train_setup(name, meet, dev):
+def _train_setup(name, meet, dev, forward_only=True):
     from veto_amd import synth, testing
     g = _load(name)
     dataset = str(g["dataset"])
     n_obj_cls = 151 if dataset == "VG" else 201
     num_objs = [int(x) for x in g["num_objs"]]
     cfg = testing.make_config(2, 8, "predcls", meet, dataset)
-    cfg.VETO_AMD.TRAIN_FORWARD_ONLY = True
+    cfg.VETO_AMD.TRAIN_FORWARD_ONLY = forward_only
     if int(g["beta_loss"]):
         cfg.GLOBAL_SETTING.BETA_LOSS = True
         cfg.GLOBAL_SETTING.REL_COUNTS = np.loadtxt(os.path.join(GOLDEN_DIR, "pred_counts.txt")).tolist()
@@ -166,7 +166,7 @@ def test_training_mode_forward_reproduces_reference_losses(name):
 
 
 @pytest.mark.gpu
-def test_training_mode_stays_refused_without_the_flag_and_with_dropout():
+def test_training_mode_refuses_dropout():
     from veto_amd import synth, testing
     dev = torch.device("cuda:0")
     cfg = testing.make_config(1, 8)
@@ -175,9 +175,48 @@ def test_training_mode_stays_refused_without_the_flag_and_with_dropout():
     props = testing.make_proposals(batch, "predcls", dev)
     args = (props, [torch.tensor([[0, 1], [1, 0]], device=dev)], [torch.tensor([1, 0], device=dev)], None)
     kw = dict(roi_features=torch.from_numpy(batch["roi_features"]).to(dev), roi_depth_features=torch.from_numpy(batch["roi_depth_features"]).to(dev))
-    with pytest.raises(NotImplementedError, match="not built"):
-        model(*args, **kw)
-    cfg.VETO_AMD.TRAIN_FORWARD_ONLY = True
-    model = testing.make_predictor(cfg, synth.predictor_state_dict(0, layers=1), dev).train()
     with pytest.raises(NotImplementedError, match="dropout"):
         model(*args, **kw)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", CASES_VANILLA + CASES_MEET)
+def test_training_backward_matches_reference_gradients(name):
+    """loss.backward() through the HIP training path (veto_forward_train / veto_backward / veto_ce_loss) against the
+    gradients the reference's autograd produced for the same weights, inputs, labels and random seed: every parameter's
+    gradient norm and a strided sample of its entries."""
+    from veto_amd import testing
+    from veto_amd.pairs import prepare_test_pairs
+    dev = torch.device("cuda:0")
+    meet = name in CASES_MEET
+    g, model, batch, num_objs = _train_setup(name, meet, dev, forward_only=False)
+    props = testing.make_proposals(batch, "predcls", dev)
+    pairs = prepare_test_pairs(dev, props)
+    rel_labels = list(torch.from_numpy(g["labels"]).to(dev).split([int(p.shape[0]) for p in pairs]))
+    random.seed(1)
+    out = model(props, pairs, rel_labels, None, roi_features=torch.from_numpy(batch["roi_features"]).to(dev),
+                roi_depth_features=torch.from_numpy(batch["roi_depth_features"]).to(dev))
+    for key, val in out[2].items():
+        ref = float(g["loss_" + key])
+        assert abs(float(val.detach()) - ref) < 2e-4 * max(1.0, abs(ref)), (key, float(val.detach()), ref)
+    sum(out[2].values()).backward()
+    torch.cuda.synchronize()
+    params = dict(model.named_parameters())
+    names = [k[9:] for k in g if k.startswith("gradnorm_")]
+    assert names
+    worst = 0.0
+    for pname in names:
+        prm = params[pname]
+        assert prm.grad is not None, pname
+        got = prm.grad.detach().reshape(-1).cpu().numpy().astype(np.float64)
+        ref_norm = float(g["gradnorm_" + pname])
+        step = int(g["gradstep_" + pname])
+        ref_s = g["gradsample_" + pname].astype(np.float64)
+        scale = max(np.abs(ref_s).max(), ref_norm / np.sqrt(got.size), 1e-8)
+        err = np.abs(got[::step] - ref_s).max() / scale
+        nerr = abs(np.linalg.norm(got) - ref_norm) / max(ref_norm, 1e-8)
+        worst = max(worst, err, nerr)
+        assert err < 2e-3 and nerr < 2e-3, (pname, err, nerr, ref_norm)
+    # parameters the loss does not depend on stay without gradient (obj_embed2 in predcls, BatchNorm statistics)
+    assert all(params[n].grad is None or float(params[n].grad.abs().max()) == 0.0 for n in params if n not in names)
+    print("%s: worst relative gradient error %.2e over %d parameters" % (name, worst, len(names)))

@@ -96,8 +96,9 @@ struct AttnArgs {
 };
 hipError_t launch_attention(const AttnArgs& a, hipStream_t s);
 
+// cls row p at cls + p*ld (ld = 576 for compact CLS rows, 19*576 to read row 0 of every pair of a token matrix)
 hipError_t launch_head(const float* cls, const float* wt, const float* bias, float* out, int n_pair,
-                       int n_out, hipStream_t s);
+                       int n_out, hipStream_t s, long ld = kDim);
 
 // ---- post-processing (inference.py:398-453, GT-box branch) -------------------------------------
 struct PostArgs {
@@ -233,5 +234,24 @@ hipError_t launch_layernorm_backward(const float* x, const float* dy, const floa
 // out[c] = sum_r dy[r][c]; partial: workspace [n_chunks, n_cols]
 hipError_t launch_column_sums(const float* dy, long ld, int rows, int n_cols, float* out, float* partial, int n_chunks, hipStream_t s);
 hipError_t launch_gelu_backward(const float* pre, const float* dh, float* dpre, size_t n, hipStream_t s);
+
+// ---- training path around the GEMMs (train.hip) ---------------------------------------------------------------
+hipError_t launch_transpose_from_split(const __bf16* src, long ld, int M, int K, __bf16* dst, int Mp, hipStream_t s);
+hipError_t launch_gelu_split(const float* pre, __bf16* dst, size_t rows, int n_cols, hipStream_t s);
+// dx[p*19, :] = dlogits[p] . W (other rows untouched); dw [n_out, 576], db [n_out]; x = token matrix [n_pair*19, 576]
+hipError_t launch_head_backward(const float* dlogits, const float* w, const float* x, float* dx, float* dw, float* db, int n_pair,
+                                int n_out, hipStream_t s);
+hipError_t launch_assemble_backward(const float* dx, const int32_t* subj, const int32_t* obj, const float* lc, float* dpatch, float* dlc,
+                                    int n_pair, hipStream_t s);
+hipError_t launch_sgemm_tn(const float* a, long lda, const float* b, long ldb, float* c, long ldc, int n, int ka, int kb, hipStream_t s);
+hipError_t launch_sgemm_nt(const float* a, long lda, const float* b, long ldb, float* c, long ldc, int n, int ki, int kj, hipStream_t s);
+hipError_t launch_obj_pos_backward(const float* boxes, int box_mode, const float* stats, const float* bn_w, const float* bn_b,
+                                   const float* pos_w, const float* pos_b, const float* dpos, float* dpre, float* xhat, float* bn_out,
+                                   float* dbn_out, float* dgamma, float* dbeta, int n_obj, hipStream_t s);
+hipError_t launch_bias_relu(float* x, const float* b, int n, int k, hipStream_t s);
+hipError_t launch_gather_rows(const float* table, const int64_t* labels, int dim, float* out, int n, hipStream_t s);
+hipError_t launch_scatter_rows(const float* demb, const int64_t* labels, int dim, float* dtable, int n, hipStream_t s);
+hipError_t launch_untranspose_pair_proj(const float* dwt, float* dw, int kin, hipStream_t s);
+hipError_t launch_patch_weight_grad(const float* dwcat_t, float* dwd, float* dwv, hipStream_t s);
 
 }  // namespace veto

@@ -370,12 +370,12 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 __global__ __launch_bounds__(128) void head_kernel(const float* __restrict__ cls,
                                                    const float* __restrict__ wt,
                                                    const float* __restrict__ bias, float* __restrict__ out,
-                                                   int n_pair, int n_out) {
+                                                   int n_pair, int n_out, long ld) {
   __shared__ float s_cls[4][kDim];
   const int p0 = blockIdx.x * 4;
   for (int i = threadIdx.x; i < 4 * kDim; i += 128) {
     const int pp = i / kDim, k = i % kDim;
-    s_cls[pp][k] = p0 + pp < n_pair ? cls[(size_t)(p0 + pp) * kDim + k] : 0.f;
+    s_cls[pp][k] = p0 + pp < n_pair ? cls[(size_t)(p0 + pp) * ld + k] : 0.f;
   }
   __syncthreads();
   for (int c = threadIdx.x; c < n_out; c += 128) {
@@ -466,8 +466,8 @@ hipError_t launch_layernorm(const float* x, long ldx, const float* w, const floa
 }
 
 hipError_t launch_head(const float* cls, const float* wt, const float* bias, float* out, int n_pair,
-                       int n_out, hipStream_t s) {
-  VETO_LAUNCH(head_kernel, dim3((n_pair + 3) / 4), dim3(128), 0, s, cls, wt, bias, out, n_pair, n_out);
+                       int n_out, hipStream_t s, long ld) {
+  VETO_LAUNCH(head_kernel, dim3((n_pair + 3) / 4), dim3(128), 0, s, cls, wt, bias, out, n_pair, n_out, ld);
   return hipGetLastError();
 }
 

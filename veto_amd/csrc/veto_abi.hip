@@ -500,6 +500,355 @@ int veto_forward(veto_handle_t h, void* stream, const veto_inputs_t* in, void* w
   return VETO_OK;
 }
 
+}  // extern "C"
+
+// ================================================================================================================
+// Training path: forward that keeps every activation the backward needs, and the
+// backward itself.  One pass over all pairs (no chunking), precise mode, no dropout (the caller refuses p > 0).
+// Every layer runs on all 19 tokens (the CLS-only shortcut of the inference path would complicate the backward).
+// ================================================================================================================
+extern "C" size_t veto_train_workspace_bytes(veto_handle_t h, int32_t n_obj, int32_t n_pair);
+
+namespace {
+
+struct TrainLayer {
+  float* xin;    // [mpad, 576]   input of the layer (residual stream)
+  __bf16* a1;    // split LN1(xin)
+  float* qkv;    // [mpad, 1728]
+  __bf16* ao;    // split attention output
+  float* xmid;   // [mpad, 576]   after the attention residual
+  __bf16* a2;    // split LN2(xmid)
+  float* pre;    // [mpad, 1152]  fc1 pre-activation
+  __bf16* hid;   // split gelu(pre)
+};
+
+struct TrainWs {
+  int32_t *subj, *obj;
+  float *lc, *patch_tab, *xout;
+  __bf16* pa;
+  std::vector<TrainLayer> layers;
+  // backward scratch
+  float *dx, *dmid, *dtmp, *dbig;
+  __bf16 *dsplit, *at, *wt, *wdg;
+  float *ln_partial, *col_partial, *dgb;
+  float *dpatch, *dlc, *dpos, *dpre, *xhat, *bn_out, *dbn_out, *emb, *demb, *dloc_wt, *dcls_wt, *dwcat_t;
+  size_t mp2;    // padded reduction length of the weight-gradient GEMMs
+  size_t total;
+};
+
+TrainWs carve_train(char* base, veto_handle_t h, int n_obj, int n_pair) {
+  TrainWs w;
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    char* ptr = base ? base + off : nullptr;
+    off += align_up(bytes, 256);
+    return ptr;
+  };
+  const int L = h->cfg.layers, E = h->cfg.embed_dim;
+  const size_t M = (size_t)n_pair * kTokens;
+  const size_t mpad = (size_t)gemm_rows_padded((int)M);
+  const size_t prow = (size_t)gemm_rows_padded(n_obj * 16);
+  w.subj = (int32_t*)take((size_t)n_pair * 4);
+  w.obj = (int32_t*)take((size_t)n_pair * 4);
+  w.lc = (float*)take((size_t)n_obj * 2 * 2 * kDim * 4);
+  w.pa = (__bf16*)take(prow * 2 * 2048 * 2);
+  w.patch_tab = (float*)take((size_t)n_obj * 16 * 2 * kDim * 4);
+  w.layers.resize(L);
+  for (int l = 0; l < L; ++l) {
+    TrainLayer& t = w.layers[l];
+    t.xin = (float*)take(mpad * kDim * 4);
+    t.a1 = (__bf16*)take(mpad * 2 * kDim * 2);
+    t.qkv = (float*)take(mpad * 3 * kDim * 4);
+    t.ao = (__bf16*)take(mpad * 2 * kDim * 2);
+    t.xmid = (float*)take(mpad * kDim * 4);
+    t.a2 = (__bf16*)take(mpad * 2 * kDim * 2);
+    t.pre = (float*)take(mpad * 2 * kDim * 4);
+    t.hid = (__bf16*)take(mpad * 4 * kDim * 2);
+  }
+  w.xout = (float*)take(mpad * kDim * 4);
+  w.dx = (float*)take(mpad * kDim * 4);
+  w.dmid = (float*)take(mpad * kDim * 4);
+  w.dtmp = (float*)take(mpad * kDim * 4);
+  w.dbig = (float*)take(mpad * 3 * kDim * 4);
+  w.dsplit = (__bf16*)take(mpad * 6 * kDim * 2);
+  w.mp2 = (M + 32 * 64 + 31) / 32 * 32;   // room for any split count up to 64
+  w.at = (__bf16*)take((size_t)gemm_rows_padded(2048) * w.mp2 * 4);
+  w.wt = (__bf16*)take((size_t)2 * kDim * w.mp2 * 4);
+  w.wdg = (__bf16*)take((size_t)3 * kDim * kDim * 4);
+  w.ln_partial = (float*)take(layernorm_backward_partial_floats((int)M) * 4);
+  w.col_partial = (float*)take((size_t)64 * kTokens * kDim * 4);
+  w.dgb = (float*)take(2 * kDim * 4);
+  w.dpatch = (float*)take((size_t)n_obj * 16 * 2 * kDim * 4);
+  w.dlc = (float*)take((size_t)n_obj * 2 * 2 * kDim * 4);
+  w.dpos = (float*)take((size_t)n_obj * kPosDim * 4);
+  w.dpre = (float*)take((size_t)n_obj * kPosDim * 4);
+  w.xhat = (float*)take((size_t)n_obj * 4 * 4);
+  w.bn_out = (float*)take((size_t)n_obj * 4 * 4);
+  w.dbn_out = (float*)take((size_t)n_obj * 4 * 4);
+  w.emb = (float*)take((size_t)n_obj * E * 4);
+  w.demb = (float*)take((size_t)n_obj * E * 4);
+  w.dloc_wt = (float*)take((size_t)kPosDim * 2 * kDim * 4);
+  w.dcls_wt = (float*)take((size_t)E * 2 * kDim * 4);
+  w.dwcat_t = (float*)take((size_t)2048 * 2 * kDim * 4);
+  w.total = off;
+  return w;
+}
+
+// dW[N, K] = dY[M, N]^T . X[M, K] with X in split rows (x_split) or fp32 (x_f32); K % 192 == 0
+int run_wgrad(veto_handle_t h, hipStream_t s, const TrainWs& w, const float* dy, long ld_dy, int M, int N, const __bf16* x_split,
+              const float* x_f32, long ld_x, int K, float* dw) {
+  const int out_tiles = ((N + 255) / 256) * (K / 192);
+  int ks = 2 * 256 / out_tiles;
+  const int max_ks = (M + 32 * 64 - 1) / (32 * 64);
+  if (ks > max_ks) ks = max_ks;
+  if (ks > 64) ks = 64;
+  if (ks < 1) ks = 1;
+  const size_t mp = ((size_t)M + 32 * (size_t)ks - 1) / (32 * (size_t)ks) * 32 * (size_t)ks;
+  if (mp > w.mp2) return fail(VETO_ERR_WORKSPACE, "weight-gradient operand buffer too small");
+  HIP_TRY(launch_transpose_split(dy, ld_dy, M, N, w.at, (int)mp, s));
+  if (x_split) HIP_TRY(launch_transpose_from_split(x_split, ld_x, M, K, w.wt, (int)mp, s));
+  else HIP_TRY(launch_transpose_split(x_f32, ld_x, M, K, w.wt, (int)mp, s));
+  HIP_TRY(hipMemsetAsync(dw, 0, (size_t)N * K * 4, s));
+  GemmArgs g{};
+  g.a = w.at; g.w = w.wt; g.c = dw;
+  g.M = N; g.N = K; g.K = (int)mp; g.ldc = K; g.k_splits = ks;
+  ProfScope ps(h, s, "bwd_wgrad", 2.0 * M * (double)N * K, 0);
+  HIP_TRY(launch_gemm_split(g, EPI_ATOMIC, 0, s));
+  return VETO_OK;
+}
+
+// dX[M, K] = dY[M, N] . W[N, K]: dY is split into w.dsplit, W^T into w.wdg, then the forward GEMM kernel
+int run_dgrad(veto_handle_t h, hipStream_t s, const TrainWs& w, const float* dy, int M, int N, const float* weight, int K, float* dx) {
+  HIP_TRY(launch_split_rows(dy, w.dsplit, (size_t)M, N, s));
+  HIP_TRY(launch_transpose_split(weight, K, N, K, w.wdg, N, s));     // W [N, K] -> W^T split rows [K, 2N]
+  GemmArgs g{};
+  g.a = w.dsplit; g.w = w.wdg; g.c = dx;
+  g.M = M; g.N = K; g.K = N; g.ldc = K;
+  ProfScope ps(h, s, "bwd_dgrad", 2.0 * M * (double)N * K, 0);
+  HIP_TRY(launch_gemm_split(g, EPI_F32, 0, s));
+  return VETO_OK;
+}
+
+int check_train_inputs(veto_handle_t h, const veto_inputs_t* in, void* workspace, size_t workspace_bytes) {
+  if (!h || !in || !workspace) return fail(VETO_ERR_INVALID, "null argument");
+  if (in->struct_size != (int32_t)sizeof(veto_inputs_t)) return fail(VETO_ERR_INVALID, "veto_inputs_t size mismatch");
+  if (in->n_obj <= 0 || in->n_pair <= 0 || in->n_img <= 0) return fail(VETO_ERR_INVALID, "empty batch");
+  if (!in->roi_rgb || !in->roi_depth || !in->boxes || !in->rel_pairs || !in->img_obj_offset || !in->img_pair_offset)
+    return fail(VETO_ERR_INVALID, "missing input pointer");
+  if (!in->obj_labels || in->obj_logits) return fail(VETO_ERR_INVALID, "the training path takes hard object labels (predcls / MEET)");
+  if (!in->bn_batch_stats) return fail(VETO_ERR_INVALID, "the training path needs bn_batch_stats (training-mode BatchNorm)");
+  if (h->cfg.precision != VETO_PRECISE) return fail(VETO_ERR_INVALID, "the training path runs in precise mode only");
+  if (workspace_bytes < veto_train_workspace_bytes(h, in->n_obj, in->n_pair)) return fail(VETO_ERR_WORKSPACE, "training workspace too small");
+  return VETO_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t veto_train_workspace_bytes(veto_handle_t h, int32_t n_obj, int32_t n_pair) {
+  if (!h || n_obj <= 0 || n_pair <= 0) return 0;
+  return carve_train(nullptr, h, n_obj, n_pair).total;
+}
+
+size_t veto_grad_floats(veto_handle_t h) {
+  if (!h || h->params.empty()) return 0;
+  const Param& q = h->params.back();
+  return q.offset + align_up(q.numel, 64);
+}
+
+int veto_weight_offset(veto_handle_t h, int index, size_t* offset_floats) {
+  if (!h || index < 0 || index >= (int)h->params.size() || !offset_floats) return fail(VETO_ERR_INVALID, "bad weight index");
+  *offset_floats = h->params[index].offset;
+  return VETO_OK;
+}
+
+int veto_forward_train(veto_handle_t h, void* stream, const veto_inputs_t* in, void* workspace, size_t workspace_bytes,
+                       float* out_logits) {
+  int rc = check_train_inputs(h, in, workspace, workspace_bytes);
+  if (rc) return rc;
+  if (!out_logits) return fail(VETO_ERR_INVALID, "null out_logits");
+  hipStream_t s = (hipStream_t)stream;
+  if (h->dirty) { rc = finalize_weights(h, s); if (rc) return rc; }
+  const int n_obj = in->n_obj, n_pair = in->n_pair, L = h->cfg.layers, H = h->cfg.heads, n_out = h->cfg.num_out;
+  const int M = n_pair * kTokens;
+  TrainWs ws = carve_train((char*)workspace, h, n_obj, n_pair);
+  const std::string T = kT;
+  HIP_TRY(launch_pair_indices(in->rel_pairs, in->img_obj_offset, in->img_pair_offset, in->n_img, n_pair, ws.subj, ws.obj, nullptr,
+                              nullptr, s));
+  {
+    ObjPrepArgs a{};
+    a.boxes = in->boxes; a.box_mode = in->box_mode; a.labels = in->obj_labels; a.obj_logits = nullptr;
+    a.embed = h->p("obj_embed.weight"); a.num_obj_cls = h->cfg.num_obj_cls; a.embed_dim = h->cfg.embed_dim;
+    a.bn_w = h->p("pos_embed.0.weight"); a.bn_b = h->p("pos_embed.0.bias");
+    HIP_TRY(launch_bn_batch_stats(in->boxes, in->box_mode, n_obj, in->bn_batch_stats, s));
+    a.bn_mean = in->bn_batch_stats; a.bn_var = in->bn_batch_stats + 4;
+    a.pos_w = h->p("pos_embed.1.weight"); a.pos_b = h->p("pos_embed.1.bias");
+    a.loc_wt = h->loc_wt; a.loc_b = h->p("location_projection.0.bias");
+    a.cls_wt = h->cls_wt; a.cls_b = h->p("class_projection.0.bias");
+    a.lc = ws.lc; a.pos_out = nullptr; a.n_obj = n_obj;
+    HIP_TRY(launch_obj_prep(a, s));
+  }
+  HIP_TRY(launch_patchify(in->roi_depth, in->roi_rgb, ws.pa, n_obj, s));
+  rc = run_gemm(h, s, "gemm_patch", ws.pa, h->patch_w, h->patch_bias, nullptr, 0, ws.patch_tab, nullptr, 2 * kDim, n_obj * 16,
+                2 * kDim, 2048, EPI_F32);
+  if (rc) return rc;
+  {
+    AssembleArgs a{};
+    a.patch_tab = ws.patch_tab; a.lc = ws.lc; a.cls_token = h->p(T + "cls_token");
+    a.pos_embedding = h->p(T + "pos_embedding");
+    a.ln_w = h->layers[0].ln1_w; a.ln_b = h->layers[0].ln1_b;
+    a.subj = ws.subj; a.obj = ws.obj; a.x = ws.layers[0].xin; a.a = ws.layers[0].a1; a.n_pair = n_pair;
+    HIP_TRY(launch_assemble(a, s));
+  }
+  for (int l = 0; l < L; ++l) {
+    const LayerW& w = h->layers[l];
+    TrainLayer& t = ws.layers[l];
+    float* xnext = l + 1 < L ? ws.layers[l + 1].xin : ws.xout;
+    rc = run_gemm(h, s, "gemm_qkv", t.a1, w.qkv, nullptr, nullptr, 0, t.qkv, nullptr, 3 * kDim, M, 3 * kDim, kDim, EPI_F32);
+    if (rc) return rc;
+    {
+      AttnArgs a{};
+      a.qkv = t.qkv; a.n_pair = n_pair; a.heads = H; a.cls_only = 0; a.o = t.ao;
+      HIP_TRY(launch_attention(a, s));
+    }
+    rc = run_gemm(h, s, "gemm_out", t.ao, w.out, w.out_b, t.xin, kDim, t.xmid, nullptr, kDim, M, kDim, kDim, EPI_RESID);
+    if (rc) return rc;
+    HIP_TRY(launch_layernorm(t.xmid, kDim, w.ln2_w, w.ln2_b, t.a2, M, s));
+    rc = run_gemm(h, s, "gemm_fc1", t.a2, w.fc1, w.fc1_b, nullptr, 0, t.pre, nullptr, 2 * kDim, M, 2 * kDim, kDim, EPI_F32);
+    if (rc) return rc;
+    HIP_TRY(launch_gelu_split(t.pre, t.hid, (size_t)M, 2 * kDim, s));
+    rc = run_gemm(h, s, "gemm_fc2", t.hid, w.fc2, w.fc2_b, t.xmid, kDim, xnext, nullptr, kDim, M, kDim, 2 * kDim, EPI_RESID);
+    if (rc) return rc;
+    if (l + 1 < L) HIP_TRY(launch_layernorm(xnext, kDim, h->layers[l + 1].ln1_w, h->layers[l + 1].ln1_b, ws.layers[l + 1].a1, M, s));
+  }
+  HIP_TRY(launch_head(ws.xout, h->head_wt, h->p("rel_out.bias"), out_logits, n_pair, n_out, s, (long)kTokens * kDim));
+  return VETO_OK;
+}
+
+int veto_backward(veto_handle_t h, void* stream, const veto_inputs_t* in, void* workspace, size_t workspace_bytes,
+                  const float* dlogits, float* grads) {
+  int rc = check_train_inputs(h, in, workspace, workspace_bytes);
+  if (rc) return rc;
+  if (!dlogits || !grads) return fail(VETO_ERR_INVALID, "null gradient pointer");
+  hipStream_t s = (hipStream_t)stream;
+  const int n_obj = in->n_obj, n_pair = in->n_pair, L = h->cfg.layers, H = h->cfg.heads, n_out = h->cfg.num_out, E = h->cfg.embed_dim;
+  const int M = n_pair * kTokens;
+  TrainWs ws = carve_train((char*)workspace, h, n_obj, n_pair);
+  const std::string T = kT;
+  auto G = [&](const std::string& name) { return grads + h->params[h->index.at(name)].offset; };
+  HIP_TRY(hipMemsetAsync(grads, 0, veto_grad_floats(h) * 4, s));
+
+  // ---- classifier head ----------------------------------------------------------------------------------------
+  HIP_TRY(hipMemsetAsync(ws.dx, 0, (size_t)M * kDim * 4, s));
+  HIP_TRY(launch_head_backward(dlogits, h->p("rel_out.weight"), ws.xout, ws.dx, G("rel_out.weight"), G("rel_out.bias"), n_pair, n_out, s));
+
+  // ---- transformer layers, last to first -------------------------------------------------------------------------
+  for (int l = L - 1; l >= 0; --l) {
+    const LayerW& w = h->layers[l];
+    TrainLayer& t = ws.layers[l];
+    // x_out = x_mid + gelu(LN2(x_mid) W1^T + b1) W2^T + b2
+    HIP_TRY(launch_column_sums(ws.dx, kDim, M, kDim, G(lname(l, "1.fn.net.3.bias")), ws.col_partial, 64, s));
+    rc = run_wgrad(h, s, ws, ws.dx, kDim, M, kDim, t.hid, nullptr, 4 * kDim, 2 * kDim, G(lname(l, "1.fn.net.3.weight")));
+    if (rc) return rc;
+    rc = run_dgrad(h, s, ws, ws.dx, M, kDim, h->p(lname(l, "1.fn.net.3.weight")), 2 * kDim, ws.dbig);
+    if (rc) return rc;
+    HIP_TRY(launch_gelu_backward(t.pre, ws.dbig, ws.dbig, (size_t)M * 2 * kDim, s));
+    HIP_TRY(launch_column_sums(ws.dbig, 2 * kDim, M, 2 * kDim, G(lname(l, "1.fn.net.0.bias")), ws.col_partial, 64, s));
+    rc = run_wgrad(h, s, ws, ws.dbig, 2 * kDim, M, 2 * kDim, t.a2, nullptr, 2 * kDim, kDim, G(lname(l, "1.fn.net.0.weight")));
+    if (rc) return rc;
+    rc = run_dgrad(h, s, ws, ws.dbig, M, 2 * kDim, h->p(lname(l, "1.fn.net.0.weight")), kDim, ws.dtmp);
+    if (rc) return rc;
+    HIP_TRY(launch_layernorm_backward(t.xmid, ws.dtmp, w.ln2_w, ws.dx, ws.dmid, ws.dgb, ws.ln_partial, M, s));
+    HIP_TRY(hipMemcpyAsync(G(lname(l, "1.norm.weight")), ws.dgb, kDim * 4, hipMemcpyDeviceToDevice, s));
+    HIP_TRY(hipMemcpyAsync(G(lname(l, "1.norm.bias")), ws.dgb + kDim, kDim * 4, hipMemcpyDeviceToDevice, s));
+    // x_mid = x_in + attention(LN1(x_in) Wqkv^T) Wo^T + bo
+    HIP_TRY(launch_column_sums(ws.dmid, kDim, M, kDim, G(lname(l, "0.fn.to_out.0.bias")), ws.col_partial, 64, s));
+    rc = run_wgrad(h, s, ws, ws.dmid, kDim, M, kDim, t.ao, nullptr, 2 * kDim, kDim, G(lname(l, "0.fn.to_out.0.weight")));
+    if (rc) return rc;
+    rc = run_dgrad(h, s, ws, ws.dmid, M, kDim, h->p(lname(l, "0.fn.to_out.0.weight")), kDim, ws.dtmp);
+    if (rc) return rc;
+    HIP_TRY(launch_attention_backward(t.qkv, ws.dtmp, ws.dbig, n_pair, H, s));
+    rc = run_wgrad(h, s, ws, ws.dbig, 3 * kDim, M, 3 * kDim, t.a1, nullptr, 2 * kDim, kDim, G(lname(l, "0.fn.to_qkv.weight")));
+    if (rc) return rc;
+    rc = run_dgrad(h, s, ws, ws.dbig, M, 3 * kDim, h->p(lname(l, "0.fn.to_qkv.weight")), kDim, ws.dtmp);
+    if (rc) return rc;
+    HIP_TRY(launch_layernorm_backward(t.xin, ws.dtmp, w.ln1_w, ws.dmid, ws.dx, ws.dgb, ws.ln_partial, M, s));
+    HIP_TRY(hipMemcpyAsync(G(lname(l, "0.norm.weight")), ws.dgb, kDim * 4, hipMemcpyDeviceToDevice, s));
+    HIP_TRY(hipMemcpyAsync(G(lname(l, "0.norm.bias")), ws.dgb + kDim, kDim * 4, hipMemcpyDeviceToDevice, s));
+  }
+
+  // ---- token assembly: cls_token, pos_embedding, per-object tables -----------------------------------------------
+  // x0[p, t] = token + pos_embedding (ONE 576-vector broadcast over all tokens, model_veto.py:43,62): its gradient is
+  // the sum over every token row; the cls_token's is the sum over row 0 of every pair
+  HIP_TRY(launch_column_sums(ws.dx, kDim, M, kDim, G(T + "pos_embedding"), ws.col_partial, 64, s));
+  HIP_TRY(launch_column_sums(ws.dx, (long)kTokens * kDim, n_pair, kDim, G(T + "cls_token"), ws.col_partial, 64, s));
+  HIP_TRY(hipMemsetAsync(ws.dpatch, 0, (size_t)n_obj * 16 * 2 * kDim * 4, s));
+  HIP_TRY(hipMemsetAsync(ws.dlc, 0, (size_t)n_obj * 2 * 2 * kDim * 4, s));
+  HIP_TRY(launch_assemble_backward(ws.dx, ws.subj, ws.obj, ws.lc, ws.dpatch, ws.dlc, n_pair, s));
+
+  // ---- patch projection: patch_tab = PA . Wcat^T + bias_cat (bias only on the subject half) ------------------------
+  {
+    const std::string pe = T + "patch_embed.";
+    const int R = n_obj * 16;
+    // dWcat^T [2048, 1152] = PA^T . dpatch: "dy" = PA (split rows), "x" = dpatch (fp32) in run_wgrad's roles swapped,
+    // so that the output width (1152) is a multiple of 192
+    {
+      const int N = 2048, K = 2 * kDim;
+      const int out_tiles = ((N + 255) / 256) * (K / 192);
+      int ks = 2 * 256 / out_tiles;
+      const int max_ks = (R + 32 * 8 - 1) / (32 * 8);
+      if (ks > max_ks) ks = max_ks;
+      if (ks < 1) ks = 1;
+      const size_t mp = ((size_t)R + 32 * (size_t)ks - 1) / (32 * (size_t)ks) * 32 * (size_t)ks;
+      if (mp > ws.mp2) return fail(VETO_ERR_WORKSPACE, "weight-gradient operand buffer too small");
+      HIP_TRY(launch_transpose_from_split(ws.pa, 2 * 2048, R, N, ws.at, (int)mp, s));
+      HIP_TRY(launch_transpose_split(ws.dpatch, K, R, K, ws.wt, (int)mp, s));
+      HIP_TRY(hipMemsetAsync(ws.dwcat_t, 0, (size_t)N * K * 4, s));
+      GemmArgs g{};
+      g.a = ws.at; g.w = ws.wt; g.c = ws.dwcat_t;
+      g.M = N; g.N = K; g.K = (int)mp; g.ldc = K; g.k_splits = ks;
+      HIP_TRY(launch_gemm_split(g, EPI_ATOMIC, 0, s));
+    }
+    HIP_TRY(launch_patch_weight_grad(ws.dwcat_t, G(pe + "proj_d.weight"), G(pe + "proj_v.weight"), s));
+    // biases: column sums of the subject half of dpatch: columns 0..511 -> proj_d.bias, 512..575 -> proj_v.bias
+    HIP_TRY(launch_column_sums(ws.dpatch, 2 * kDim, R, kDim, ws.dgb, ws.col_partial, 64, s));
+    HIP_TRY(hipMemcpyAsync(G(pe + "proj_d.bias"), ws.dgb, 512 * 4, hipMemcpyDeviceToDevice, s));
+    HIP_TRY(hipMemcpyAsync(G(pe + "proj_v.bias"), ws.dgb + 512, 64 * 4, hipMemcpyDeviceToDevice, s));
+  }
+
+  // ---- location / class projections and what feeds them -----------------------------------------------------------
+  {
+    const long ldlc = 2 * 2 * kDim;   // dlc row n = [location 1152 | class 1152]
+    // biases sit on the subject half
+    HIP_TRY(launch_column_sums(ws.dlc, ldlc, n_obj, kDim, G("location_projection.0.bias"), ws.col_partial, 64, s));
+    HIP_TRY(launch_column_sums(ws.dlc + 2 * kDim, ldlc, n_obj, kDim, G("class_projection.0.bias"), ws.col_partial, 64, s));
+    // position branch: recompute pos (post-ReLU) through the masked gradient path
+    //   dpos = dlc_loc . loc_wt^T ; obj_pos_backward -> dpre (ReLU'), BatchNorm affine gradients
+    HIP_TRY(launch_sgemm_nt(ws.dlc, ldlc, h->loc_wt, 2 * kDim, ws.dpos, kPosDim, n_obj, kPosDim, 2 * kDim, s));
+    HIP_TRY(launch_obj_pos_backward(in->boxes, in->box_mode, in->bn_batch_stats, h->p("pos_embed.0.weight"), h->p("pos_embed.0.bias"),
+                                    h->p("pos_embed.1.weight"), h->p("pos_embed.1.bias"), ws.dpos, ws.dpre, ws.xhat, ws.bn_out, ws.dbn_out,
+                                    G("pos_embed.0.weight"), G("pos_embed.0.bias"), n_obj, s));
+    // pos_embed.1: Linear(4, 128): dW[k, c] = sum_n dpre[n, k] bn_out[n, c]; db = column sums of dpre
+    HIP_TRY(launch_sgemm_tn(ws.dpre, kPosDim, ws.bn_out, 4, G("pos_embed.1.weight"), 4, n_obj, kPosDim, 4, s));
+    HIP_TRY(launch_column_sums(ws.dpre, kPosDim, n_obj, kPosDim, G("pos_embed.1.bias"), ws.col_partial, 64, s));
+    // location_projection weight: d loc_wt[k, j] = sum_n pos[n, k] dlc_loc[n, j], pos = relu(pre): recompute pos = the
+    // forward's value; it equals (dpre != 0 ? ... ) no -- recompute it from bn_out
+    // pos[n, k] = relu(pos_b[k] + sum_c pos_w[k, c] bn_out[n, c]): one small product + ReLU, done by reusing dpos as storage
+    HIP_TRY(launch_sgemm_nt(ws.bn_out, 4, h->p("pos_embed.1.weight"), 4, ws.dpos, kPosDim, n_obj, kPosDim, 4, s));
+    HIP_TRY(launch_bias_relu(ws.dpos, h->p("pos_embed.1.bias"), n_obj, kPosDim, s));
+    HIP_TRY(launch_sgemm_tn(ws.dpos, kPosDim, ws.dlc, ldlc, ws.dloc_wt, 2 * kDim, n_obj, kPosDim, 2 * kDim, s));
+    HIP_TRY(launch_untranspose_pair_proj(ws.dloc_wt, G("location_projection.0.weight"), kPosDim, s));
+    // class branch: emb = E[label]; d cls_wt[k, j] = sum_n emb[n, k] dlc_cls[n, j]; demb = dlc_cls . cls_wt^T
+    HIP_TRY(launch_gather_rows(h->p("obj_embed.weight"), in->obj_labels, E, ws.emb, n_obj, s));
+    HIP_TRY(launch_sgemm_tn(ws.emb, E, ws.dlc + 2 * kDim, ldlc, ws.dcls_wt, 2 * kDim, n_obj, E, 2 * kDim, s));
+    HIP_TRY(launch_untranspose_pair_proj(ws.dcls_wt, G("class_projection.0.weight"), E, s));
+    HIP_TRY(launch_sgemm_nt(ws.dlc + 2 * kDim, ldlc, h->cls_wt, 2 * kDim, ws.demb, E, n_obj, E, 2 * kDim, s));
+    HIP_TRY(launch_scatter_rows(ws.demb, in->obj_labels, E, G("obj_embed.weight"), n_obj, s));
+  }
+  return VETO_OK;
+}
+
 int veto_enumerate_pairs(void* stream, int32_t n, int64_t* out) {
   if (n < 0 || !out) return fail(VETO_ERR_INVALID, "bad argument");
   HIP_TRY(launch_enumerate_pairs(n, out, (hipStream_t)stream));

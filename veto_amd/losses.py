@@ -48,6 +48,30 @@ def relation_ce_loss(logits, labels, weight=None, rows=None, want_grad=False):
     return loss, grad
 
 
+class _CELossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, labels, weight, rows):
+        loss, grad = relation_ce_loss(logits, labels, weight=weight, rows=rows, want_grad=True)
+        ctx.save_for_backward(grad)
+        ctx.rows, ctx.shape = rows, tuple(logits.shape)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        grad = grad * g
+        if ctx.rows is not None:     # gradient rows back to their places (tiny: [n, <= 21] per MEET group)
+            full = torch.zeros(ctx.shape, dtype=grad.dtype, device=grad.device)
+            full.index_add_(0, ctx.rows.to(grad.device), grad)
+            grad = full
+        return grad, None, None, None
+
+
+def ce_loss(logits, labels, weight=None, rows=None):
+    """relation_ce_loss as a differentiable scalar: the value and d loss / d logits both come from veto_ce_loss."""
+    return _CELossFn.apply(logits, labels, weight, rows)
+
+
 def _numpy_generator_from_python_random():
     st = random.getstate()
     bg = np.random.MT19937()

@@ -20,6 +20,7 @@ EXPORTS = [
     "veto_enumerate_pairs", "veto_profile_enable", "veto_profile_collect", "veto_profile_entry",
     "veto_profile_reset", "veto_debug_gemm", "veto_debug_gemm_workspace_bytes",
     "veto_postprocess", "veto_postprocess_workspace_bytes", "veto_postprocess_meet", "veto_postprocess_vote",
+    "veto_train_workspace_bytes", "veto_grad_floats", "veto_weight_offset", "veto_forward_train", "veto_backward",
     "veto_debug_attention_backward", "veto_debug_layernorm_backward", "veto_debug_layernorm_backward_workspace_bytes",
     "veto_debug_gelu_backward", "veto_debug_column_sums",
     "veto_debug_wgrad", "veto_debug_wgrad_workspace_bytes", "veto_ce_loss", "veto_ce_loss_workspace_bytes", "veto_meet_sample",
@@ -139,6 +140,13 @@ def load_library():
     lib.veto_postprocess.argtypes = [c_void_p, POINTER(VetoPostArgs), c_void_p, c_size_t]
     lib.veto_postprocess_meet.argtypes = [c_void_p, POINTER(VetoPostMeetArgs), c_void_p, c_size_t]
     lib.veto_postprocess_vote.argtypes = [c_void_p, POINTER(VetoPostVoteArgs), c_void_p, c_size_t]
+    lib.veto_train_workspace_bytes.argtypes = [c_void_p, c_int32, c_int32]
+    lib.veto_train_workspace_bytes.restype = c_size_t
+    lib.veto_grad_floats.argtypes = [c_void_p]
+    lib.veto_grad_floats.restype = c_size_t
+    lib.veto_weight_offset.argtypes = [c_void_p, c_int, POINTER(c_size_t)]
+    lib.veto_forward_train.argtypes = [c_void_p, c_void_p, POINTER(VetoInputs), c_void_p, c_size_t, c_void_p]
+    lib.veto_backward.argtypes = [c_void_p, c_void_p, POINTER(VetoInputs), c_void_p, c_size_t, c_void_p, c_void_p]
     lib.veto_debug_attention_backward.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32]
     lib.veto_debug_layernorm_backward_workspace_bytes.argtypes = [c_int32]
     lib.veto_debug_layernorm_backward_workspace_bytes.restype = c_size_t
@@ -211,6 +219,18 @@ class Engine:
     def forward(self, stream, inputs, workspace_ptr, workspace_bytes, out_ptr, dbg=None):
         check(self.lib.veto_forward(self.handle, c_void_p(stream), byref(inputs), c_void_p(workspace_ptr),
                                     workspace_bytes, c_void_p(out_ptr), byref(dbg) if dbg is not None else None))
+
+    def weight_offsets(self):
+        """{weight name: (offset, numel)} in floats into the flat gradient buffer of veto_backward."""
+        if getattr(self, "_offsets", None) is None:
+            out = {}
+            for i in range(check(self.lib.veto_num_weights(self.handle))):
+                name, numel, off = c_char_p(), c_size_t(), c_size_t()
+                check(self.lib.veto_weight_info(self.handle, i, byref(name), byref(numel)))
+                check(self.lib.veto_weight_offset(self.handle, i, byref(off)))
+                out[name.value.decode()] = (off.value, numel.value)
+            self._offsets = out
+        return self._offsets
 
     def profile_enable(self, on):
         check(self.lib.veto_profile_enable(self.handle, 1 if on else 0))

@@ -241,15 +241,12 @@ class _NativeForward:
     def _offsets(self, n_objs, n_pairs, device):
         return cached_offsets(n_objs, n_pairs, device)
 
-    def _check_train_forward(self, config_flag):
-        """Training mode runs only as a FORWARD + LOSS pass (no backward exists yet), only when asked for
-        (VETO_AMD.TRAIN_FORWARD_ONLY) and only without dropout (dropout masks are not built)."""
-        if not config_flag:
-            raise NotImplementedError(_TRAIN_MSG)
+    def _check_train(self):
+        """Training mode runs without dropout only (dropout masks are not built)."""
         live = [n for n, m in self._trunk.named_modules() if isinstance(m, nn.Dropout) and m.p > 0]
         if live:
-            raise NotImplementedError("veto_amd: the training-mode forward exists without dropout only; these modules have "
-                                      "p > 0: %s" % ", ".join(live[:6]))
+            raise NotImplementedError("veto_amd: training mode exists without dropout only; these modules have p > 0: %s (set "
+                                      "them to 0, or call .eval() for inference)" % ", ".join(live[:6]))
 
     def _run_native_train(self, proposals, rel_pair_idxs, roi_features, roi_depth_features, labels, logits):
         """Forward in training mode: BatchNorm1d(4) of pos_embed on batch statistics (and its running statistics
@@ -265,8 +262,9 @@ class _NativeForward:
             bn.num_batches_tracked += 1
         return out
 
-    def _run_native(self, proposals, rel_pair_idxs, roi_features, roi_depth_features, labels, logits,
-                    debug=False, bn_batch_stats=None):
+    def _prepare_inputs(self, proposals, rel_pair_idxs, roi_features, roi_depth_features, labels, logits, bn_batch_stats=None):
+        """Validates the call and flattens it into a veto_inputs_t.  Returns (inp, keep, n_objs, n_pairs, device, eng);
+        `keep` are the tensors the struct points into."""
         device = roi_features.device
         eng = self._ensure_engine(device)
         n_objs = [len(p) for p in proposals]
@@ -286,12 +284,6 @@ class _NativeForward:
         obj_off, pair_off = self._offsets(tuple(n_objs), tuple(n_pairs), device)
         lab = labels.to(device=device, dtype=torch.int64).contiguous() if labels is not None else None
         lg = logits.detach().to(**f32).contiguous() if logits is not None else None
-
-        need = eng.workspace_bytes(n_obj, n_pair)
-        if self._workspace is None or self._workspace.numel() < need or self._workspace.device != device:
-            self._workspace = None
-            self._workspace = torch.empty(need, dtype=torch.uint8, device=device)
-        out = torch.empty((n_pair, self._num_out), **f32)
         inp = native.VetoInputs()
         inp.struct_size = ctypes.sizeof(native.VetoInputs)
         inp.n_obj, inp.n_pair, inp.n_img = n_obj, n_pair, len(proposals)
@@ -302,6 +294,20 @@ class _NativeForward:
         inp.rel_pairs = pairs.data_ptr()
         inp.img_obj_offset, inp.img_pair_offset = obj_off.data_ptr(), pair_off.data_ptr()
         inp.bn_batch_stats = bn_batch_stats.data_ptr() if bn_batch_stats is not None else None
+        keep = [t for t in (rgb, dep, boxes, pairs, lab, lg, obj_off, pair_off, bn_batch_stats) if t is not None]
+        return inp, keep, n_objs, n_pairs, device, eng
+
+    def _run_native(self, proposals, rel_pair_idxs, roi_features, roi_depth_features, labels, logits,
+                    debug=False, bn_batch_stats=None):
+        inp, keep, n_objs, n_pairs, device, eng = self._prepare_inputs(proposals, rel_pair_idxs, roi_features, roi_depth_features,
+                                                                       labels, logits, bn_batch_stats)
+        n_obj, n_pair = inp.n_obj, inp.n_pair
+        f32 = dict(device=device, dtype=torch.float32)
+        need = eng.workspace_bytes(n_obj, n_pair)
+        if self._workspace is None or self._workspace.numel() < need or self._workspace.device != device:
+            self._workspace = None
+            self._workspace = torch.empty(need, dtype=torch.uint8, device=device)
+        out = torch.empty((n_pair, self._num_out), **f32)
         dbg, extras = None, None
         if debug:
             extras = {"subj_inds": torch.empty(n_pair, dtype=torch.int64, device=device),
@@ -315,11 +321,81 @@ class _NativeForward:
         stream = torch.cuda.current_stream(device).cuda_stream
         eng.forward(stream, inp, self._workspace.data_ptr(), self._workspace.numel(), out.data_ptr(), dbg)
         # the inputs above are referenced by enqueued kernels: keep them alive on this stream
-        for t in (rgb, dep, boxes, pairs, lab, lg):
-            if t is not None:
-                t.record_stream(torch.cuda.current_stream(device))
+        for t in keep:
+            t.record_stream(torch.cuda.current_stream(device))
         self.last_debug = extras
         return out, n_objs, n_pairs
+
+    # ---- training path with gradients (veto_forward_train / veto_backward) ---------------------------------------
+    def _train_param_spec(self):
+        """[(Parameter, engine weight name, first row, row count or None)] for every tensor the backward fills."""
+        trunk = dict(self._trunk.named_parameters())
+        spec = []
+        for name, prm in trunk.items():
+            if name.startswith(("obj_embed.", "class_projection.0.", "pos_embed.", "location_projection.0.", "fusion_transformer.")):
+                spec.append((prm, name, 0, None))
+        row = 0
+        for head in self._head_modules:
+            spec.append((head.weight, "rel_out.weight", row, head.out_features))
+            spec.append((head.bias, "rel_out.bias", row, head.out_features))
+            row += head.out_features
+        return spec
+
+    def _run_native_train_grad(self, proposals, rel_pair_idxs, roi_features, roi_depth_features, labels):
+        """Training-mode forward whose result carries an autograd graph: logits [sum P, num_out]."""
+        spec = self._train_param_spec()
+        return _TrainFn.apply(self, (proposals, rel_pair_idxs, roi_features, roi_depth_features, labels), *[s[0] for s in spec])
+
+
+class _TrainFn(torch.autograd.Function):
+    """logits = VETO trunk + heads in training mode; backward fills the gradients of every parameter through
+    veto_backward.  The parameters are inputs only so that autograd routes their gradients."""
+
+    @staticmethod
+    def forward(ctx, owner, call, *params):
+        proposals, rel_pair_idxs, roi_features, roi_depth_features, labels = call
+        device = roi_features.device
+        stats = torch.empty(12, dtype=torch.float32, device=device)
+        inp, keep, n_objs, n_pairs, device, eng = owner._prepare_inputs(proposals, rel_pair_idxs, roi_features, roi_depth_features,
+                                                                        labels, None, stats)
+        lib = native.load_library()
+        need = lib.veto_train_workspace_bytes(eng.handle, inp.n_obj, inp.n_pair)
+        ws = torch.empty(need, dtype=torch.uint8, device=device)
+        out = torch.empty((inp.n_pair, owner._num_out), dtype=torch.float32, device=device)
+        stream = torch.cuda.current_stream(device)
+        native.check(lib.veto_forward_train(eng.handle, ctypes.c_void_p(stream.cuda_stream), ctypes.byref(inp), ctypes.c_void_p(ws.data_ptr()),
+                                            ws.numel(), ctypes.c_void_p(out.data_ptr())))
+        bn = owner._trunk.pos_embed[0]
+        with torch.no_grad():    # nn.BatchNorm1d(momentum=0.001) running statistics
+            m = bn.momentum
+            bn.running_mean.mul_(1 - m).add_(stats[0:4].to(bn.running_mean.device), alpha=m)
+            bn.running_var.mul_(1 - m).add_(stats[8:12].to(bn.running_var.device), alpha=m)
+            bn.num_batches_tracked += 1
+        ctx.owner, ctx.inp, ctx.keep, ctx.ws, ctx.eng = owner, inp, keep, ws, eng
+        ctx.spec = owner._train_param_spec()
+        return out
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        owner, eng, lib = ctx.owner, ctx.eng, native.load_library()
+        device = dlogits.device
+        dlogits = dlogits.detach().to(torch.float32).contiguous()
+        n_floats = lib.veto_grad_floats(eng.handle)
+        flat = torch.empty(n_floats, dtype=torch.float32, device=device)
+        stream = torch.cuda.current_stream(device)
+        native.check(lib.veto_backward(eng.handle, ctypes.c_void_p(stream.cuda_stream), ctypes.byref(ctx.inp), ctypes.c_void_p(ctx.ws.data_ptr()),
+                                       ctx.ws.numel(), ctypes.c_void_p(dlogits.data_ptr()), ctypes.c_void_p(flat.data_ptr())))
+        offsets = eng.weight_offsets()
+        grads = []
+        for prm, name, row0, rows in ctx.spec:
+            off, numel = offsets[name]
+            if rows is None:
+                g = flat[off:off + numel]
+            else:
+                per_row = prm.numel() // rows
+                g = flat[off + row0 * per_row: off + (row0 + rows) * per_row]
+            grads.append(g.view_as(prm).to(prm.device))
+        return (None, None) + tuple(grads)
 
 
 def _offset_tensors(n_objs, n_pairs, device):
@@ -339,8 +415,6 @@ def _cat_field(proposals, name):
     return torch.cat([p.get_field(name) for p in proposals], 0)
 
 
-_TRAIN_MSG = ("veto_amd: training forward/backward of the fused HIP path is not built yet "
-              "(SURVEY.md section 8(f) row f3); call .eval() for inference")
 
 
 @ROI_RELATION_PREDICTOR.register("VETOPredictor")
@@ -370,7 +444,7 @@ class VETOPredictor(nn.Module, _NativeForward):
     def forward(self, proposals, rel_pair_idxs, rel_labels, logger, roi_features=None,
                 roi_depth_features=None, rel_binarys=None):
         if self.training:
-            self._check_train_forward(self._train_forward_only)
+            self._check_train()
         if self.mode == "predcls":
             labels = _cat_field(proposals, "labels").long()
             logits = None
@@ -379,15 +453,23 @@ class VETOPredictor(nn.Module, _NativeForward):
             logits = _cat_field(proposals, "predict_logits").detach()
             obj_label_for_dist = _cat_field(proposals, "pred_labels").detach().long()
             labels = None
-        if self.training:   # :4127-4136: losses only; forward-only here (the losses carry no autograd graph)
-            from .losses import relation_ce_loss
-            rel, _, _ = self._run_native_train(proposals, rel_pair_idxs, roi_features, roi_depth_features, labels, logits)
+        if self.training:   # :4127-4136: losses only
+            from .losses import ce_loss, relation_ce_loss
+            target = torch.cat(list(rel_labels), 0)
+            w = self.criterion_loss_rel.weight
             add_losses = {}
+            if self._train_forward_only or self.mode != "predcls":
+                if not self._train_forward_only:
+                    raise NotImplementedError("veto_amd: the backward of the soft object embedding (sgcls / sgdet of VETOPredictor) is not "
+                                              "built; VETO_AMD.TRAIN_FORWARD_ONLY gives the losses without gradients")
+                rel, _, _ = self._run_native_train(proposals, rel_pair_idxs, roi_features, roi_depth_features, labels, logits)
+                add_losses["rel_loss"] = relation_ce_loss(rel, target, weight=w)[0][0]
+            else:
+                rel = self._run_native_train_grad(proposals, rel_pair_idxs, roi_features, roi_depth_features, labels)
+                add_losses["rel_loss"] = ce_loss(rel, target, weight=w)
             if self.mode != "predcls":
                 fg = _cat_field(proposals, "labels").long()
                 add_losses["obj_loss"] = relation_ce_loss(logits.to(rel.device), fg)[0][0]
-            w = self.criterion_loss_rel.weight
-            add_losses["rel_loss"] = relation_ce_loss(rel, torch.cat(list(rel_labels), 0), weight=w)[0][0]
             return None, None, add_losses, None, None, None
         rel, n_objs, n_pairs = self._run_native(proposals, rel_pair_idxs, roi_features, roi_depth_features,
                                                 labels, logits, debug=getattr(self, "debug_outputs", False))
@@ -464,9 +546,9 @@ class VETOPredictor_MEET(nn.Module, _NativeForward):
     def forward(self, proposals, rel_pair_idxs, rel_labels, logger, roi_features=None,
                 roi_depth_features=None, rel_binarys=None):
         if self.training:
-            self._check_train_forward(self._train_forward_only)
+            self._check_train()
             if self.expert_group:
-                raise NotImplementedError("veto_amd: the training-mode forward of the EXPERT_GROUP heads is not built")
+                raise NotImplementedError("veto_amd: training of the EXPERT_GROUP heads is not built")
         if self.mode == "predcls":
             labels = _cat_field(proposals, "labels").long()
             dist_labels = labels
@@ -478,16 +560,21 @@ class VETOPredictor_MEET(nn.Module, _NativeForward):
             # obj_dists[:, 1:].max(1)[1] + 1 over a one-hot (:3776-3784): the label itself, or 1 for label 0
             labels = torch.where(dist_labels > 0, dist_labels, torch.ones_like(dist_labels))
         if self.training:
-            # :3930-3969 expert sampling, :3806-3846 group label remap + per-group CE; forward-only (no autograd graph)
-            from .losses import MeetTrainingSampler, relation_ce_loss
-            rel, _, _ = self._run_native_train(proposals, rel_pair_idxs, roi_features, roi_depth_features, labels, None)
+            # :3930-3969 expert sampling, :3806-3846 group label remap + per-group CE
+            from .losses import MeetTrainingSampler, ce_loss, relation_ce_loss
+            if self._train_forward_only:
+                rel, _, _ = self._run_native_train(proposals, rel_pair_idxs, roi_features, roi_depth_features, labels, None)
+            else:
+                rel = self._run_native_train_grad(proposals, rel_pair_idxs, roi_features, roi_depth_features, labels)
             if self._sampler is None or self._sampler.device != rel.device:
                 self._sampler = MeetTrainingSampler(self._dataset, self.max_group_element_number_list, device=rel.device,
                                                     zero_label_padding_mode=self._zero_label_padding_mode)
             chosen, group_labels = self._sampler.sample(torch.cat(list(rel_labels), 0))
             add_losses, col = {}, 0
             for k, g in enumerate(self.max_group_element_number_list):
-                add_losses["group_%d_CE_loss" % k] = relation_ce_loss(rel[:, col:col + g + 2], group_labels[k], rows=chosen[k])[0][0]
+                sl = rel[:, col:col + g + 2]
+                add_losses["group_%d_CE_loss" % k] = relation_ce_loss(sl, group_labels[k], rows=chosen[k])[0][0] \
+                    if self._train_forward_only else ce_loss(sl, group_labels[k], rows=chosen[k])
                 col += g + 2
             if self.mode != "predcls":   # :3823-3827
                 obj_logits = _cat_field(proposals, "predict_logits").detach()
