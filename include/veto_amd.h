@@ -309,20 +309,30 @@ int veto_meet_sample(void* stream, const int64_t* labels, int32_t n, const uint3
 
 /* ---- training path: forward that keeps the activations + backward --------------
  * The backward of VETOPredictor.forward's computation graph (roi_relation_predictors.py:4074-4133, model_veto.py)
- * w.r.t. every parameter, for hard object labels (predcls, MEET), precise mode, WITHOUT dropout (the caller must have
- * dropout off).  veto_forward_train runs all pairs in one pass, every layer on all 19 tokens, BatchNorm on batch
+ * w.r.t. every parameter, for hard object labels (predcls, MEET), precise mode.  veto_forward_train runs all pairs in one pass, every layer on all 19 tokens, BatchNorm on batch
  * statistics (in->bn_batch_stats is mandatory), and leaves the activations in `workspace`
  * (veto_train_workspace_bytes, ~28 KB per token row and layer); veto_backward takes d loss / d logits
  * [n_pair, num_out] and writes d loss / d parameter for every state-dict tensor into `grads`, a flat float buffer of
  * veto_grad_floats(h) elements in which tensor i starts at veto_weight_offset(h, i) (buffers such as running
  * statistics get zeros).  Both calls must see the same inputs and workspace. */
+/* Dropout of the training path (NULL = none): pos_embed's Dropout(0.1) (roi_relation_predictors.py:4042-4047), the
+ * transformer's pos_drop (EMB_DROPOUT, model_veto.py:44,63) and the Dropout behind every attention out projection
+ * (T_DROPOUT, model_veto.py:80-83).  Masks come from a counter-based hash of (seed, site, element index), recomputed in
+ * the backward: the same opts must be given to both calls.  The masks are this library's own (the reference draws from
+ * torch's generator), i.e. equal in distribution, not bit for bit. */
+typedef struct veto_train_opts {
+  int32_t struct_size;
+  float p_pos, p_emb, p_attn;
+  uint64_t seed;
+} veto_train_opts_t;
+
 size_t veto_train_workspace_bytes(veto_handle_t h, int32_t n_obj, int32_t n_pair);
 size_t veto_grad_floats(veto_handle_t h);
 int veto_weight_offset(veto_handle_t h, int index, size_t* offset_floats);
-int veto_forward_train(veto_handle_t h, void* stream, const veto_inputs_t* in, void* workspace, size_t workspace_bytes,
-                       float* out_logits);
-int veto_backward(veto_handle_t h, void* stream, const veto_inputs_t* in, void* workspace, size_t workspace_bytes,
-                  const float* dlogits, float* grads);
+int veto_forward_train(veto_handle_t h, void* stream, const veto_inputs_t* in, const veto_train_opts_t* opts, void* workspace,
+                       size_t workspace_bytes, float* out_logits);
+int veto_backward(veto_handle_t h, void* stream, const veto_inputs_t* in, const veto_train_opts_t* opts, void* workspace,
+                  size_t workspace_bytes, const float* dlogits, float* grads);
 
 /* ---- test hook: dw[N,K] = dy[M,N]^T . x[M,K], the weight-gradient GEMM (reduction over the M rows) through the
  * production split-bf16 kernel in its split-K / atomic-add form.  k must be a multiple of 192; k_splits 0 = auto. */

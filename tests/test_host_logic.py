@@ -88,8 +88,9 @@ def test_no_cpu_path_and_no_training_path():
     with pytest.raises(RuntimeError, match="HIP device"):
         m(props, pairs, None, None, roi_features=torch.from_numpy(batch["roi_features"]),
           roi_depth_features=torch.from_numpy(batch["roi_depth_features"]))
-    with pytest.raises(NotImplementedError):
-        m.train()(props, pairs, None, None)
+    with pytest.raises(RuntimeError, match="HIP device"):      # training mode has no CPU path either
+        m.train()(props, pairs, [torch.tensor([1, 0])], None, roi_features=torch.from_numpy(batch["roi_features"]),
+                  roi_depth_features=torch.from_numpy(batch["roi_depth_features"]))
 
 
 def test_beta_loss_weights_from_reference_counts():

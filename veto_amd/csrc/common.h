@@ -55,4 +55,14 @@ __device__ __forceinline__ float gelu_erf(float x) {
   return 0.5f * x * (1.0f + copysignf(erf_abs, x));
 }
 
+// Counter-based dropout mask (training path): element `idx` of dropout site `seed` is kept iff the top 24 bits of a
+// splitmix64 hash reach the threshold p * 2^24.  Forward and backward recompute the same mask; nothing is stored.
+__device__ __forceinline__ bool dropout_keep(unsigned long long seed, unsigned long long idx, unsigned thresh) {
+  unsigned long long z = seed + idx * 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  return (unsigned)(z >> 40) >= thresh;
+}
+
 }  // namespace veto

@@ -76,8 +76,10 @@ __device__ __forceinline__ void wg_barrier() {
   asm volatile("" ::: "memory");
 }
 
-template <int NTERMS, int EPI>
+template <int NTERMS, int EPI_T>
 __global__ __launch_bounds__(64 * (NCONS + NLOAD), 3) void gemm_split_ps_kernel(GemmArgs g) {
+  constexpr bool kDrop = EPI_T == EPI_RESID_DROP;          // training-only instantiation: dropout before the residual add
+  constexpr int EPI = kDrop ? (int)EPI_RESID : EPI_T;
   __shared__ __attribute__((aligned(16))) char smem[kLdsBytes];
 
   const int tid = threadIdx.x;
@@ -330,6 +332,11 @@ __global__ __launch_bounds__(64 * (NCONS + NLOAD), 3) void gemm_split_ps_kernel(
         if (row < g.M) {
           const int col = col0 + n * 16;
           f32x4 v = t + bias_v[n];
+          if (kDrop) {   // training: Dropout behind the attention out projection
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              v[e] = dropout_keep(g.drop_seed, (unsigned long long)row * g.N + col + e, g.drop_thresh) ? v[e] * g.drop_scale : 0.f;
+          }
           if (EPI == EPI_RESID) v += res[u & 1][j];
           if (EPI == EPI_GELU_SPLIT) {
             bf16x4 hi, lo;
@@ -371,6 +378,7 @@ hipError_t launch_ps_terms(GemmArgs g, int epi, int nblocks, hipStream_t s) {
     case EPI_RESID: VETO_LAUNCH((gemm_split_ps_kernel<NTERMS, EPI_RESID>), grid, block, 0, s, g); break;
     case EPI_GELU_SPLIT: VETO_LAUNCH((gemm_split_ps_kernel<NTERMS, EPI_GELU_SPLIT>), grid, block, 0, s, g); break;
     case EPI_ATOMIC: VETO_LAUNCH((gemm_split_ps_kernel<NTERMS, EPI_ATOMIC>), grid, block, 0, s, g); break;
+    case EPI_RESID_DROP: VETO_LAUNCH((gemm_split_ps_kernel<NTERMS, EPI_RESID_DROP>), grid, block, 0, s, g); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();

@@ -4,7 +4,7 @@
 
 namespace veto {
 
-enum Epi { EPI_F32 = 0, EPI_RESID = 1, EPI_GELU_SPLIT = 2, EPI_ATOMIC = 3 };
+enum Epi { EPI_F32 = 0, EPI_RESID = 1, EPI_GELU_SPLIT = 2, EPI_ATOMIC = 3, EPI_RESID_DROP = 4 };
 
 // C[M,N] = A[M,K] . W[N,K]^T with A and W in the split-row format (common.h): rows of 2K bf16.
 struct GemmArgs {
@@ -20,6 +20,11 @@ struct GemmArgs {
   long ldc;
   int k_splits;          // EPI_ATOMIC: the reduction K is cut into this many equal ranges (K/32 % k_splits == 0), each a
                          // tile of its own that ADDS into c with fp32 atomics (c zero-initialised); 0/1 = one range
+  // EPI_RESID_DROP (training only): EPI_RESID with dropout on (A.W^T + bias) before the residual is added; element (row, col) uses index
+  // row * N + col of site drop_seed.  drop_thresh = p * 2^24 (0 = off), drop_scale = 1 / (1 - p)
+  unsigned long long drop_seed;
+  unsigned drop_thresh;
+  float drop_scale;
   int tiles_m, tiles_n;  // filled by the launcher
   int stagger;           // persistent kernel: start-phase stagger in units of s_sleep(127) (speed only)
 };
@@ -58,6 +63,10 @@ struct ObjPrepArgs {
   float* lc;                 // out [n_obj, 2, 1152]: (location | class) x (subj(+bias) | obj)
   float* pos_out;            // optional debug [n_obj,128]
   int n_obj;
+  // training only: Dropout(0.1) behind the position embedding's ReLU; element (n, k) -> index n*128 + k
+  unsigned long long drop_seed;
+  unsigned drop_thresh;
+  float drop_scale;
 };
 hipError_t launch_obj_prep(const ObjPrepArgs& a, hipStream_t s);
 // training-mode BatchNorm1d(4) statistics of the box features center_xywh(boxes): out[0..3] mean, [4..7] biased
@@ -82,8 +91,15 @@ struct AssembleArgs {
   float* x;                 // [n_pair*19, 576]
   __bf16* a;                // LN(x), split rows [n_pair*19, 2*576]
   int n_pair;
+  // training only: pos_drop (EMB_DROPOUT) on the assembled tokens; element (row, col) -> index row*576 + col
+  unsigned long long drop_seed;
+  unsigned drop_thresh;
+  float drop_scale;
 };
 hipError_t launch_assemble(const AssembleArgs& a, hipStream_t s);
+// y = dropout mask of site `seed` applied to x ([rows, n_cols], index row*n_cols + col), scaled by `scale`; in place allowed
+hipError_t launch_dropout_apply(const float* x, float* y, size_t rows, int n_cols, unsigned long long seed, unsigned thresh,
+                                float scale, hipStream_t s);
 
 // LayerNorm(eps 1e-5) of `rows` rows (row r at x + r*ldx) -> split rows [rows, 2*576]
 hipError_t launch_layernorm(const float* x, long ldx, const float* w, const float* b, __bf16* dst, int rows,

@@ -170,6 +170,8 @@ __global__ __launch_bounds__(256) void obj_prep_kernel(ObjPrepArgs a) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) acc += a.pos_w[tid * 4 + k] * s_box[k];
     s_pos[tid] = fmaxf(acc, 0.f);
+    if (a.drop_thresh)   // training: Dropout(0.1) of pos_embed (roi_relation_predictors.py:4042-4047)
+      s_pos[tid] = dropout_keep(a.drop_seed, (unsigned long long)n * kPosDim + tid, a.drop_thresh) ? s_pos[tid] * a.drop_scale : 0.f;
     if (a.pos_out && blockIdx.y == 0) a.pos_out[(size_t)n * kPosDim + tid] = s_pos[tid];
   }
   if (a.obj_logits) {
@@ -346,6 +348,11 @@ __global__ __launch_bounds__(256) void assemble_kernel(AssembleArgs a) {
       }
     }
     v += *(const f32x4*)(a.pos_embedding + c);
+    if (a.drop_thresh) {   // training: pos_drop (model_veto.py:63)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        v[e] = dropout_keep(a.drop_seed, (unsigned long long)row * kDim + c + e, a.drop_thresh) ? v[e] * a.drop_scale : 0.f;
+    }
     r.v[j] = v;
     *(f32x4*)(xr + c) = v;
   }
@@ -364,6 +371,13 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 #pragma unroll
   for (int j = 0; j < 9; ++j) r.v[j] = *(const f32x4*)(xr + 4 * (q + 16 * j));
   rowq_layernorm_store(r, q, w, b, dst + (size_t)row * (2 * kDim));
+}
+
+__global__ __launch_bounds__(256) void dropout_apply_kernel(const float* __restrict__ x, float* __restrict__ y, size_t n,
+                                                            unsigned long long seed, unsigned thresh, float scale) {
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * 256;
+  for (; i < n; i += stride) y[i] = dropout_keep(seed, i, thresh) ? x[i] * scale : 0.f;
 }
 
 // logits[p][c] = cls[p] . W[c] + b[c]; weights pre-transposed to [576][n_out]; 4 pairs per block.
@@ -421,6 +435,14 @@ hipError_t launch_transpose_pair_proj(const float* src, float* dst, int kin, hip
 
 hipError_t launch_transpose_head(const float* src, float* dst, int n_out, hipStream_t s) {
   VETO_LAUNCH(transpose_head_kernel, dim3(kDim), dim3(128), 0, s, src, dst, n_out);
+  return hipGetLastError();
+}
+
+hipError_t launch_dropout_apply(const float* x, float* y, size_t rows, int n_cols, unsigned long long seed, unsigned thresh,
+                                float scale, hipStream_t s) {
+  const size_t n = rows * (size_t)n_cols;
+  const int blocks = (int)((n + 255) / 256 < 16384 ? (n + 255) / 256 : 16384);
+  VETO_LAUNCH(dropout_apply_kernel, dim3(blocks), dim3(256), 0, s, x, y, n, seed, thresh, scale);
   return hipGetLastError();
 }
 

@@ -195,10 +195,21 @@ Workspace carve(char* base, int n_obj, int n_pair, int chunk) {
 }
 
 // lda / ldc of split operands are in bf16 elements (2K / 2N for contiguous rows).
+struct DropSite {   // one dropout site of the training path: threshold p * 2^24 (0 = off), scale 1 / (1 - p)
+  unsigned long long seed = 0;
+  unsigned thresh = 0;
+  float scale = 1.f;
+};
+
 int run_gemm(veto_handle_t h, hipStream_t s, const char* name, const __bf16* a, SplitW w, const float* bias,
              const float* resid, long ldr, float* c, __bf16* c_split, long ldc, int M, int N, int K, int epi,
-             long lda = 0, int w_row0 = 0) {
+             long lda = 0, int w_row0 = 0, DropSite drop = DropSite()) {
   GemmArgs g{};
+  if (drop.thresh) {
+    if (epi != EPI_RESID) return fail(VETO_ERR_INVALID, "dropout is fused into the residual epilogue only");
+    epi = EPI_RESID_DROP;
+    g.drop_seed = drop.seed; g.drop_thresh = drop.thresh; g.drop_scale = drop.scale;
+  }
   g.a = a; g.lda = lda;
   g.w = w + (size_t)w_row0 * 2 * K;
   g.bias = bias; g.resid = resid; g.c = c; g.c_split = c_split;
@@ -629,6 +640,26 @@ int run_dgrad(veto_handle_t h, hipStream_t s, const TrainWs& w, const float* dy,
   return VETO_OK;
 }
 
+// dropout sites of the training path: 1 = pos_embed Dropout(0.1), 2 = pos_drop on the tokens, 3 + l = to_out of layer l
+DropSite drop_site(const veto_train_opts_t* o, int site) {
+  DropSite d;
+  if (!o) return d;
+  const float p = site == 1 ? o->p_pos : site == 2 ? o->p_emb : o->p_attn;
+  if (!(p > 0.f)) return d;
+  d.seed = o->seed + (unsigned long long)site * 0x632BE59BD9B4E019ull;
+  d.thresh = (unsigned)(p * 16777216.0f);
+  d.scale = 1.f / (1.f - p);
+  return d;
+}
+
+int check_train_opts(const veto_train_opts_t* o) {
+  if (!o) return VETO_OK;
+  if (o->struct_size != (int32_t)sizeof(veto_train_opts_t)) return fail(VETO_ERR_INVALID, "veto_train_opts_t size mismatch");
+  for (float p : {o->p_pos, o->p_emb, o->p_attn})
+    if (!(p >= 0.f && p < 1.f)) return fail(VETO_ERR_INVALID, "dropout probabilities must be in [0, 1)");
+  return VETO_OK;
+}
+
 int check_train_inputs(veto_handle_t h, const veto_inputs_t* in, void* workspace, size_t workspace_bytes) {
   if (!h || !in || !workspace) return fail(VETO_ERR_INVALID, "null argument");
   if (in->struct_size != (int32_t)sizeof(veto_inputs_t)) return fail(VETO_ERR_INVALID, "veto_inputs_t size mismatch");
@@ -663,10 +694,11 @@ int veto_weight_offset(veto_handle_t h, int index, size_t* offset_floats) {
   return VETO_OK;
 }
 
-int veto_forward_train(veto_handle_t h, void* stream, const veto_inputs_t* in, void* workspace, size_t workspace_bytes,
-                       float* out_logits) {
+int veto_forward_train(veto_handle_t h, void* stream, const veto_inputs_t* in, const veto_train_opts_t* opts, void* workspace,
+                       size_t workspace_bytes, float* out_logits) {
   int rc = check_train_inputs(h, in, workspace, workspace_bytes);
   if (rc) return rc;
+  if ((rc = check_train_opts(opts))) return rc;
   if (!out_logits) return fail(VETO_ERR_INVALID, "null out_logits");
   hipStream_t s = (hipStream_t)stream;
   if (h->dirty) { rc = finalize_weights(h, s); if (rc) return rc; }
@@ -687,6 +719,8 @@ int veto_forward_train(veto_handle_t h, void* stream, const veto_inputs_t* in, v
     a.loc_wt = h->loc_wt; a.loc_b = h->p("location_projection.0.bias");
     a.cls_wt = h->cls_wt; a.cls_b = h->p("class_projection.0.bias");
     a.lc = ws.lc; a.pos_out = nullptr; a.n_obj = n_obj;
+    const DropSite d = drop_site(opts, 1);
+    a.drop_seed = d.seed; a.drop_thresh = d.thresh; a.drop_scale = d.scale;
     HIP_TRY(launch_obj_prep(a, s));
   }
   HIP_TRY(launch_patchify(in->roi_depth, in->roi_rgb, ws.pa, n_obj, s));
@@ -699,6 +733,8 @@ int veto_forward_train(veto_handle_t h, void* stream, const veto_inputs_t* in, v
     a.pos_embedding = h->p(T + "pos_embedding");
     a.ln_w = h->layers[0].ln1_w; a.ln_b = h->layers[0].ln1_b;
     a.subj = ws.subj; a.obj = ws.obj; a.x = ws.layers[0].xin; a.a = ws.layers[0].a1; a.n_pair = n_pair;
+    const DropSite d = drop_site(opts, 2);
+    a.drop_seed = d.seed; a.drop_thresh = d.thresh; a.drop_scale = d.scale;
     HIP_TRY(launch_assemble(a, s));
   }
   for (int l = 0; l < L; ++l) {
@@ -712,7 +748,8 @@ int veto_forward_train(veto_handle_t h, void* stream, const veto_inputs_t* in, v
       a.qkv = t.qkv; a.n_pair = n_pair; a.heads = H; a.cls_only = 0; a.o = t.ao;
       HIP_TRY(launch_attention(a, s));
     }
-    rc = run_gemm(h, s, "gemm_out", t.ao, w.out, w.out_b, t.xin, kDim, t.xmid, nullptr, kDim, M, kDim, kDim, EPI_RESID);
+    rc = run_gemm(h, s, "gemm_out", t.ao, w.out, w.out_b, t.xin, kDim, t.xmid, nullptr, kDim, M, kDim, kDim, EPI_RESID, 0, 0,
+                  drop_site(opts, 3 + l));
     if (rc) return rc;
     HIP_TRY(launch_layernorm(t.xmid, kDim, w.ln2_w, w.ln2_b, t.a2, M, s));
     rc = run_gemm(h, s, "gemm_fc1", t.a2, w.fc1, w.fc1_b, nullptr, 0, t.pre, nullptr, 2 * kDim, M, 2 * kDim, kDim, EPI_F32);
@@ -726,10 +763,11 @@ int veto_forward_train(veto_handle_t h, void* stream, const veto_inputs_t* in, v
   return VETO_OK;
 }
 
-int veto_backward(veto_handle_t h, void* stream, const veto_inputs_t* in, void* workspace, size_t workspace_bytes,
-                  const float* dlogits, float* grads) {
+int veto_backward(veto_handle_t h, void* stream, const veto_inputs_t* in, const veto_train_opts_t* opts, void* workspace,
+                  size_t workspace_bytes, const float* dlogits, float* grads) {
   int rc = check_train_inputs(h, in, workspace, workspace_bytes);
   if (rc) return rc;
+  if ((rc = check_train_opts(opts))) return rc;
   if (!dlogits || !grads) return fail(VETO_ERR_INVALID, "null gradient pointer");
   hipStream_t s = (hipStream_t)stream;
   const int n_obj = in->n_obj, n_pair = in->n_pair, L = h->cfg.layers, H = h->cfg.heads, n_out = h->cfg.num_out, E = h->cfg.embed_dim;
@@ -762,11 +800,19 @@ int veto_backward(veto_handle_t h, void* stream, const veto_inputs_t* in, void* 
     HIP_TRY(launch_layernorm_backward(t.xmid, ws.dtmp, w.ln2_w, ws.dx, ws.dmid, ws.dgb, ws.ln_partial, M, s));
     HIP_TRY(hipMemcpyAsync(G(lname(l, "1.norm.weight")), ws.dgb, kDim * 4, hipMemcpyDeviceToDevice, s));
     HIP_TRY(hipMemcpyAsync(G(lname(l, "1.norm.bias")), ws.dgb + kDim, kDim * 4, hipMemcpyDeviceToDevice, s));
-    // x_mid = x_in + attention(LN1(x_in) Wqkv^T) Wo^T + bo
-    HIP_TRY(launch_column_sums(ws.dmid, kDim, M, kDim, G(lname(l, "0.fn.to_out.0.bias")), ws.col_partial, 64, s));
-    rc = run_wgrad(h, s, ws, ws.dmid, kDim, M, kDim, t.ao, nullptr, 2 * kDim, kDim, G(lname(l, "0.fn.to_out.0.weight")));
+    // x_mid = x_in + dropout(attention(LN1(x_in) Wqkv^T) Wo^T + bo): the projection sees the masked gradient
+    const float* dproj = ws.dmid;
+    {
+      const DropSite d = drop_site(opts, 3 + l);
+      if (d.thresh) {
+        HIP_TRY(launch_dropout_apply(ws.dmid, ws.dtmp, (size_t)M, kDim, d.seed, d.thresh, d.scale, s));
+        dproj = ws.dtmp;
+      }
+    }
+    HIP_TRY(launch_column_sums(dproj, kDim, M, kDim, G(lname(l, "0.fn.to_out.0.bias")), ws.col_partial, 64, s));
+    rc = run_wgrad(h, s, ws, dproj, kDim, M, kDim, t.ao, nullptr, 2 * kDim, kDim, G(lname(l, "0.fn.to_out.0.weight")));
     if (rc) return rc;
-    rc = run_dgrad(h, s, ws, ws.dmid, M, kDim, h->p(lname(l, "0.fn.to_out.0.weight")), kDim, ws.dtmp);
+    rc = run_dgrad(h, s, ws, dproj, M, kDim, h->p(lname(l, "0.fn.to_out.0.weight")), kDim, ws.dtmp);
     if (rc) return rc;
     HIP_TRY(launch_attention_backward(t.qkv, ws.dtmp, ws.dbig, n_pair, H, s));
     rc = run_wgrad(h, s, ws, ws.dbig, 3 * kDim, M, 3 * kDim, t.a1, nullptr, 2 * kDim, kDim, G(lname(l, "0.fn.to_qkv.weight")));
@@ -781,6 +827,10 @@ int veto_backward(veto_handle_t h, void* stream, const veto_inputs_t* in, void* 
   // ---- token assembly: cls_token, pos_embedding, per-object tables -----------------------------------------------
   // x0[p, t] = token + pos_embedding (ONE 576-vector broadcast over all tokens, model_veto.py:43,62): its gradient is
   // the sum over every token row; the cls_token's is the sum over row 0 of every pair
+  {
+    const DropSite d = drop_site(opts, 2);   // pos_drop sits between (token + pos_embedding) and the first layer
+    if (d.thresh) HIP_TRY(launch_dropout_apply(ws.dx, ws.dx, (size_t)M, kDim, d.seed, d.thresh, d.scale, s));
+  }
   HIP_TRY(launch_column_sums(ws.dx, kDim, M, kDim, G(T + "pos_embedding"), ws.col_partial, 64, s));
   HIP_TRY(launch_column_sums(ws.dx, (long)kTokens * kDim, n_pair, kDim, G(T + "cls_token"), ws.col_partial, 64, s));
   HIP_TRY(hipMemsetAsync(ws.dpatch, 0, (size_t)n_obj * 16 * 2 * kDim * 4, s));
@@ -826,6 +876,8 @@ int veto_backward(veto_handle_t h, void* stream, const veto_inputs_t* in, void* 
     // position branch: recompute pos (post-ReLU) through the masked gradient path
     //   dpos = dlc_loc . loc_wt^T ; obj_pos_backward -> dpre (ReLU'), BatchNorm affine gradients
     HIP_TRY(launch_sgemm_nt(ws.dlc, ldlc, h->loc_wt, 2 * kDim, ws.dpos, kPosDim, n_obj, kPosDim, 2 * kDim, s));
+    const DropSite dpos_site = drop_site(opts, 1);   // Dropout(0.1) behind the ReLU of pos_embed
+    if (dpos_site.thresh) HIP_TRY(launch_dropout_apply(ws.dpos, ws.dpos, (size_t)n_obj, kPosDim, dpos_site.seed, dpos_site.thresh, dpos_site.scale, s));
     HIP_TRY(launch_obj_pos_backward(in->boxes, in->box_mode, in->bn_batch_stats, h->p("pos_embed.0.weight"), h->p("pos_embed.0.bias"),
                                     h->p("pos_embed.1.weight"), h->p("pos_embed.1.bias"), ws.dpos, ws.dpre, ws.xhat, ws.bn_out, ws.dbn_out,
                                     G("pos_embed.0.weight"), G("pos_embed.0.bias"), n_obj, s));
@@ -837,6 +889,7 @@ int veto_backward(veto_handle_t h, void* stream, const veto_inputs_t* in, void* 
     // pos[n, k] = relu(pos_b[k] + sum_c pos_w[k, c] bn_out[n, c]): one small product + ReLU, done by reusing dpos as storage
     HIP_TRY(launch_sgemm_nt(ws.bn_out, 4, h->p("pos_embed.1.weight"), 4, ws.dpos, kPosDim, n_obj, kPosDim, 4, s));
     HIP_TRY(launch_bias_relu(ws.dpos, h->p("pos_embed.1.bias"), n_obj, kPosDim, s));
+    if (dpos_site.thresh) HIP_TRY(launch_dropout_apply(ws.dpos, ws.dpos, (size_t)n_obj, kPosDim, dpos_site.seed, dpos_site.thresh, dpos_site.scale, s));
     HIP_TRY(launch_sgemm_tn(ws.dpos, kPosDim, ws.dlc, ldlc, ws.dloc_wt, 2 * kDim, n_obj, kPosDim, 2 * kDim, s));
     HIP_TRY(launch_untranspose_pair_proj(ws.dloc_wt, G("location_projection.0.weight"), kPosDim, s));
     // class branch: emb = E[label]; d cls_wt[k, j] = sum_n emb[n, k] dlc_cls[n, j]; demb = dlc_cls . cls_wt^T

@@ -94,6 +94,11 @@ class VetoSggEvalArgs(Structure):
                                         "metrics")]
 
 
+class VetoTrainOpts(Structure):
+    _fields_ = [("struct_size", c_int32), ("p_pos", ctypes.c_float), ("p_emb", ctypes.c_float), ("p_attn", ctypes.c_float),
+                ("seed", ctypes.c_uint64)]
+
+
 class VetoError(RuntimeError):
     pass
 
@@ -145,8 +150,8 @@ def load_library():
     lib.veto_grad_floats.argtypes = [c_void_p]
     lib.veto_grad_floats.restype = c_size_t
     lib.veto_weight_offset.argtypes = [c_void_p, c_int, POINTER(c_size_t)]
-    lib.veto_forward_train.argtypes = [c_void_p, c_void_p, POINTER(VetoInputs), c_void_p, c_size_t, c_void_p]
-    lib.veto_backward.argtypes = [c_void_p, c_void_p, POINTER(VetoInputs), c_void_p, c_size_t, c_void_p, c_void_p]
+    lib.veto_forward_train.argtypes = [c_void_p, c_void_p, POINTER(VetoInputs), POINTER(VetoTrainOpts), c_void_p, c_size_t, c_void_p]
+    lib.veto_backward.argtypes = [c_void_p, c_void_p, POINTER(VetoInputs), POINTER(VetoTrainOpts), c_void_p, c_size_t, c_void_p, c_void_p]
     lib.veto_debug_attention_backward.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32]
     lib.veto_debug_layernorm_backward_workspace_bytes.argtypes = [c_int32]
     lib.veto_debug_layernorm_backward_workspace_bytes.restype = c_size_t

@@ -241,18 +241,35 @@ class _NativeForward:
     def _offsets(self, n_objs, n_pairs, device):
         return cached_offsets(n_objs, n_pairs, device)
 
-    def _check_train(self):
-        """Training mode runs without dropout only (dropout masks are not built)."""
-        live = [n for n, m in self._trunk.named_modules() if isinstance(m, nn.Dropout) and m.p > 0]
-        if live:
-            raise NotImplementedError("veto_amd: training mode exists without dropout only; these modules have p > 0: %s (set "
-                                      "them to 0, or call .eval() for inference)" % ", ".join(live[:6]))
+    def _train_opts(self):
+        """Dropout probabilities of the three sites the training path implements, read from the mirror modules (so that
+        `module.p = 0` behaves as in torch), plus a fresh seed drawn from torch's generator."""
+        t = self._trunk
+        tr = t.fusion_transformer.transformer
+        o = native.VetoTrainOpts()
+        o.struct_size = ctypes.sizeof(native.VetoTrainOpts)
+        o.p_pos = float(t.pos_embed[3].p)
+        o.p_emb = float(tr.pos_drop.p)
+        ps = {float(layer[0].fn.to_out[1].p) for layer in tr.layers}
+        if len(ps) != 1:
+            raise NotImplementedError("veto_amd: per-layer attention dropout rates must be equal")
+        o.p_attn = ps.pop()
+        others = [n for n, m in t.named_modules() if isinstance(m, nn.Dropout) and m.p > 0 and
+                  not (n == "pos_embed.3" or n.endswith("pos_drop") or n.endswith("fn.to_out.1"))]
+        others = [n for n in others if not n.startswith("bbox_embed")]        # bbox_embed is not on the VETO path
+        if others:
+            raise NotImplementedError("veto_amd: dropout is built for pos_embed, pos_drop and the attention output only; "
+                                      "these modules also have p > 0: %s" % ", ".join(others[:6]))
+        o.seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        return o
 
     def _run_native_train(self, proposals, rel_pair_idxs, roi_features, roi_depth_features, labels, logits):
         """Forward in training mode: BatchNorm1d(4) of pos_embed on batch statistics (and its running statistics
         updated the way nn.BatchNorm1d(momentum=0.001) does, roi_relation_predictors.py:4042-4047)."""
         device = roi_features.device
         stats = torch.empty(12, dtype=torch.float32, device=device)
+        if any(isinstance(m, nn.Dropout) and m.p > 0 for n, m in self._trunk.named_modules() if not n.startswith("bbox_embed")):
+            raise NotImplementedError("veto_amd: the forward-only training pass (VETO_AMD.TRAIN_FORWARD_ONLY) runs without dropout")
         out = self._run_native(proposals, rel_pair_idxs, roi_features, roi_depth_features, labels, logits, bn_batch_stats=stats)
         bn = self._trunk.pos_embed[0]
         with torch.no_grad():
@@ -359,12 +376,14 @@ class _TrainFn(torch.autograd.Function):
         inp, keep, n_objs, n_pairs, device, eng = owner._prepare_inputs(proposals, rel_pair_idxs, roi_features, roi_depth_features,
                                                                         labels, None, stats)
         lib = native.load_library()
+        opts = owner._train_opts()
         need = lib.veto_train_workspace_bytes(eng.handle, inp.n_obj, inp.n_pair)
         ws = torch.empty(need, dtype=torch.uint8, device=device)
         out = torch.empty((inp.n_pair, owner._num_out), dtype=torch.float32, device=device)
         stream = torch.cuda.current_stream(device)
-        native.check(lib.veto_forward_train(eng.handle, ctypes.c_void_p(stream.cuda_stream), ctypes.byref(inp), ctypes.c_void_p(ws.data_ptr()),
-                                            ws.numel(), ctypes.c_void_p(out.data_ptr())))
+        native.check(lib.veto_forward_train(eng.handle, ctypes.c_void_p(stream.cuda_stream), ctypes.byref(inp), ctypes.byref(opts),
+                                            ctypes.c_void_p(ws.data_ptr()), ws.numel(), ctypes.c_void_p(out.data_ptr())))
+        ctx.opts = opts
         bn = owner._trunk.pos_embed[0]
         with torch.no_grad():    # nn.BatchNorm1d(momentum=0.001) running statistics
             m = bn.momentum
@@ -383,8 +402,9 @@ class _TrainFn(torch.autograd.Function):
         n_floats = lib.veto_grad_floats(eng.handle)
         flat = torch.empty(n_floats, dtype=torch.float32, device=device)
         stream = torch.cuda.current_stream(device)
-        native.check(lib.veto_backward(eng.handle, ctypes.c_void_p(stream.cuda_stream), ctypes.byref(ctx.inp), ctypes.c_void_p(ctx.ws.data_ptr()),
-                                       ctx.ws.numel(), ctypes.c_void_p(dlogits.data_ptr()), ctypes.c_void_p(flat.data_ptr())))
+        native.check(lib.veto_backward(eng.handle, ctypes.c_void_p(stream.cuda_stream), ctypes.byref(ctx.inp), ctypes.byref(ctx.opts),
+                                       ctypes.c_void_p(ctx.ws.data_ptr()), ctx.ws.numel(), ctypes.c_void_p(dlogits.data_ptr()),
+                                       ctypes.c_void_p(flat.data_ptr())))
         offsets = eng.weight_offsets()
         grads = []
         for prm, name, row0, rows in ctx.spec:
@@ -443,8 +463,6 @@ class VETOPredictor(nn.Module, _NativeForward):
 
     def forward(self, proposals, rel_pair_idxs, rel_labels, logger, roi_features=None,
                 roi_depth_features=None, rel_binarys=None):
-        if self.training:
-            self._check_train()
         if self.mode == "predcls":
             labels = _cat_field(proposals, "labels").long()
             logits = None
@@ -546,7 +564,6 @@ class VETOPredictor_MEET(nn.Module, _NativeForward):
     def forward(self, proposals, rel_pair_idxs, rel_labels, logger, roi_features=None,
                 roi_depth_features=None, rel_binarys=None):
         if self.training:
-            self._check_train()
             if self.expert_group:
                 raise NotImplementedError("veto_amd: training of the EXPERT_GROUP heads is not built")
         if self.mode == "predcls":
