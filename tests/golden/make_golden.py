@@ -330,13 +330,13 @@ def run_postprocessor_vote(cfg, BoxList, name, n, dataset, voting):
     print("%-24s expert voting %s: %d of %d rows kept" % (name, voting, out["rel_pair_idxs"].shape[0], len(sizes) * P_))
 
 
-def run_train_losses(P, cfg, BoxList, name, meet, beta_loss=False, dataset="VG"):
+def run_train_losses(P, cfg, BoxList, name, meet, beta_loss=False, dataset="VG", mode="predcls"):
     """Training-mode forward of the reference predictor (dropout off, so it is deterministic) on a small batch with
     random relation labels: stores the classifier logits it produced (forward hooks on the rel_out modules), the
     labels, and the losses it returned.  MEET: also the expert sampling (`cur_chosen_matrix`), which the reference
     draws from Python's `random` (seeded with 1, tools/relation_train_net.py:44-50), and its sample_rate_matrix."""
     import random
-    n_obj, n_rel = configure(P, cfg, "predcls", 2, 8, "VETOPredictor_MEET" if meet else "VETOPredictor", dataset)
+    n_obj, n_rel = configure(P, cfg, mode, 2, 8, "VETOPredictor_MEET" if meet else "VETOPredictor", dataset)
     cfg.ENSEMBLE_LEARNING.EXPERT_GROUP = False
     cfg.GLOBAL_SETTING.BETA_LOSS = False
     torch.manual_seed(0)
@@ -354,7 +354,7 @@ def run_train_losses(P, cfg, BoxList, name, meet, beta_loss=False, dataset="VG")
         if isinstance(m, torch.nn.Dropout):
             m.p = 0.0
     batch = synth.synthetic_batch(7, len(num_objs), num_objs, num_obj_cls=n_obj)
-    props = make_proposals(BoxList, batch, "predcls")
+    props = make_proposals(BoxList, batch, mode)
     pairs = test_pairs(num_objs)
     P_tot = sum(len(p) for p in pairs)
     u = synth.uniform01(9, "train.labels", P_tot)
@@ -377,7 +377,8 @@ def run_train_losses(P, cfg, BoxList, name, meet, beta_loss=False, dataset="VG")
                 roi_features=torch.from_numpy(batch["roi_features"]), roi_depth_features=torch.from_numpy(batch["roi_depth_features"]))
     for h in hooks:
         h.remove()
-    out = {"labels": labels, "meet": int(meet), "dataset": dataset, "beta_loss": int(beta_loss), "num_objs": np.array(num_objs)}
+    out = {"labels": labels, "meet": int(meet), "dataset": dataset, "beta_loss": int(beta_loss), "num_objs": np.array(num_objs),
+           "mode": mode}
     # gradients of the summed losses w.r.t. every parameter (the reference's training loop sums the loss dict,
     # engine/trainer + tools/relation_train_net.py:297): stored as norm + a strided sample (full tensor when small)
     sum(res[2].values()).backward()
@@ -466,6 +467,8 @@ def main():
         run_train_losses(P, cfg, BoxList, "train_vanilla_beta", meet=False, beta_loss=True)
         run_train_losses(P, cfg, BoxList, "train_meet_vg", meet=True)
         run_train_losses(P, cfg, BoxList, "train_meet_gqa", meet=True, dataset="GQA")
+        run_train_losses(P, cfg, BoxList, "train_vanilla_sgcls", meet=False, mode="sgcls")
+        run_train_losses(P, cfg, BoxList, "train_meet_sgcls", meet=True, mode="sgcls")
         return
     if os.environ.get("GOLDEN_ONLY") == "sggeval":   # regenerate only the evaluator fixtures
         for name in SGG_EVAL_CASES:
@@ -481,6 +484,8 @@ def main():
     run_train_losses(P, cfg, BoxList, "train_vanilla_beta", meet=False, beta_loss=True)
     run_train_losses(P, cfg, BoxList, "train_meet_vg", meet=True)
     run_train_losses(P, cfg, BoxList, "train_meet_gqa", meet=True, dataset="GQA")
+    run_train_losses(P, cfg, BoxList, "train_vanilla_sgcls", meet=False, mode="sgcls")
+    run_train_losses(P, cfg, BoxList, "train_meet_sgcls", meet=True, mode="sgcls")
     for name in SGG_EVAL_CASES:
         run_sgg_eval(cfg, BoxList, name)
     run_postprocessor_vote(cfg, BoxList, "postvote_vg_c_n10", 10, "VG", "C")

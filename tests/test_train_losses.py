@@ -12,8 +12,8 @@ from conftest import GOLDEN_DIR
 from oracle import train_oracle as to
 from veto_amd import meet_tables
 
-CASES_VANILLA = ["train_vanilla", "train_vanilla_beta"]
-CASES_MEET = ["train_meet_vg", "train_meet_gqa"]
+CASES_VANILLA = ["train_vanilla", "train_vanilla_beta", "train_vanilla_sgcls"]
+CASES_MEET = ["train_meet_vg", "train_meet_gqa", "train_meet_sgcls"]
 
 
 def _load(name):
@@ -108,7 +108,7 @@ def _train_setup(name, meet, dev, forward_only=True):
     dataset = str(g["dataset"])
     n_obj_cls = 151 if dataset == "VG" else 201
     num_objs = [int(x) for x in g["num_objs"]]
-    cfg = testing.make_config(2, 8, "predcls", meet, dataset)
+    cfg = testing.make_config(2, 8, str(g["mode"]), meet, dataset)
     cfg.VETO_AMD.TRAIN_FORWARD_ONLY = forward_only
     if int(g["beta_loss"]):
         cfg.GLOBAL_SETTING.BETA_LOSS = True
@@ -139,7 +139,7 @@ def test_training_mode_forward_reproduces_reference_losses(name):
     dev = torch.device("cuda:0")
     meet = name in CASES_MEET
     g, model, batch, num_objs = _train_setup(name, meet, dev)
-    props = testing.make_proposals(batch, "predcls", dev)
+    props = testing.make_proposals(batch, str(g["mode"]), dev)
     pairs = prepare_test_pairs(dev, props)
     rel_labels = list(torch.from_numpy(g["labels"]).to(dev).split([int(p.shape[0]) for p in pairs]))
     bn = (model.model if meet else model).pos_embed[0]
@@ -255,7 +255,7 @@ def test_training_backward_matches_reference_gradients(name):
     dev = torch.device("cuda:0")
     meet = name in CASES_MEET
     g, model, batch, num_objs = _train_setup(name, meet, dev, forward_only=False)
-    props = testing.make_proposals(batch, "predcls", dev)
+    props = testing.make_proposals(batch, str(g["mode"]), dev)
     pairs = prepare_test_pairs(dev, props)
     rel_labels = list(torch.from_numpy(g["labels"]).to(dev).split([int(p.shape[0]) for p in pairs]))
     random.seed(1)

@@ -264,6 +264,8 @@ hipError_t launch_sgemm_nt(const float* a, long lda, const float* b, long ldb, f
 hipError_t launch_obj_pos_backward(const float* boxes, int box_mode, const float* stats, const float* bn_w, const float* bn_b,
                                    const float* pos_w, const float* pos_b, const float* dpos, float* dpre, float* xhat, float* bn_out,
                                    float* dbn_out, float* dgamma, float* dbeta, int n_obj, hipStream_t s);
+hipError_t launch_sgemm_nn(const float* a, long lda, const float* b, long ldb, float* c, long ldc, int n, int ki, int kj, hipStream_t s);
+hipError_t launch_softmax_rows(const float* x, float* y, int n, int c, hipStream_t s);
 hipError_t launch_bias_relu(float* x, const float* b, int n, int k, hipStream_t s);
 hipError_t launch_gather_rows(const float* table, const int64_t* labels, int dim, float* out, int n, hipStream_t s);
 hipError_t launch_scatter_rows(const float* demb, const int64_t* labels, int dim, float* dtable, int n, hipStream_t s);

@@ -148,6 +148,33 @@ __global__ __launch_bounds__(256) void sgemm_nt_kernel(const float* __restrict__
   c[(size_t)r * ldc + i] = acc;
 }
 
+// C[r, i] = sum_j A[r, j] B[j, i]   (A: [n, kj] lda, B: [kj, ki] ldb, C: [n, ki] ldc)
+__global__ __launch_bounds__(256) void sgemm_nn_kernel(const float* __restrict__ a, long lda, const float* __restrict__ b, long ldb,
+                                                       float* __restrict__ c, long ldc, int n, int ki, int kj) {
+  const int r = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= ki) return;
+  float acc = 0.f;
+  for (int j = 0; j < kj; ++j) acc += a[(size_t)r * lda + j] * b[(size_t)j * ldb + i];
+  c[(size_t)r * ldc + i] = acc;
+}
+
+// row softmax of [n, c] (c <= 256), one workgroup per row: the soft object embedding of sgcls (:4092-4095)
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ x, float* __restrict__ y, int c) {
+  __shared__ float s_v[256], s_red[2];
+  const int n = blockIdx.x, tid = threadIdx.x;
+  s_v[tid] = tid < c ? x[(size_t)n * c + tid] : -INFINITY;
+  __syncthreads();
+  if (tid == 0) {
+    float mx = -INFINITY, sum = 0.f;
+    for (int i = 0; i < c; ++i) mx = fmaxf(mx, s_v[i]);
+    for (int i = 0; i < c; ++i) sum += expf(s_v[i] - mx);
+    s_red[0] = mx;
+    s_red[1] = sum;
+  }
+  __syncthreads();
+  if (tid < c) y[(size_t)n * c + tid] = expf(s_v[tid] - s_red[0]) * (1.f / s_red[1]);
+}
+
 // x[n, k] = relu(x[n, k] + b[k])
 __global__ __launch_bounds__(256) void bias_relu_kernel(float* __restrict__ x, const float* __restrict__ b, int n, int k) {
   const int i = blockIdx.x * 256 + threadIdx.x;
@@ -287,6 +314,17 @@ hipError_t launch_obj_pos_backward(const float* boxes, int box_mode, const float
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   VETO_LAUNCH(bn_affine_backward_kernel, dim3(1), dim3(64), 0, s, dbn_out, xhat, n_obj, dgamma, dbeta);
+  return hipGetLastError();
+}
+
+hipError_t launch_sgemm_nn(const float* a, long lda, const float* b, long ldb, float* c, long ldc, int n, int ki, int kj, hipStream_t s) {
+  VETO_LAUNCH(sgemm_nn_kernel, dim3((ki + 255) / 256, n), dim3(256), 0, s, a, lda, b, ldb, c, ldc, n, ki, kj);
+  return hipGetLastError();
+}
+
+hipError_t launch_softmax_rows(const float* x, float* y, int n, int c, hipStream_t s) {
+  if (c > 256) return hipErrorInvalidValue;
+  VETO_LAUNCH(softmax_rows_kernel, dim3(n), dim3(256), 0, s, x, y, c);
   return hipGetLastError();
 }
 

@@ -542,7 +542,7 @@ struct TrainWs {
   float *dx, *dmid, *dtmp, *dbig;
   __bf16 *dsplit, *at, *wt, *wdg;
   float *ln_partial, *col_partial, *dgb;
-  float *dpatch, *dlc, *dpos, *dpre, *xhat, *bn_out, *dbn_out, *emb, *demb, *dloc_wt, *dcls_wt, *dwcat_t;
+  float *dpatch, *dlc, *dpos, *dpre, *xhat, *bn_out, *dbn_out, *emb, *demb, *prob, *dloc_wt, *dcls_wt, *dwcat_t;
   size_t mp2;    // padded reduction length of the weight-gradient GEMMs
   size_t total;
 };
@@ -598,6 +598,7 @@ TrainWs carve_train(char* base, veto_handle_t h, int n_obj, int n_pair) {
   w.dbn_out = (float*)take((size_t)n_obj * 4 * 4);
   w.emb = (float*)take((size_t)n_obj * E * 4);
   w.demb = (float*)take((size_t)n_obj * E * 4);
+  w.prob = (float*)take((size_t)n_obj * 256 * 4);
   w.dloc_wt = (float*)take((size_t)kPosDim * 2 * kDim * 4);
   w.dcls_wt = (float*)take((size_t)E * 2 * kDim * 4);
   w.dwcat_t = (float*)take((size_t)2048 * 2 * kDim * 4);
@@ -666,7 +667,7 @@ int check_train_inputs(veto_handle_t h, const veto_inputs_t* in, void* workspace
   if (in->n_obj <= 0 || in->n_pair <= 0 || in->n_img <= 0) return fail(VETO_ERR_INVALID, "empty batch");
   if (!in->roi_rgb || !in->roi_depth || !in->boxes || !in->rel_pairs || !in->img_obj_offset || !in->img_pair_offset)
     return fail(VETO_ERR_INVALID, "missing input pointer");
-  if (!in->obj_labels || in->obj_logits) return fail(VETO_ERR_INVALID, "the training path takes hard object labels (predcls / MEET)");
+  if (!in->obj_labels && !in->obj_logits) return fail(VETO_ERR_INVALID, "neither obj_labels nor obj_logits given");
   if (!in->bn_batch_stats) return fail(VETO_ERR_INVALID, "the training path needs bn_batch_stats (training-mode BatchNorm)");
   if (h->cfg.precision != VETO_PRECISE) return fail(VETO_ERR_INVALID, "the training path runs in precise mode only");
   if (workspace_bytes < veto_train_workspace_bytes(h, in->n_obj, in->n_pair)) return fail(VETO_ERR_WORKSPACE, "training workspace too small");
@@ -710,7 +711,7 @@ int veto_forward_train(veto_handle_t h, void* stream, const veto_inputs_t* in, c
                               nullptr, s));
   {
     ObjPrepArgs a{};
-    a.boxes = in->boxes; a.box_mode = in->box_mode; a.labels = in->obj_labels; a.obj_logits = nullptr;
+    a.boxes = in->boxes; a.box_mode = in->box_mode; a.labels = in->obj_labels; a.obj_logits = in->obj_logits;
     a.embed = h->p("obj_embed.weight"); a.num_obj_cls = h->cfg.num_obj_cls; a.embed_dim = h->cfg.embed_dim;
     a.bn_w = h->p("pos_embed.0.weight"); a.bn_b = h->p("pos_embed.0.bias");
     HIP_TRY(launch_bn_batch_stats(in->boxes, in->box_mode, n_obj, in->bn_batch_stats, s));
@@ -892,12 +893,20 @@ int veto_backward(veto_handle_t h, void* stream, const veto_inputs_t* in, const 
     if (dpos_site.thresh) HIP_TRY(launch_dropout_apply(ws.dpos, ws.dpos, (size_t)n_obj, kPosDim, dpos_site.seed, dpos_site.thresh, dpos_site.scale, s));
     HIP_TRY(launch_sgemm_tn(ws.dpos, kPosDim, ws.dlc, ldlc, ws.dloc_wt, 2 * kDim, n_obj, kPosDim, 2 * kDim, s));
     HIP_TRY(launch_untranspose_pair_proj(ws.dloc_wt, G("location_projection.0.weight"), kPosDim, s));
-    // class branch: emb = E[label]; d cls_wt[k, j] = sum_n emb[n, k] dlc_cls[n, j]; demb = dlc_cls . cls_wt^T
-    HIP_TRY(launch_gather_rows(h->p("obj_embed.weight"), in->obj_labels, E, ws.emb, n_obj, s));
+    // class branch: emb = E[label] (hard labels) or softmax(logits) . E (sgcls, :4092-4095);
+    // d cls_wt[k, j] = sum_n emb[n, k] dlc_cls[n, j]; demb = dlc_cls . cls_wt^T
+    const int C_obj = h->cfg.num_obj_cls;
+    if (in->obj_logits) {
+      HIP_TRY(launch_softmax_rows(in->obj_logits, ws.prob, n_obj, C_obj, s));
+      HIP_TRY(launch_sgemm_nn(ws.prob, C_obj, h->p("obj_embed.weight"), E, ws.emb, E, n_obj, E, C_obj, s));
+    } else {
+      HIP_TRY(launch_gather_rows(h->p("obj_embed.weight"), in->obj_labels, E, ws.emb, n_obj, s));
+    }
     HIP_TRY(launch_sgemm_tn(ws.emb, E, ws.dlc + 2 * kDim, ldlc, ws.dcls_wt, 2 * kDim, n_obj, E, 2 * kDim, s));
     HIP_TRY(launch_untranspose_pair_proj(ws.dcls_wt, G("class_projection.0.weight"), E, s));
     HIP_TRY(launch_sgemm_nt(ws.dlc + 2 * kDim, ldlc, h->cls_wt, 2 * kDim, ws.demb, E, n_obj, E, 2 * kDim, s));
-    HIP_TRY(launch_scatter_rows(ws.demb, in->obj_labels, E, G("obj_embed.weight"), n_obj, s));
+    if (in->obj_logits) HIP_TRY(launch_sgemm_tn(ws.prob, C_obj, ws.demb, E, G("obj_embed.weight"), E, n_obj, C_obj, E, s));
+    else HIP_TRY(launch_scatter_rows(ws.demb, in->obj_labels, E, G("obj_embed.weight"), n_obj, s));
   }
   return VETO_OK;
 }

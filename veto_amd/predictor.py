@@ -358,10 +358,10 @@ class _NativeForward:
             row += head.out_features
         return spec
 
-    def _run_native_train_grad(self, proposals, rel_pair_idxs, roi_features, roi_depth_features, labels):
+    def _run_native_train_grad(self, proposals, rel_pair_idxs, roi_features, roi_depth_features, labels, logits=None):
         """Training-mode forward whose result carries an autograd graph: logits [sum P, num_out]."""
         spec = self._train_param_spec()
-        return _TrainFn.apply(self, (proposals, rel_pair_idxs, roi_features, roi_depth_features, labels), *[s[0] for s in spec])
+        return _TrainFn.apply(self, (proposals, rel_pair_idxs, roi_features, roi_depth_features, labels, logits), *[s[0] for s in spec])
 
 
 class _TrainFn(torch.autograd.Function):
@@ -370,11 +370,11 @@ class _TrainFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, owner, call, *params):
-        proposals, rel_pair_idxs, roi_features, roi_depth_features, labels = call
+        proposals, rel_pair_idxs, roi_features, roi_depth_features, labels, obj_logits = call
         device = roi_features.device
         stats = torch.empty(12, dtype=torch.float32, device=device)
         inp, keep, n_objs, n_pairs, device, eng = owner._prepare_inputs(proposals, rel_pair_idxs, roi_features, roi_depth_features,
-                                                                        labels, None, stats)
+                                                                        labels, obj_logits, stats)
         lib = native.load_library()
         opts = owner._train_opts()
         need = lib.veto_train_workspace_bytes(eng.handle, inp.n_obj, inp.n_pair)
@@ -476,18 +476,16 @@ class VETOPredictor(nn.Module, _NativeForward):
             target = torch.cat(list(rel_labels), 0)
             w = self.criterion_loss_rel.weight
             add_losses = {}
-            if self._train_forward_only or self.mode != "predcls":
-                if not self._train_forward_only:
-                    raise NotImplementedError("veto_amd: the backward of the soft object embedding (sgcls / sgdet of VETOPredictor) is not "
-                                              "built; VETO_AMD.TRAIN_FORWARD_ONLY gives the losses without gradients")
+            if self._train_forward_only:
                 rel, _, _ = self._run_native_train(proposals, rel_pair_idxs, roi_features, roi_depth_features, labels, logits)
                 add_losses["rel_loss"] = relation_ce_loss(rel, target, weight=w)[0][0]
             else:
-                rel = self._run_native_train_grad(proposals, rel_pair_idxs, roi_features, roi_depth_features, labels)
+                rel = self._run_native_train_grad(proposals, rel_pair_idxs, roi_features, roi_depth_features, labels, logits)
                 add_losses["rel_loss"] = ce_loss(rel, target, weight=w)
-            if self.mode != "predcls":
+            if self.mode != "predcls":   # :4129-4132: CE over obj_dists, which is the ONE-HOT of pred_labels here
                 fg = _cat_field(proposals, "labels").long()
-                add_losses["obj_loss"] = relation_ce_loss(logits.to(rel.device), fg)[0][0]
+                onehot = nn.functional.one_hot(obj_label_for_dist.to(rel.device), self.num_obj_cls).float()
+                add_losses["obj_loss"] = relation_ce_loss(onehot, fg)[0][0]
             return None, None, add_losses, None, None, None
         rel, n_objs, n_pairs = self._run_native(proposals, rel_pair_idxs, roi_features, roi_depth_features,
                                                 labels, logits, debug=getattr(self, "debug_outputs", False))
