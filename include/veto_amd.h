@@ -345,7 +345,7 @@ size_t veto_debug_wgrad_workspace_bytes(int32_t m, int32_t n, int32_t k, int32_t
  * veto_debug_layernorm_backward: x, dy, dx device [rows, 576] (dres optional, added to dx), gamma [576],
  *                                dgamma_dbeta device [2, 576]; workspace of veto_debug_layernorm_backward_workspace_bytes
  * veto_debug_gelu_backward:      dpre = dh * gelu'(pre), n elements (n % 4 == 0)                       (model_veto.py:140)
- * veto_debug_column_sums:        out[c] = sum_r dy[r, c] (bias gradients); workspace 64 * n_cols floats */
+ * veto_debug_column_sums:        out[c] = sum_r dy[r, c] (bias gradients); workspace 256 * n_cols floats */
 int veto_debug_attention_backward(void* stream, const float* qkv, const float* dout, float* dqkv, int32_t n_pair, int32_t heads);
 size_t veto_debug_layernorm_backward_workspace_bytes(int32_t rows);
 int veto_debug_layernorm_backward(void* stream, const float* x, const float* dy, const float* gamma, const float* dres,

@@ -74,7 +74,7 @@ def test_gelu_backward_and_column_sums_against_autograd():
     pre_d, dh_d = pre.to(dev), dh.to(dev)
     native.check(lib.veto_debug_gelu_backward(None, pre_d.data_ptr(), dh_d.data_ptr(), dpre.data_ptr(), pre.numel()))
     out = torch.empty(1152, device=dev)
-    ws = torch.empty(64 * 1152 * 4, dtype=torch.uint8, device=dev)
+    ws = torch.empty(1024 * 1152 * 4, dtype=torch.uint8, device=dev)
     dyd = dh.to(dev)
     native.check(lib.veto_debug_column_sums(None, dyd.data_ptr(), 1152, 513, 1152, out.data_ptr(), ws.data_ptr(), ws.numel()))
     torch.cuda.synchronize()

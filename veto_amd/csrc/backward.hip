@@ -11,6 +11,8 @@ namespace veto {
 
 namespace {
 
+constexpr int kColChunks = 256;    // row chunks of the two-stage column sums (fixed order -> deterministic)
+
 // One wave per (pair, head), everything in fp32.  With S = q k^T * scale, P = softmax(S), O = P v:
 //   dV = P^T dO,  dP = dO v^T,  dS = P * (dP - rowsum(dP * P)),  dQ = dS k * scale,  dK = dS^T q * scale.
 template <int DH>
@@ -70,16 +72,29 @@ __global__ __launch_bounds__(64) void attention_backward_kernel(const float* __r
 
 // LayerNorm backward over 576-wide rows, one quarter wave per row (lane q holds chunks q + 16 j as the forward):
 //   xhat = (x - mean) * rstd, g = dy * gamma, dx = rstd * (g - mean(g) - xhat * mean(g * xhat)) (+ dres)
-// dgamma / dbeta: every block adds its 16 rows in LDS and writes one partial row [2, 576]; ln_param_reduce_kernel
-// folds the partial rows in block order.
+// dgamma / dbeta: a thread always owns the same 36 columns, so it adds its kLnRowsPerBlock / 16 rows in registers;
+// the 16 row slots of the block then meet in LDS once per block, and the block writes one partial row [2, 576]
+// that a two-stage column sum folds in a fixed order.
+constexpr int kLnRowsPerBlock = 64;
+
 __global__ __launch_bounds__(256) void layernorm_backward_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                                  const float* __restrict__ gamma, const float* __restrict__ dres,
                                                                  float* __restrict__ dx, float* __restrict__ partial, int rows) {
   __shared__ float s_dg[kDim], s_db[kDim];
   for (int c = threadIdx.x; c < kDim; c += 256) { s_dg[c] = 0.f; s_db[c] = 0.f; }
   __syncthreads();
-  const int row = blockIdx.x * 16 + (threadIdx.x >> 4), q = threadIdx.x & 15;
-  if (row < rows) {
+  const int q = threadIdx.x & 15;
+  auto gsum = [](float t) {
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+    return t;
+  };
+  f32x4 acc_g[9], acc_b[9];
+#pragma unroll
+  for (int j = 0; j < 9; ++j) { acc_g[j] = f32x4{0.f, 0.f, 0.f, 0.f}; acc_b[j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  for (int it = 0; it < kLnRowsPerBlock / 16; ++it) {
+    const int row = blockIdx.x * kLnRowsPerBlock + it * 16 + (threadIdx.x >> 4);
+    if (row >= rows) continue;      // uniform per quarter wave
     const float* xr = x + (size_t)row * kDim;
     const float* gr = dy + (size_t)row * kDim;
     f32x4 xv[9], gv[9];
@@ -90,11 +105,6 @@ __global__ __launch_bounds__(256) void layernorm_backward_kernel(const float* __
       gv[j] = *(const f32x4*)(gr + 4 * (q + 16 * j));
       s += (xv[j][0] + xv[j][1]) + (xv[j][2] + xv[j][3]);
     }
-    auto gsum = [](float t) {
-#pragma unroll
-      for (int o = 8; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
-      return t;
-    };
     const float mean = gsum(s) * (1.f / kDim);
     float sq = 0.f;
 #pragma unroll
@@ -105,13 +115,12 @@ __global__ __launch_bounds__(256) void layernorm_backward_kernel(const float* __
     float sg = 0.f, sgx = 0.f;
 #pragma unroll
     for (int j = 0; j < 9; ++j) {
-      const int c = 4 * (q + 16 * j);
-      const f32x4 w = *(const f32x4*)(gamma + c);
+      const f32x4 w = *(const f32x4*)(gamma + 4 * (q + 16 * j));
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const float xh = (xv[j][e] - mean) * rstd;
-        atomicAdd(&s_dg[c + e], gv[j][e] * xh);    // LDS atomics: 16 rows of this block share a column
-        atomicAdd(&s_db[c + e], gv[j][e]);
+        acc_g[j][e] += gv[j][e] * xh;
+        acc_b[j][e] += gv[j][e];
         const float g = gv[j][e] * w[e];
         xv[j][e] = xh;      // keep xhat
         gv[j][e] = g;       // keep g
@@ -131,6 +140,14 @@ __global__ __launch_bounds__(256) void layernorm_backward_kernel(const float* __
       *(f32x4*)(dr + c) = o;
     }
   }
+#pragma unroll
+  for (int j = 0; j < 9; ++j)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int c = 4 * (q + 16 * j) + e;
+      atomicAdd(&s_dg[c], acc_g[j][e]);    // 16 row slots per column, once per block
+      atomicAdd(&s_db[c], acc_b[j][e]);
+    }
   __syncthreads();
   float* pr = partial + (size_t)blockIdx.x * 2 * kDim;
   for (int c = threadIdx.x; c < kDim; c += 256) { pr[c] = s_dg[c]; pr[kDim + c] = s_db[c]; }
@@ -190,17 +207,21 @@ hipError_t launch_attention_backward(const float* qkv, const float* dout, float*
   return hipGetLastError();
 }
 
-size_t layernorm_backward_partial_floats(int rows) { return (size_t)((rows + 15) / 16) * 2 * kDim; }
+// partial rows of the LayerNorm parameter gradients + the scratch of the two-stage column sum over them
+size_t layernorm_backward_partial_floats(int rows) {
+  return (size_t)((rows + kLnRowsPerBlock - 1) / kLnRowsPerBlock) * 2 * kDim + (size_t)kColChunks * 2 * kDim;
+}
 
 hipError_t launch_layernorm_backward(const float* x, const float* dy, const float* gamma, const float* dres, float* dx,
                                      float* dgamma_dbeta, float* partial, int rows, hipStream_t s) {
-  const int blocks = (rows + 15) / 16;
+  const int blocks = (rows + kLnRowsPerBlock - 1) / kLnRowsPerBlock;
   VETO_LAUNCH(layernorm_backward_kernel, dim3(blocks), dim3(256), 0, s, x, dy, gamma, dres, dx, partial, rows);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  VETO_LAUNCH(fold_rows_kernel, dim3((2 * kDim + 255) / 256), dim3(256), 0, s, partial, (long)(2 * kDim), blocks, 2 * kDim, dgamma_dbeta);
-  return hipGetLastError();
+  return launch_column_sums(partial, 2 * kDim, blocks, 2 * kDim, dgamma_dbeta, partial + (size_t)blocks * 2 * kDim, kColChunks, s);
 }
+
+int column_sums_chunks() { return kColChunks; }
 
 hipError_t launch_column_sums(const float* dy, long ld, int rows, int n_cols, float* out, float* partial, int n_chunks, hipStream_t s) {
   const int chunk = (rows + n_chunks - 1) / n_chunks;

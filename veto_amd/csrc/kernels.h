@@ -247,7 +247,8 @@ hipError_t launch_attention_backward(const float* qkv, const float* dout, float*
 size_t layernorm_backward_partial_floats(int rows);
 hipError_t launch_layernorm_backward(const float* x, const float* dy, const float* gamma, const float* dres, float* dx,
                                      float* dgamma_dbeta, float* partial, int rows, hipStream_t s);
-// out[c] = sum_r dy[r][c]; partial: workspace [n_chunks, n_cols]
+// out[c] = sum_r dy[r][c]; partial: workspace [n_chunks, n_cols]; column_sums_chunks() chunks keep every stage short
+int column_sums_chunks();
 hipError_t launch_column_sums(const float* dy, long ld, int rows, int n_cols, float* out, float* partial, int n_chunks, hipStream_t s);
 hipError_t launch_gelu_backward(const float* pre, const float* dh, float* dpre, size_t n, hipStream_t s);
 
@@ -255,8 +256,10 @@ hipError_t launch_gelu_backward(const float* pre, const float* dh, float* dpre, 
 hipError_t launch_transpose_from_split(const __bf16* src, long ld, int M, int K, __bf16* dst, int Mp, hipStream_t s);
 hipError_t launch_gelu_split(const float* pre, __bf16* dst, size_t rows, int n_cols, hipStream_t s);
 // dx[p*19, :] = dlogits[p] . W (other rows untouched); dw [n_out, 576], db [n_out]; x = token matrix [n_pair*19, 576]
-hipError_t launch_head_backward(const float* dlogits, const float* w, const float* x, float* dx, float* dw, float* db, int n_pair,
-                                int n_out, hipStream_t s);
+// partial: workspace of head_backward_partial_floats(n_out) floats
+size_t head_backward_partial_floats(int n_out);
+hipError_t launch_head_backward(const float* dlogits, const float* w, const float* x, float* dx, float* dw, float* db, float* partial,
+                                int n_pair, int n_out, hipStream_t s);
 hipError_t launch_assemble_backward(const float* dx, const int32_t* subj, const int32_t* obj, const float* lc, float* dpatch, float* dlc,
                                     int n_pair, hipStream_t s);
 hipError_t launch_sgemm_tn(const float* a, long lda, const float* b, long ldb, float* c, long ldc, int n, int ka, int kb, hipStream_t s);

@@ -79,18 +79,15 @@ __global__ __launch_bounds__(576) void head_dcls_kernel(const float* __restrict_
   dx[(size_t)p * kTokens * kDim + k] = acc;
 }
 
-// dW[c, k] = sum_p dlogits[p, c] x[p*19, k];  db[c] = sum_p dlogits[p, c]
+// dW[c, k] = sum_p dlogits[p, c] x[p*19, k]: pair chunk blockIdx.y writes partial[chunk, c, k]; a fixed-order fold
+// over the chunks follows (launch_column_sums on the [chunks, n_out*576] matrix)
 __global__ __launch_bounds__(576) void head_dw_kernel(const float* __restrict__ dlogits, const float* __restrict__ x,
-                                                      float* __restrict__ dw, float* __restrict__ db, int n_pair, int n_out) {
+                                                      float* __restrict__ partial, int n_pair, int n_out, int chunk) {
   const int c = blockIdx.x, k = threadIdx.x;
-  float acc = 0.f, accb = 0.f;
-  for (int p = 0; p < n_pair; ++p) {
-    const float g = dlogits[(size_t)p * n_out + c];
-    acc += g * x[(size_t)p * kTokens * kDim + k];
-    accb += g;
-  }
-  dw[(size_t)c * kDim + k] = acc;
-  if (k == 0) db[c] = accb;
+  const int p0 = blockIdx.y * chunk, p1 = p0 + chunk < n_pair ? p0 + chunk : n_pair;
+  float acc = 0.f;
+  for (int p = p0; p < p1; ++p) acc += dlogits[(size_t)p * n_out + c] * x[(size_t)p * kTokens * kDim + k];
+  partial[((size_t)blockIdx.y * n_out + c) * kDim + k] = acc;
 }
 
 // ---- token assembly backward: token gradients -> per-object tables -----------------------------------------------
@@ -280,13 +277,22 @@ hipError_t launch_gelu_split(const float* pre, __bf16* dst, size_t rows, int n_c
   return hipGetLastError();
 }
 
-hipError_t launch_head_backward(const float* dlogits, const float* w, const float* x, float* dx, float* dw, float* db, int n_pair,
-                                int n_out, hipStream_t s) {
+size_t head_backward_partial_floats(int n_out) {
+  const size_t a = (size_t)(64 + 8) * n_out * kDim, b = (size_t)column_sums_chunks() * n_out;
+  return a + b;
+}
+
+hipError_t launch_head_backward(const float* dlogits, const float* w, const float* x, float* dx, float* dw, float* db, float* partial,
+                                int n_pair, int n_out, hipStream_t s) {
   VETO_LAUNCH(head_dcls_kernel, dim3(n_pair), dim3(576), (size_t)n_out * 4, s, dlogits, w, dx, n_out);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  VETO_LAUNCH(head_dw_kernel, dim3(n_out), dim3(576), 0, s, dlogits, x, dw, db, n_pair, n_out);
-  return hipGetLastError();
+  const int n_chunks = 64, chunk = (n_pair + n_chunks - 1) / n_chunks;
+  VETO_LAUNCH(head_dw_kernel, dim3(n_out, n_chunks), dim3(576), 0, s, dlogits, x, partial, n_pair, n_out, chunk);
+  if ((e = hipGetLastError()) != hipSuccess) return e;
+  float* scratch = partial + (size_t)n_chunks * n_out * kDim;
+  if ((e = launch_column_sums(partial, (long)n_out * kDim, n_chunks, n_out * kDim, dw, scratch, 8, s)) != hipSuccess) return e;
+  return launch_column_sums(dlogits, n_out, n_pair, n_out, db, scratch, column_sums_chunks(), s);
 }
 
 hipError_t launch_assemble_backward(const float* dx, const int32_t* subj, const int32_t* obj, const float* lc, float* dpatch, float* dlc,

@@ -541,7 +541,7 @@ struct TrainWs {
   // backward scratch
   float *dx, *dmid, *dtmp, *dbig;
   __bf16 *dsplit, *at, *wt, *wdg;
-  float *ln_partial, *col_partial, *dgb;
+  float *ln_partial, *col_partial, *dgb, *head_partial;
   float *dpatch, *dlc, *dpos, *dpre, *xhat, *bn_out, *dbn_out, *emb, *demb, *prob, *dloc_wt, *dcls_wt, *dwcat_t;
   size_t mp2;    // padded reduction length of the weight-gradient GEMMs
   size_t total;
@@ -587,8 +587,9 @@ TrainWs carve_train(char* base, veto_handle_t h, int n_obj, int n_pair) {
   w.wt = (__bf16*)take((size_t)2 * kDim * w.mp2 * 4);
   w.wdg = (__bf16*)take((size_t)3 * kDim * kDim * 4);
   w.ln_partial = (float*)take(layernorm_backward_partial_floats((int)M) * 4);
-  w.col_partial = (float*)take((size_t)64 * kTokens * kDim * 4);
+  w.col_partial = (float*)take((size_t)column_sums_chunks() * 3 * kDim * 4);
   w.dgb = (float*)take(2 * kDim * 4);
+  w.head_partial = (float*)take(head_backward_partial_floats(h->cfg.num_out) * 4);
   w.dpatch = (float*)take((size_t)n_obj * 16 * 2 * kDim * 4);
   w.dlc = (float*)take((size_t)n_obj * 2 * 2 * kDim * 4);
   w.dpos = (float*)take((size_t)n_obj * kPosDim * 4);
@@ -780,20 +781,21 @@ int veto_backward(veto_handle_t h, void* stream, const veto_inputs_t* in, const 
 
   // ---- classifier head ----------------------------------------------------------------------------------------
   HIP_TRY(hipMemsetAsync(ws.dx, 0, (size_t)M * kDim * 4, s));
-  HIP_TRY(launch_head_backward(dlogits, h->p("rel_out.weight"), ws.xout, ws.dx, G("rel_out.weight"), G("rel_out.bias"), n_pair, n_out, s));
+  HIP_TRY(launch_head_backward(dlogits, h->p("rel_out.weight"), ws.xout, ws.dx, G("rel_out.weight"), G("rel_out.bias"), ws.head_partial,
+                               n_pair, n_out, s));
 
   // ---- transformer layers, last to first -------------------------------------------------------------------------
   for (int l = L - 1; l >= 0; --l) {
     const LayerW& w = h->layers[l];
     TrainLayer& t = ws.layers[l];
     // x_out = x_mid + gelu(LN2(x_mid) W1^T + b1) W2^T + b2
-    HIP_TRY(launch_column_sums(ws.dx, kDim, M, kDim, G(lname(l, "1.fn.net.3.bias")), ws.col_partial, 64, s));
+    HIP_TRY(launch_column_sums(ws.dx, kDim, M, kDim, G(lname(l, "1.fn.net.3.bias")), ws.col_partial, column_sums_chunks(), s));
     rc = run_wgrad(h, s, ws, ws.dx, kDim, M, kDim, t.hid, nullptr, 4 * kDim, 2 * kDim, G(lname(l, "1.fn.net.3.weight")));
     if (rc) return rc;
     rc = run_dgrad(h, s, ws, ws.dx, M, kDim, h->p(lname(l, "1.fn.net.3.weight")), 2 * kDim, ws.dbig);
     if (rc) return rc;
     HIP_TRY(launch_gelu_backward(t.pre, ws.dbig, ws.dbig, (size_t)M * 2 * kDim, s));
-    HIP_TRY(launch_column_sums(ws.dbig, 2 * kDim, M, 2 * kDim, G(lname(l, "1.fn.net.0.bias")), ws.col_partial, 64, s));
+    HIP_TRY(launch_column_sums(ws.dbig, 2 * kDim, M, 2 * kDim, G(lname(l, "1.fn.net.0.bias")), ws.col_partial, column_sums_chunks(), s));
     rc = run_wgrad(h, s, ws, ws.dbig, 2 * kDim, M, 2 * kDim, t.a2, nullptr, 2 * kDim, kDim, G(lname(l, "1.fn.net.0.weight")));
     if (rc) return rc;
     rc = run_dgrad(h, s, ws, ws.dbig, M, 2 * kDim, h->p(lname(l, "1.fn.net.0.weight")), kDim, ws.dtmp);
@@ -810,7 +812,7 @@ int veto_backward(veto_handle_t h, void* stream, const veto_inputs_t* in, const 
         dproj = ws.dtmp;
       }
     }
-    HIP_TRY(launch_column_sums(dproj, kDim, M, kDim, G(lname(l, "0.fn.to_out.0.bias")), ws.col_partial, 64, s));
+    HIP_TRY(launch_column_sums(dproj, kDim, M, kDim, G(lname(l, "0.fn.to_out.0.bias")), ws.col_partial, column_sums_chunks(), s));
     rc = run_wgrad(h, s, ws, dproj, kDim, M, kDim, t.ao, nullptr, 2 * kDim, kDim, G(lname(l, "0.fn.to_out.0.weight")));
     if (rc) return rc;
     rc = run_dgrad(h, s, ws, dproj, M, kDim, h->p(lname(l, "0.fn.to_out.0.weight")), kDim, ws.dtmp);
@@ -832,8 +834,8 @@ int veto_backward(veto_handle_t h, void* stream, const veto_inputs_t* in, const 
     const DropSite d = drop_site(opts, 2);   // pos_drop sits between (token + pos_embedding) and the first layer
     if (d.thresh) HIP_TRY(launch_dropout_apply(ws.dx, ws.dx, (size_t)M, kDim, d.seed, d.thresh, d.scale, s));
   }
-  HIP_TRY(launch_column_sums(ws.dx, kDim, M, kDim, G(T + "pos_embedding"), ws.col_partial, 64, s));
-  HIP_TRY(launch_column_sums(ws.dx, (long)kTokens * kDim, n_pair, kDim, G(T + "cls_token"), ws.col_partial, 64, s));
+  HIP_TRY(launch_column_sums(ws.dx, kDim, M, kDim, G(T + "pos_embedding"), ws.col_partial, column_sums_chunks(), s));
+  HIP_TRY(launch_column_sums(ws.dx, (long)kTokens * kDim, n_pair, kDim, G(T + "cls_token"), ws.col_partial, column_sums_chunks(), s));
   HIP_TRY(hipMemsetAsync(ws.dpatch, 0, (size_t)n_obj * 16 * 2 * kDim * 4, s));
   HIP_TRY(hipMemsetAsync(ws.dlc, 0, (size_t)n_obj * 2 * 2 * kDim * 4, s));
   HIP_TRY(launch_assemble_backward(ws.dx, ws.subj, ws.obj, ws.lc, ws.dpatch, ws.dlc, n_pair, s));
@@ -863,7 +865,7 @@ int veto_backward(veto_handle_t h, void* stream, const veto_inputs_t* in, const 
     }
     HIP_TRY(launch_patch_weight_grad(ws.dwcat_t, G(pe + "proj_d.weight"), G(pe + "proj_v.weight"), s));
     // biases: column sums of the subject half of dpatch: columns 0..511 -> proj_d.bias, 512..575 -> proj_v.bias
-    HIP_TRY(launch_column_sums(ws.dpatch, 2 * kDim, R, kDim, ws.dgb, ws.col_partial, 64, s));
+    HIP_TRY(launch_column_sums(ws.dpatch, 2 * kDim, R, kDim, ws.dgb, ws.col_partial, column_sums_chunks(), s));
     HIP_TRY(hipMemcpyAsync(G(pe + "proj_d.bias"), ws.dgb, 512 * 4, hipMemcpyDeviceToDevice, s));
     HIP_TRY(hipMemcpyAsync(G(pe + "proj_v.bias"), ws.dgb + 512, 64 * 4, hipMemcpyDeviceToDevice, s));
   }
@@ -872,8 +874,8 @@ int veto_backward(veto_handle_t h, void* stream, const veto_inputs_t* in, const 
   {
     const long ldlc = 2 * 2 * kDim;   // dlc row n = [location 1152 | class 1152]
     // biases sit on the subject half
-    HIP_TRY(launch_column_sums(ws.dlc, ldlc, n_obj, kDim, G("location_projection.0.bias"), ws.col_partial, 64, s));
-    HIP_TRY(launch_column_sums(ws.dlc + 2 * kDim, ldlc, n_obj, kDim, G("class_projection.0.bias"), ws.col_partial, 64, s));
+    HIP_TRY(launch_column_sums(ws.dlc, ldlc, n_obj, kDim, G("location_projection.0.bias"), ws.col_partial, column_sums_chunks(), s));
+    HIP_TRY(launch_column_sums(ws.dlc + 2 * kDim, ldlc, n_obj, kDim, G("class_projection.0.bias"), ws.col_partial, column_sums_chunks(), s));
     // position branch: recompute pos (post-ReLU) through the masked gradient path
     //   dpos = dlc_loc . loc_wt^T ; obj_pos_backward -> dpre (ReLU'), BatchNorm affine gradients
     HIP_TRY(launch_sgemm_nt(ws.dlc, ldlc, h->loc_wt, 2 * kDim, ws.dpos, kPosDim, n_obj, kPosDim, 2 * kDim, s));
@@ -884,7 +886,7 @@ int veto_backward(veto_handle_t h, void* stream, const veto_inputs_t* in, const 
                                     G("pos_embed.0.weight"), G("pos_embed.0.bias"), n_obj, s));
     // pos_embed.1: Linear(4, 128): dW[k, c] = sum_n dpre[n, k] bn_out[n, c]; db = column sums of dpre
     HIP_TRY(launch_sgemm_tn(ws.dpre, kPosDim, ws.bn_out, 4, G("pos_embed.1.weight"), 4, n_obj, kPosDim, 4, s));
-    HIP_TRY(launch_column_sums(ws.dpre, kPosDim, n_obj, kPosDim, G("pos_embed.1.bias"), ws.col_partial, 64, s));
+    HIP_TRY(launch_column_sums(ws.dpre, kPosDim, n_obj, kPosDim, G("pos_embed.1.bias"), ws.col_partial, column_sums_chunks(), s));
     // location_projection weight: d loc_wt[k, j] = sum_n pos[n, k] dlc_loc[n, j], pos = relu(pre): recompute pos = the
     // forward's value; it equals (dpre != 0 ? ... ) no -- recompute it from bn_out
     // pos[n, k] = relu(pos_b[k] + sum_c pos_w[k, c] bn_out[n, c]): one small product + ReLU, done by reusing dpos as storage
@@ -1316,8 +1318,8 @@ int veto_debug_gelu_backward(void* stream, const float* pre, const float* dh, fl
 int veto_debug_column_sums(void* stream, const float* dy, int64_t ld, int32_t rows, int32_t n_cols, float* out, void* workspace,
                            size_t workspace_bytes) {
   if (!dy || !out || !workspace || rows <= 0 || n_cols <= 0 || ld < n_cols) return fail(VETO_ERR_INVALID, "bad argument");
-  if (workspace_bytes < (size_t)64 * n_cols * 4) return fail(VETO_ERR_WORKSPACE, "workspace too small (64 * n_cols floats)");
-  HIP_TRY(launch_column_sums(dy, ld, rows, n_cols, out, (float*)workspace, 64, (hipStream_t)stream));
+  if (workspace_bytes < (size_t)column_sums_chunks() * n_cols * 4) return fail(VETO_ERR_WORKSPACE, "workspace too small (256 * n_cols floats)");
+  HIP_TRY(launch_column_sums(dy, ld, rows, n_cols, out, (float*)workspace, column_sums_chunks(), (hipStream_t)stream));
   return VETO_OK;
 }
 

@@ -378,7 +378,16 @@ class _TrainFn(torch.autograd.Function):
         lib = native.load_library()
         opts = owner._train_opts()
         need = lib.veto_train_workspace_bytes(eng.handle, inp.n_obj, inp.n_pair)
-        ws = torch.empty(need, dtype=torch.uint8, device=device)
+        # tens of GB: keep one workspace on the module and hand it to the next step once its backward has run (an
+        # allocation of this size goes to the driver every time, and releasing it synchronises the device)
+        ws = owner.__dict__.get("_train_ws")
+        if ws is None or ws.numel() < need or ws.device != device or owner.__dict__.get("_train_ws_busy", False):
+            ws = torch.empty(need, dtype=torch.uint8, device=device)
+            if not owner.__dict__.get("_train_ws_busy", False):
+                owner.__dict__["_train_ws"] = ws
+        ctx.owns_cached_ws = ws is owner.__dict__.get("_train_ws")
+        if ctx.owns_cached_ws:
+            owner.__dict__["_train_ws_busy"] = True
         out = torch.empty((inp.n_pair, owner._num_out), dtype=torch.float32, device=device)
         stream = torch.cuda.current_stream(device)
         native.check(lib.veto_forward_train(eng.handle, ctypes.c_void_p(stream.cuda_stream), ctypes.byref(inp), ctypes.byref(opts),
@@ -405,6 +414,8 @@ class _TrainFn(torch.autograd.Function):
         native.check(lib.veto_backward(eng.handle, ctypes.c_void_p(stream.cuda_stream), ctypes.byref(ctx.inp), ctypes.byref(ctx.opts),
                                        ctypes.c_void_p(ctx.ws.data_ptr()), ctx.ws.numel(), ctypes.c_void_p(dlogits.data_ptr()),
                                        ctypes.c_void_p(flat.data_ptr())))
+        if ctx.owns_cached_ws:
+            owner.__dict__["_train_ws_busy"] = False
         offsets = eng.weight_offsets()
         grads = []
         for prm, name, row0, rows in ctx.spec:
