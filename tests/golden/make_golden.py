@@ -408,6 +408,32 @@ def run_train_losses(P, cfg, BoxList, name, meet, beta_loss=False, dataset="VG",
     print("%-24s losses %s" % (name, {k: round(float(v.item()), 5) for k, v in res[2].items()}))
 
 
+def relsample_inputs(BoxList_cls):
+    props, targets = [], []
+    for boxes, rel in synth.synthetic_relation_targets():
+        b = torch.from_numpy(boxes)
+        t = BoxList_cls(b.clone(), (800, 600), mode="xyxy")
+        t.add_field("relation", torch.from_numpy(rel))
+        props.append(BoxList_cls(b, (800, 600), mode="xyxy"))
+        targets.append(t)
+    return props, targets
+
+
+def run_relsample(BoxList, name):
+    """The reference's RelationSampling.gtbox_relsample (sampling.py:54-107) with VETO_final.yaml's budget (1024 pairs per
+    image, a quarter of them foreground at most), torch seeded with 0."""
+    from pysgg.modeling.roi_heads.relation_head.sampling import RelationSampling
+    samp = RelationSampling(0.5, False, 4, 1024, 0.25, 2048, True, False)
+    props, targets = relsample_inputs(BoxList)
+    torch.manual_seed(0)
+    _, labels, pairs, binaries = samp.gtbox_relsample(props, targets)
+    out = {}
+    for i, (l, p, b) in enumerate(zip(labels, pairs, binaries)):
+        out["labels_%d" % i], out["pairs_%d" % i], out["binary_%d" % i] = l.numpy(), p.numpy(), b.numpy()
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print("%-24s %s pairs per image, foreground %s" % (name, [len(p) for p in pairs], [int((l > 0).sum()) for l in labels]))
+
+
 SGG_EVAL_CASES = {"sggeval_predcls": (31, [6, 9, 12, 3, 15, 20, 2, 8], "predcls"),
                   "sggeval_sgcls": (32, [6, 9, 12, 3, 15, 20, 2, 8], "sgcls")}
 
@@ -462,6 +488,9 @@ def run_sgg_eval(cfg, BoxList, name):
 def main():
     torch.set_num_threads(8)
     P, cfg, BoxList = import_reference()
+    if os.environ.get("GOLDEN_ONLY") == "relsample":
+        run_relsample(BoxList, "relsample_gtbox")
+        return
     if os.environ.get("GOLDEN_ONLY") == "train":   # regenerate only the training-loss fixtures
         run_train_losses(P, cfg, BoxList, "train_vanilla", meet=False)
         run_train_losses(P, cfg, BoxList, "train_vanilla_beta", meet=False, beta_loss=True)
@@ -480,6 +509,7 @@ def main():
         run_postprocessor_vote(cfg, BoxList, "postvote_gqa_c_n7", 7, "GQA", "C")
         run_case(P, cfg, BoxList, "meetx_n10_l4h8", "predcls", 4, 8, [10], meet=True, experts=True)
         return
+    run_relsample(BoxList, "relsample_gtbox")
     run_train_losses(P, cfg, BoxList, "train_vanilla", meet=False)
     run_train_losses(P, cfg, BoxList, "train_vanilla_beta", meet=False, beta_loss=True)
     run_train_losses(P, cfg, BoxList, "train_meet_vg", meet=True)

@@ -138,3 +138,26 @@ def test_synthetic_generators_are_bit_stable():
     for k in ("boxes", "labels", "roi_features", "predict_logits"):
         h.update(np.ascontiguousarray(b[k]).tobytes())
     assert h.hexdigest() == "5fffec42c9ef2181a42859be88e635aa1c1ff2db4c7890dd2ddc2d1cba19197e"
+
+
+def test_gtbox_relsample_matches_reference_sampler():
+    """veto_amd.sampling.RelationSampling.gtbox_relsample against the reference's own function run with the same torch
+    seed (tests/golden/relsample_gtbox.npz): same pairs, same labels, same order."""
+    import os
+    from conftest import GOLDEN_DIR
+    from veto_amd.sampling import make_roi_relation_samp_processor
+    props, targets = [], []
+    for boxes, rel in synth.synthetic_relation_targets():
+        props.append(BoxList(torch.from_numpy(boxes), (800, 600)))
+        t = BoxList(torch.from_numpy(boxes.copy()), (800, 600))
+        t.add_field("relation", torch.from_numpy(rel))
+        targets.append(t)
+    g = np.load(os.path.join(GOLDEN_DIR, "relsample_gtbox.npz"))
+    samp = make_roi_relation_samp_processor(testing.make_config(1, 8))
+    torch.manual_seed(0)
+    out_props, labels, pairs, binaries = samp.gtbox_relsample(props, targets)
+    assert out_props is props and all(p.get_field("locating_match").sum() == len(p) for p in props)
+    for i in range(len(props)):
+        assert np.array_equal(pairs[i].numpy(), g["pairs_%d" % i]) and np.array_equal(labels[i].numpy(), g["labels_%d" % i])
+        assert np.array_equal(binaries[i].numpy(), g["binary_%d" % i])
+    assert len(pairs[1]) == 1024 and int((labels[1] > 0).sum()) == 256 and len(pairs[3]) == 0     # budget hit; single object

@@ -285,3 +285,42 @@ def test_training_backward_matches_reference_gradients(name):
     # parameters the loss does not depend on stay without gradient (obj_embed2 in predcls, BatchNorm statistics)
     assert all(params[n].grad is None or float(params[n].grad.abs().max()) == 0.0 for n in params if n not in names)
     print("%s: worst relative gradient error %.2e over %d parameters" % (name, worst, len(names)))
+
+
+@pytest.mark.gpu
+def test_relation_head_training_branch_end_to_end():
+    """ROIRelationHead.forward in training mode on the device: GT-box relation sampling (budget 1024 / 25 % foreground),
+    ROI pooling from FPN + depth maps, the predictor's loss with an autograd graph whose backward fills the predictor's
+    parameter gradients (the ROI features are plain inputs of the predictor: the relation stage trains the head only)."""
+    from veto_amd import synth, testing
+    from veto_amd.relation_head import VETORelationHead
+    from veto_amd.structures import BoxList
+    dev = torch.device("cuda:0")
+    rng = np.random.RandomState(21)
+    W, H = 512, 384
+    feats = [torch.from_numpy((0.5 * rng.randn(2, 256, H >> (2 + l), W >> (2 + l))).astype(np.float32)).to(dev) for l in range(4)]
+    depth = torch.from_numpy((0.5 * rng.randn(2, 256, H >> 4, W >> 4)).astype(np.float32)).to(dev)
+    cfg = testing.make_config(2, 8)
+    head = VETORelationHead(cfg)
+    head.predictor = testing.make_predictor(cfg, synth.predictor_state_dict(3, layers=2), dev)
+    head.train()
+    props, targets = [], []
+    for i, (boxes, rel) in enumerate(synth.synthetic_relation_targets(num_objs=(7, 5))):
+        b = torch.from_numpy(boxes)
+        b[:, 2:] = b[:, :2] + b[:, 2:].abs() * 0.5 + 8
+        labels = torch.from_numpy(synth.integers(3, "head.labels.%d" % i, (len(boxes),), 1, 151))
+        p = BoxList(b, (W, H)).to(dev)
+        p.add_field("labels", labels.to(dev))
+        t = BoxList(b.clone(), (W, H)).to(dev)
+        t.add_field("relation", torch.from_numpy(rel).to(dev))
+        t.add_field("labels", labels.to(dev))
+        props.append(p)
+        targets.append(t)
+    torch.manual_seed(5)
+    roi, out_props, losses = head(feats, props, targets, None, depth_features=depth)
+    assert set(losses) == {"rel_loss"} and losses["rel_loss"].requires_grad and roi.shape == (12, 256, 8, 8)
+    assert all(p.has_field("locating_match") if hasattr(p, "has_field") else "locating_match" in p.extra_fields for p in out_props)
+    losses["rel_loss"].backward()
+    grads = [p.grad for p in head.predictor.parameters() if p.grad is not None]
+    assert len(grads) >= 30 and all(torch.isfinite(g).all() for g in grads)
+    assert float(head.predictor.rel_out.weight.grad.abs().max()) > 0

@@ -30,6 +30,10 @@ def default_config():
     rh.USE_GT_OBJECT_LABEL = True
     rh.POOLER_RESOLUTION = 8                      # VETO_final.yaml:57
     rh.MAX_PROPOSAL_PAIR = 2048
+    rh.BATCH_SIZE_PER_IMAGE = 1024                # VETO_final.yaml:64
+    rh.POSITIVE_FRACTION = 0.25                   # VETO_final.yaml:65
+    rh.NUM_SAMPLE_PER_GT_REL = 4                  # defaults.py:352
+    rh.REQUIRE_BOX_OVERLAP = False                # VETO_final.yaml:60
     rh.FEATURE_EXTRACTOR_MINI = "VETOFeatureExtractor"   # VETO_final.yaml:71
     rh.CONTEXT_HIDDEN_DIM = 512
     rh.CONTEXT_POOLING_DIM = 4096
@@ -40,6 +44,8 @@ def default_config():
     vt.NHEADS = 6
     vt.EMB_DROPOUT = 0.35
     vt.T_DROPOUT = 0.35
+    c.MODEL.ROI_HEADS = CfgNode()
+    c.MODEL.ROI_HEADS.FG_IOU_THRESHOLD = 0.5      # defaults.py:202
     bh = c.MODEL.ROI_BOX_HEAD = CfgNode()
     bh.FEATURE_EXTRACTOR = "FPN2MLPFeatureExtractor"       # VETO_final.yaml:41 (the detector's own box head)
     bh.POOLER_SCALES = (0.25, 0.125, 0.0625, 0.03125)      # VETO_final.yaml:39
@@ -61,6 +67,7 @@ def default_config():
     c.TEST = CfgNode()
     c.TEST.RELATION = CfgNode()
     c.TEST.RELATION.LATER_NMS_PREDICTION_THRES = 0.3
+    c.TEST.RELATION.REQUIRE_OVERLAP = False       # VETO_final.yaml:133
     c.GLOVE_DIR = ""
     # veto_amd extensions (absent from the reference config; read with getattr defaults)
     c.VETO_AMD = CfgNode()

@@ -19,6 +19,7 @@ from . import registry
 from .pairs import prepare_test_pairs
 from .poolers import make_roi_box_feature_extractor
 from .postprocess import make_roi_relation_post_processor
+from .sampling import make_roi_relation_samp_processor
 
 
 def to_onehot(vec, num_classes, fill=1000.0):
@@ -41,6 +42,7 @@ class VETORelationHead(nn.Module):
         self.box_feature_extractor = make_roi_box_feature_extractor(cfg, in_channels, for_relation=True)  # :53
         self.predictor = registry.make_roi_relation_predictor(cfg, in_channels)
         self.post_processor = make_roi_relation_post_processor(cfg)
+        self.samp_processor = make_roi_relation_samp_processor(cfg)
         self.num_obj_cls = self.predictor.num_obj_cls
         self.max_proposal_pairs = int(getattr(rh, "MAX_PROPOSAL_PAIR", 2048))
 
@@ -48,27 +50,40 @@ class VETORelationHead(nn.Module):
         """The reference's signature (:90): features = list of FPN maps [B, 256, H_l, W_l], depth_features =
         [B, 256, H/16, W/16], proposals = list[BoxList] (xyxy) on the HIP device.
         Returns (roi_features, result, {}) like the reference's test branch (:243)."""
-        if self.training:
-            raise NotImplementedError("veto_amd: the training branch (pair sampling, losses, backward) is not built")
         if depth_features is None:
             raise ValueError("the VETO predictors need depth_features (relation_head.py:141)")
+        if self.training:
+            # :112-121 GT-box relation sampling, :140-141 ROI features, :196-203 predictor -> losses, :247 return
+            if targets is None:
+                raise ValueError("training needs the targets (GT BoxLists with a 'relation' matrix)")
+            self._overload_predcls_fields(proposals, features[0].device)
+            with torch.no_grad():
+                proposals, rel_labels, rel_pair_idxs, _ = self.samp_processor.gtbox_relsample(proposals, targets)
+            roi_features, d_2d, _, _ = self.box_feature_extractor(features, proposals, depth_features=depth_features)
+            _, _, add_losses, _, _, _ = self.predictor(proposals, rel_pair_idxs, rel_labels, logger, roi_features=roi_features,
+                                                       roi_depth_features=d_2d)
+            return roi_features, proposals, add_losses
         roi_features, d_2d, _, _ = self.box_feature_extractor(features, proposals, depth_features=depth_features)
         return self.forward_pooled(proposals, roi_features, d_2d, logger)
+
+    def _overload_predcls_fields(self, proposals, device):
+        if self.mode != "predcls":
+            return
+        n_objs = [len(p) for p in proposals]   # :104-111, one batched one-hot instead of one per image
+        labels = torch.cat([p.get_field("labels") for p in proposals]).to(device)
+        onehot = to_onehot(labels, self.num_obj_cls).split(n_objs)
+        ones = torch.ones(labels.shape[0], device=device).split(n_objs)
+        for p, oh, sc, lab in zip(proposals, onehot, ones, labels.split(n_objs)):
+            p.add_field("predict_logits", oh)
+            p.add_field("pred_scores", sc)
+            p.add_field("pred_labels", lab)
 
     def forward_pooled(self, proposals, roi_features, roi_depth_features, logger=None):
         """Same, from already pooled ROI maps [sum N, 256, 8, 8] (the rest of :104-243)."""
         if self.training:
-            raise NotImplementedError("veto_amd: the training branch (pair sampling, losses, backward) is not built")
+            raise NotImplementedError("forward_pooled is the test-time tail; call forward(features, proposals, targets, ...) to train")
         device = roi_features.device
-        if self.mode == "predcls":   # :104-111, one batched one-hot instead of one per image
-            n_objs = [len(p) for p in proposals]
-            labels = torch.cat([p.get_field("labels") for p in proposals]).to(device)
-            onehot = to_onehot(labels, self.num_obj_cls).split(n_objs)
-            ones = torch.ones(labels.shape[0], device=device).split(n_objs)
-            for p, oh, sc, lab in zip(proposals, onehot, ones, labels.split(n_objs)):
-                p.add_field("predict_logits", oh)
-                p.add_field("pred_scores", sc)
-                p.add_field("pred_labels", lab)
+        self._overload_predcls_fields(proposals, device)
         rel_pair_idxs = prepare_test_pairs(device, proposals, self.max_proposal_pairs)
         obj_dists, relation_logits, add_losses, incre_idx_list, _, _ = self.predictor(
             proposals, rel_pair_idxs, None, logger, roi_features=roi_features, roi_depth_features=roi_depth_features)

@@ -254,3 +254,17 @@ def synthetic_eval_images(seed, num_objs, mode="predcls", num_rel_cls=51, num_ob
     filler[:, 2] = 1 + filler[:, 2] % (num_rel_cls - 1)
     zeroshot = np.concatenate([np.array(zs_rows, dtype=np.int64).reshape(-1, 3), filler.astype(np.int64)], 0)
     return images, zeroshot
+
+
+def synthetic_relation_targets(seed=41, num_objs=(6, 40, 3, 1), num_rel_cls=51):
+    """(boxes [n, 4], relation matrix [n, n]) per image for the training-time relation sampler: random predicate matrices,
+    one image with more foreground pairs than the positive budget, one with a single object (no candidate pair)."""
+    out = []
+    for i, n in enumerate(num_objs):
+        boxes = uniform(seed, "rs.boxes.%d" % i, (n, 4), 0.0, 300.0)
+        u = uniform01(seed, "rs.rel.%d" % i, n * n).reshape(n, n)
+        lab = integers(seed, "rs.lab.%d" % i, (n, n), 1, num_rel_cls)
+        rel = np.where(u < (0.5 if n >= 30 else 0.15), lab, 0)
+        np.fill_diagonal(rel, 0)
+        out.append((boxes, rel.astype(np.int64)))
+    return out
