@@ -330,21 +330,21 @@ def run_postprocessor_vote(cfg, BoxList, name, n, dataset, voting):
     print("%-24s expert voting %s: %d of %d rows kept" % (name, voting, out["rel_pair_idxs"].shape[0], len(sizes) * P_))
 
 
-def run_train_losses(P, cfg, BoxList, name, meet, beta_loss=False, dataset="VG", mode="predcls"):
+def run_train_losses(P, cfg, BoxList, name, meet, beta_loss=False, dataset="VG", mode="predcls", experts=False):
     """Training-mode forward of the reference predictor (dropout off, so it is deterministic) on a small batch with
     random relation labels: stores the classifier logits it produced (forward hooks on the rel_out modules), the
     labels, and the losses it returned.  MEET: also the expert sampling (`cur_chosen_matrix`), which the reference
     draws from Python's `random` (seeded with 1, tools/relation_train_net.py:44-50), and its sample_rate_matrix."""
     import random
     n_obj, n_rel = configure(P, cfg, mode, 2, 8, "VETOPredictor_MEET" if meet else "VETOPredictor", dataset)
-    cfg.ENSEMBLE_LEARNING.EXPERT_GROUP = False
+    cfg.ENSEMBLE_LEARNING.EXPERT_GROUP = bool(experts)
     cfg.GLOBAL_SETTING.BETA_LOSS = False
     torch.manual_seed(0)
     num_objs = [7, 5, 9]
     if meet:
         model = P.VETOPredictor_MEET(cfg, 512)
         groups = list(model.max_group_element_number_list)
-        sd = synth.meet_state_dict(0, groups, layers=2, num_obj_cls=n_obj)
+        sd = synth.meet_state_dict(0, groups, layers=2, num_obj_cls=n_obj, experts=3 if experts else 0)
     else:
         model = P.VETOPredictor(cfg, 512)
         sd = synth.predictor_state_dict(0, layers=2, num_obj_cls=n_obj, num_rel_cls=n_rel)
@@ -362,7 +362,7 @@ def run_train_losses(P, cfg, BoxList, name, meet, beta_loss=False, dataset="VG",
     labels = np.minimum(labels, n_rel - 1)
     rel_labels = torch.from_numpy(labels)
     captured = {}
-    heads = list(model.model.rel_out) if meet else [model.rel_out]
+    heads = ([h for lst in model.model.rel_out_group for h in lst] if experts else list(model.model.rel_out)) if meet else [model.rel_out]
     hooks = [h.register_forward_hook(lambda mod, i, o, k=k: captured.__setitem__(k, o.detach().clone())) for k, h in enumerate(heads)]
     if beta_loss:   # roi_relation_predictors.py:4057-4066 with the counts of pred_counts.pkl (the path there is absolute)
         import pickle
@@ -378,7 +378,7 @@ def run_train_losses(P, cfg, BoxList, name, meet, beta_loss=False, dataset="VG",
     for h in hooks:
         h.remove()
     out = {"labels": labels, "meet": int(meet), "dataset": dataset, "beta_loss": int(beta_loss), "num_objs": np.array(num_objs),
-           "mode": mode}
+           "mode": mode, "experts": int(bool(experts))}
     # gradients of the summed losses w.r.t. every parameter (the reference's training loop sums the loss dict,
     # engine/trainer + tools/relation_train_net.py:297): stored as norm + a strided sample (full tensor when small)
     sum(res[2].values()).backward()
@@ -498,6 +498,7 @@ def main():
         run_train_losses(P, cfg, BoxList, "train_meet_gqa", meet=True, dataset="GQA")
         run_train_losses(P, cfg, BoxList, "train_vanilla_sgcls", meet=False, mode="sgcls")
         run_train_losses(P, cfg, BoxList, "train_meet_sgcls", meet=True, mode="sgcls")
+        run_train_losses(P, cfg, BoxList, "train_meet_experts", meet=True, experts=True)
         return
     if os.environ.get("GOLDEN_ONLY") == "sggeval":   # regenerate only the evaluator fixtures
         for name in SGG_EVAL_CASES:
@@ -516,6 +517,7 @@ def main():
     run_train_losses(P, cfg, BoxList, "train_meet_gqa", meet=True, dataset="GQA")
     run_train_losses(P, cfg, BoxList, "train_vanilla_sgcls", meet=False, mode="sgcls")
     run_train_losses(P, cfg, BoxList, "train_meet_sgcls", meet=True, mode="sgcls")
+    run_train_losses(P, cfg, BoxList, "train_meet_experts", meet=True, experts=True)
     for name in SGG_EVAL_CASES:
         run_sgg_eval(cfg, BoxList, name)
     run_postprocessor_vote(cfg, BoxList, "postvote_vg_c_n10", 10, "VG", "C")

@@ -14,6 +14,7 @@ from veto_amd import meet_tables
 
 CASES_VANILLA = ["train_vanilla", "train_vanilla_beta", "train_vanilla_sgcls"]
 CASES_MEET = ["train_meet_vg", "train_meet_gqa", "train_meet_sgcls"]
+CASES_EXPERTS = ["train_meet_experts"]     # EXPERT_GROUP: 3 experts per group, 15 heads
 
 
 def _load(name):
@@ -113,8 +114,10 @@ def _train_setup(name, meet, dev, forward_only=True):
     if int(g["beta_loss"]):
         cfg.GLOBAL_SETTING.BETA_LOSS = True
         cfg.GLOBAL_SETTING.REL_COUNTS = np.loadtxt(os.path.join(GOLDEN_DIR, "pred_counts.txt")).tolist()
+    experts = bool(int(g.get("experts", 0)))
+    cfg.ENSEMBLE_LEARNING.EXPERT_GROUP = experts
     if meet:
-        sd = synth.meet_state_dict(0, [int(x) for x in g["group_sizes"]], layers=2, num_obj_cls=n_obj_cls)
+        sd = synth.meet_state_dict(0, [int(x) for x in g["group_sizes"]], layers=2, num_obj_cls=n_obj_cls, experts=3 if experts else 0)
     else:
         sd = synth.predictor_state_dict(0, layers=2, num_obj_cls=n_obj_cls, num_rel_cls=51 if dataset == "VG" else 101)
     if int(g["beta_loss"]):
@@ -129,7 +132,7 @@ def _train_setup(name, meet, dev, forward_only=True):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", CASES_VANILLA + CASES_MEET)
+@pytest.mark.parametrize("name", CASES_VANILLA + CASES_MEET + CASES_EXPERTS)
 def test_training_mode_forward_reproduces_reference_losses(name):
     """The predictor in .train() (forward + losses only, VETO_AMD.TRAIN_FORWARD_ONLY, dropout off): BatchNorm on batch
     statistics, relation loss / MEET group losses as the reference returned them for the same weights, inputs, labels
@@ -137,7 +140,7 @@ def test_training_mode_forward_reproduces_reference_losses(name):
     from veto_amd import testing
     from veto_amd.pairs import prepare_test_pairs
     dev = torch.device("cuda:0")
-    meet = name in CASES_MEET
+    meet = name in CASES_MEET + CASES_EXPERTS
     g, model, batch, num_objs = _train_setup(name, meet, dev)
     props = testing.make_proposals(batch, str(g["mode"]), dev)
     pairs = prepare_test_pairs(dev, props)
@@ -245,7 +248,7 @@ def test_training_steps_reduce_the_loss():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", CASES_VANILLA + CASES_MEET)
+@pytest.mark.parametrize("name", CASES_VANILLA + CASES_MEET + CASES_EXPERTS)
 def test_training_backward_matches_reference_gradients(name):
     """loss.backward() through the HIP training path (veto_forward_train / veto_backward / veto_ce_loss) against the
     gradients the reference's autograd produced for the same weights, inputs, labels and random seed: every parameter's
@@ -253,7 +256,7 @@ def test_training_backward_matches_reference_gradients(name):
     from veto_amd import testing
     from veto_amd.pairs import prepare_test_pairs
     dev = torch.device("cuda:0")
-    meet = name in CASES_MEET
+    meet = name in CASES_MEET + CASES_EXPERTS
     g, model, batch, num_objs = _train_setup(name, meet, dev, forward_only=False)
     props = testing.make_proposals(batch, str(g["mode"]), dev)
     pairs = prepare_test_pairs(dev, props)
@@ -266,7 +269,7 @@ def test_training_backward_matches_reference_gradients(name):
         assert abs(float(val.detach()) - ref) < 2e-4 * max(1.0, abs(ref)), (key, float(val.detach()), ref)
     sum(out[2].values()).backward()
     torch.cuda.synchronize()
-    params = dict(model.named_parameters())
+    params = dict(model.named_parameters(remove_duplicate=False))     # EXPERT_GROUP: rel_out aliases the last expert's heads
     names = [k[9:] for k in g if k.startswith("gradnorm_")]
     assert names
     worst = 0.0
@@ -283,7 +286,8 @@ def test_training_backward_matches_reference_gradients(name):
         worst = max(worst, err, nerr)
         assert err < 2e-3 and nerr < 2e-3, (pname, err, nerr, ref_norm)
     # parameters the loss does not depend on stay without gradient (obj_embed2 in predcls, BatchNorm statistics)
-    assert all(params[n].grad is None or float(params[n].grad.abs().max()) == 0.0 for n in params if n not in names)
+    used = {id(params[n]) for n in names}
+    assert all(p.grad is None or float(p.grad.abs().max()) == 0.0 for p in params.values() if id(p) not in used)
     print("%s: worst relative gradient error %.2e over %d parameters" % (name, worst, len(names)))
 
 

@@ -572,9 +572,6 @@ class VETOPredictor_MEET(nn.Module, _NativeForward):
 
     def forward(self, proposals, rel_pair_idxs, rel_labels, logger, roi_features=None,
                 roi_depth_features=None, rel_binarys=None):
-        if self.training:
-            if self.expert_group:
-                raise NotImplementedError("veto_amd: training of the EXPERT_GROUP heads is not built")
         if self.mode == "predcls":
             labels = _cat_field(proposals, "labels").long()
             dist_labels = labels
@@ -597,11 +594,13 @@ class VETOPredictor_MEET(nn.Module, _NativeForward):
                                                     zero_label_padding_mode=self._zero_label_padding_mode)
             chosen, group_labels = self._sampler.sample(torch.cat(list(rel_labels), 0))
             add_losses, col = {}, 0
-            for k, g in enumerate(self.max_group_element_number_list):
-                sl = rel[:, col:col + g + 2]
-                add_losses["group_%d_CE_loss" % k] = relation_ce_loss(sl, group_labels[k], rows=chosen[k])[0][0] \
-                    if self._train_forward_only else ce_loss(sl, group_labels[k], rows=chosen[k])
-                col += g + 2
+            for e in range(self.experts_per_group):      # :3833-3846: every expert of a group sees the same rows and labels
+                for k, g in enumerate(self.max_group_element_number_list):
+                    sl = rel[:, col:col + g + 2]
+                    key = "group_%d%d_CE_loss" % (k, e + 1) if self.expert_group else "group_%d_CE_loss" % k
+                    add_losses[key] = relation_ce_loss(sl, group_labels[k], rows=chosen[k])[0][0] \
+                        if self._train_forward_only else ce_loss(sl, group_labels[k], rows=chosen[k])
+                    col += g + 2
             if self.mode != "predcls":   # :3823-3827
                 obj_logits = _cat_field(proposals, "predict_logits").detach()
                 add_losses["obj_loss"] = relation_ce_loss(obj_logits.to(rel.device), _cat_field(proposals, "labels").long())[0][0]
