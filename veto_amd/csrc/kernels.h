@@ -254,6 +254,10 @@ hipError_t launch_gelu_backward(const float* pre, const float* dh, float* dpre, 
 
 // ---- training path around the GEMMs (train.hip) ---------------------------------------------------------------
 hipError_t launch_transpose_from_split(const __bf16* src, long ld, int M, int K, __bf16* dst, int Mp, hipStream_t s);
+// dY fp32 [M, N] -> split rows [M, 2N], split rows of the transpose [N, 2*Mp] and (optional) per-32-row column sums
+// col_partial [Mp/32, N] in one pass
+hipError_t launch_prep_grad(const float* src, long ld, int M, int N, __bf16* rows_out, __bf16* t_out, int Mp, float* col_partial,
+                            hipStream_t s);
 hipError_t launch_gelu_split(const float* pre, __bf16* dst, size_t rows, int n_cols, hipStream_t s);
 // dx[p*19, :] = dlogits[p] . W (other rows untouched); dw [n_out, 576], db [n_out]; x = token matrix [n_pair*19, 576]
 // partial: workspace of head_backward_partial_floats(n_out) floats

@@ -42,6 +42,62 @@ __global__ __launch_bounds__(256) void transpose_from_split_kernel(const __bf16*
   }
 }
 
+// ---- one pass over a gradient matrix dY fp32 [M, N]: split rows (A operand of the input-gradient GEMM), split rows of the
+// transpose (operand of the weight-gradient GEMM) and, optionally, per-block column sums (bias gradient, folded later).
+// 32 (m) x 64 (n) tile through LDS; the three consumers used to read dY once each.
+__global__ __launch_bounds__(256) void prep_grad_kernel(const float* __restrict__ src, long ld, int M, int N, __bf16* __restrict__ rows_out,
+                                                        __bf16* __restrict__ t_out, int Mp, float* __restrict__ col_partial) {
+  __shared__ float t[32][65];
+  const int m0 = blockIdx.x * 32, n0 = blockIdx.y * 64, tid = threadIdx.x;
+  const int tx = tid & 63, ty = tid >> 6;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int m = m0 + ty * 8 + i, n = n0 + tx;
+    t[ty * 8 + i][tx] = (m < M && n < N) ? src[(size_t)m * ld + n] : 0.f;
+  }
+  __syncthreads();
+  // transposed split rows: output row n receives the 32-m block [hi | lo]
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const int id = tid + 256 * r, nl = id >> 3, piece = id & 7;
+    if (n0 + nl < N) {
+      bf16x8 out;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        __bf16 h, l;
+        split_bf16(t[8 * (piece & 3) + e][nl], h, l);
+        out[e] = piece < 4 ? h : l;
+      }
+      __bf16* d = t_out + (size_t)(n0 + nl) * (2 * (size_t)Mp) + (size_t)(m0 >> 5) * 64 + (piece < 4 ? 8 * piece : 32 + 8 * (piece - 4));
+      *(bf16x8*)d = out;
+    }
+  }
+  // split rows: row m, the two 32-column blocks of this tile; one 8-column piece per thread
+  {
+    const int ml = tid >> 3, piece = tid & 7;       // 32 rows x 8 pieces of 8 columns
+    const int m = m0 + ml, c = n0 + piece * 8;
+    if (m < M && c < N) {
+      bf16x8 hi, lo;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        __bf16 h, l;
+        split_bf16(t[ml][piece * 8 + e], h, l);
+        hi[e] = h;
+        lo[e] = l;
+      }
+      __bf16* d = rows_out + (size_t)m * (2 * (size_t)N) + split_index(c);
+      *(bf16x8*)d = hi;
+      *(bf16x8*)(d + 32) = lo;
+    }
+  }
+  if (col_partial && tid < 64 && n0 + tid < N) {
+    float acc = 0.f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) acc += t[i][tid];
+    col_partial[(size_t)blockIdx.x * N + n0 + tid] = acc;
+  }
+}
+
 // ---- hid = split(gelu(pre)), pre fp32 [rows, n_cols] (n_cols % 4 == 0) --------------------------------------------
 __global__ __launch_bounds__(256) void gelu_split_kernel(const float* __restrict__ pre, __bf16* __restrict__ dst, size_t rows,
                                                          int n_cols) {
@@ -266,6 +322,13 @@ __global__ __launch_bounds__(256) void patch_weight_grad_kernel(const float* __r
 hipError_t launch_transpose_from_split(const __bf16* src, long ld, int M, int K, __bf16* dst, int Mp, hipStream_t s) {
   if (Mp % 32 != 0 || Mp < M) return hipErrorInvalidValue;
   VETO_LAUNCH(transpose_from_split_kernel, dim3(Mp / 32, (K + 63) / 64), dim3(256), 0, s, src, ld, M, K, dst, Mp);
+  return hipGetLastError();
+}
+
+hipError_t launch_prep_grad(const float* src, long ld, int M, int N, __bf16* rows_out, __bf16* t_out, int Mp, float* col_partial,
+                            hipStream_t s) {
+  if (Mp % 32 != 0 || Mp < M || N % 32 != 0) return hipErrorInvalidValue;
+  VETO_LAUNCH(prep_grad_kernel, dim3(Mp / 32, (N + 63) / 64), dim3(256), 0, s, src, ld, M, N, rows_out, t_out, Mp, col_partial);
   return hipGetLastError();
 }
 

@@ -541,7 +541,7 @@ struct TrainWs {
   // backward scratch
   float *dx, *dmid, *dtmp, *dbig;
   __bf16 *dsplit, *at, *wt, *wdg;
-  float *ln_partial, *col_partial, *dgb, *head_partial;
+  float *ln_partial, *col_partial, *colp, *dgb, *head_partial;
   float *dpatch, *dlc, *dpos, *dpre, *xhat, *bn_out, *dbn_out, *emb, *demb, *prob, *dloc_wt, *dcls_wt, *dwcat_t;
   size_t mp2;    // padded reduction length of the weight-gradient GEMMs
   size_t total;
@@ -588,6 +588,7 @@ TrainWs carve_train(char* base, veto_handle_t h, int n_obj, int n_pair) {
   w.wdg = (__bf16*)take((size_t)3 * kDim * kDim * 4);
   w.ln_partial = (float*)take(layernorm_backward_partial_floats((int)M) * 4);
   w.col_partial = (float*)take((size_t)column_sums_chunks() * 3 * kDim * 4);
+  w.colp = (float*)take((w.mp2 / 32) * 3 * kDim * 4);
   w.dgb = (float*)take(2 * kDim * 4);
   w.head_partial = (float*)take(head_backward_partial_floats(h->cfg.num_out) * 4);
   w.dpatch = (float*)take((size_t)n_obj * 16 * 2 * kDim * 4);
@@ -607,9 +608,10 @@ TrainWs carve_train(char* base, veto_handle_t h, int n_obj, int n_pair) {
   return w;
 }
 
-// dW[N, K] = dY[M, N]^T . X[M, K] with X in split rows (x_split) or fp32 (x_f32); K % 192 == 0
-int run_wgrad(veto_handle_t h, hipStream_t s, const TrainWs& w, const float* dy, long ld_dy, int M, int N, const __bf16* x_split,
-              const float* x_f32, long ld_x, int K, float* dw) {
+// Backward of y = x W^T (+ b) over the token rows: dW[N, K] = dY^T x, db[N] = column sums of dY (if db), dX[M, K] = dY W.
+// One pass over dY (prep_grad_kernel) produces both GEMM operands and the bias partials.
+int run_linear_backward(veto_handle_t h, hipStream_t s, const TrainWs& w, const float* dy, int M, int N, const __bf16* x_split, int K,
+                        const float* weight, float* dw, float* db, float* dx) {
   const int out_tiles = ((N + 255) / 256) * (K / 192);
   int ks = 2 * 256 / out_tiles;
   const int max_ks = (M + 32 * 64 - 1) / (32 * 64);
@@ -618,27 +620,25 @@ int run_wgrad(veto_handle_t h, hipStream_t s, const TrainWs& w, const float* dy,
   if (ks < 1) ks = 1;
   const size_t mp = ((size_t)M + 32 * (size_t)ks - 1) / (32 * (size_t)ks) * 32 * (size_t)ks;
   if (mp > w.mp2) return fail(VETO_ERR_WORKSPACE, "weight-gradient operand buffer too small");
-  HIP_TRY(launch_transpose_split(dy, ld_dy, M, N, w.at, (int)mp, s));
-  if (x_split) HIP_TRY(launch_transpose_from_split(x_split, ld_x, M, K, w.wt, (int)mp, s));
-  else HIP_TRY(launch_transpose_split(x_f32, ld_x, M, K, w.wt, (int)mp, s));
+  HIP_TRY(launch_prep_grad(dy, N, M, N, w.dsplit, w.at, (int)mp, db ? w.colp : nullptr, s));
+  if (db) HIP_TRY(launch_column_sums(w.colp, N, (int)(mp / 32), N, db, w.col_partial, column_sums_chunks(), s));
+  HIP_TRY(launch_transpose_from_split(x_split, 2 * (long)K, M, K, w.wt, (int)mp, s));
   HIP_TRY(hipMemsetAsync(dw, 0, (size_t)N * K * 4, s));
-  GemmArgs g{};
-  g.a = w.at; g.w = w.wt; g.c = dw;
-  g.M = N; g.N = K; g.K = (int)mp; g.ldc = K; g.k_splits = ks;
-  ProfScope ps(h, s, "bwd_wgrad", 2.0 * M * (double)N * K, 0);
-  HIP_TRY(launch_gemm_split(g, EPI_ATOMIC, 0, s));
-  return VETO_OK;
-}
-
-// dX[M, K] = dY[M, N] . W[N, K]: dY is split into w.dsplit, W^T into w.wdg, then the forward GEMM kernel
-int run_dgrad(veto_handle_t h, hipStream_t s, const TrainWs& w, const float* dy, int M, int N, const float* weight, int K, float* dx) {
-  HIP_TRY(launch_split_rows(dy, w.dsplit, (size_t)M, N, s));
+  {
+    GemmArgs g{};
+    g.a = w.at; g.w = w.wt; g.c = dw;
+    g.M = N; g.N = K; g.K = (int)mp; g.ldc = K; g.k_splits = ks;
+    ProfScope ps(h, s, "bwd_wgrad", 2.0 * M * (double)N * K, 0);
+    HIP_TRY(launch_gemm_split(g, EPI_ATOMIC, 0, s));
+  }
   HIP_TRY(launch_transpose_split(weight, K, N, K, w.wdg, N, s));     // W [N, K] -> W^T split rows [K, 2N]
-  GemmArgs g{};
-  g.a = w.dsplit; g.w = w.wdg; g.c = dx;
-  g.M = M; g.N = K; g.K = N; g.ldc = K;
-  ProfScope ps(h, s, "bwd_dgrad", 2.0 * M * (double)N * K, 0);
-  HIP_TRY(launch_gemm_split(g, EPI_F32, 0, s));
+  {
+    GemmArgs g{};
+    g.a = w.dsplit; g.w = w.wdg; g.c = dx;
+    g.M = M; g.N = K; g.K = N; g.ldc = K;
+    ProfScope ps(h, s, "bwd_dgrad", 2.0 * M * (double)N * K, 0);
+    HIP_TRY(launch_gemm_split(g, EPI_F32, 0, s));
+  }
   return VETO_OK;
 }
 
@@ -789,16 +789,12 @@ int veto_backward(veto_handle_t h, void* stream, const veto_inputs_t* in, const 
     const LayerW& w = h->layers[l];
     TrainLayer& t = ws.layers[l];
     // x_out = x_mid + gelu(LN2(x_mid) W1^T + b1) W2^T + b2
-    HIP_TRY(launch_column_sums(ws.dx, kDim, M, kDim, G(lname(l, "1.fn.net.3.bias")), ws.col_partial, column_sums_chunks(), s));
-    rc = run_wgrad(h, s, ws, ws.dx, kDim, M, kDim, t.hid, nullptr, 4 * kDim, 2 * kDim, G(lname(l, "1.fn.net.3.weight")));
-    if (rc) return rc;
-    rc = run_dgrad(h, s, ws, ws.dx, M, kDim, h->p(lname(l, "1.fn.net.3.weight")), 2 * kDim, ws.dbig);
+    rc = run_linear_backward(h, s, ws, ws.dx, M, kDim, t.hid, 2 * kDim, h->p(lname(l, "1.fn.net.3.weight")),
+                             G(lname(l, "1.fn.net.3.weight")), G(lname(l, "1.fn.net.3.bias")), ws.dbig);
     if (rc) return rc;
     HIP_TRY(launch_gelu_backward(t.pre, ws.dbig, ws.dbig, (size_t)M * 2 * kDim, s));
-    HIP_TRY(launch_column_sums(ws.dbig, 2 * kDim, M, 2 * kDim, G(lname(l, "1.fn.net.0.bias")), ws.col_partial, column_sums_chunks(), s));
-    rc = run_wgrad(h, s, ws, ws.dbig, 2 * kDim, M, 2 * kDim, t.a2, nullptr, 2 * kDim, kDim, G(lname(l, "1.fn.net.0.weight")));
-    if (rc) return rc;
-    rc = run_dgrad(h, s, ws, ws.dbig, M, 2 * kDim, h->p(lname(l, "1.fn.net.0.weight")), kDim, ws.dtmp);
+    rc = run_linear_backward(h, s, ws, ws.dbig, M, 2 * kDim, t.a2, kDim, h->p(lname(l, "1.fn.net.0.weight")),
+                             G(lname(l, "1.fn.net.0.weight")), G(lname(l, "1.fn.net.0.bias")), ws.dtmp);
     if (rc) return rc;
     HIP_TRY(launch_layernorm_backward(t.xmid, ws.dtmp, w.ln2_w, ws.dx, ws.dmid, ws.dgb, ws.ln_partial, M, s));
     HIP_TRY(hipMemcpyAsync(G(lname(l, "1.norm.weight")), ws.dgb, kDim * 4, hipMemcpyDeviceToDevice, s));
@@ -812,15 +808,12 @@ int veto_backward(veto_handle_t h, void* stream, const veto_inputs_t* in, const 
         dproj = ws.dtmp;
       }
     }
-    HIP_TRY(launch_column_sums(dproj, kDim, M, kDim, G(lname(l, "0.fn.to_out.0.bias")), ws.col_partial, column_sums_chunks(), s));
-    rc = run_wgrad(h, s, ws, dproj, kDim, M, kDim, t.ao, nullptr, 2 * kDim, kDim, G(lname(l, "0.fn.to_out.0.weight")));
-    if (rc) return rc;
-    rc = run_dgrad(h, s, ws, dproj, M, kDim, h->p(lname(l, "0.fn.to_out.0.weight")), kDim, ws.dtmp);
+    rc = run_linear_backward(h, s, ws, dproj, M, kDim, t.ao, kDim, h->p(lname(l, "0.fn.to_out.0.weight")),
+                             G(lname(l, "0.fn.to_out.0.weight")), G(lname(l, "0.fn.to_out.0.bias")), ws.dtmp);
     if (rc) return rc;
     HIP_TRY(launch_attention_backward(t.qkv, ws.dtmp, ws.dbig, n_pair, H, s));
-    rc = run_wgrad(h, s, ws, ws.dbig, 3 * kDim, M, 3 * kDim, t.a1, nullptr, 2 * kDim, kDim, G(lname(l, "0.fn.to_qkv.weight")));
-    if (rc) return rc;
-    rc = run_dgrad(h, s, ws, ws.dbig, M, 3 * kDim, h->p(lname(l, "0.fn.to_qkv.weight")), kDim, ws.dtmp);
+    rc = run_linear_backward(h, s, ws, ws.dbig, M, 3 * kDim, t.a1, kDim, h->p(lname(l, "0.fn.to_qkv.weight")),
+                             G(lname(l, "0.fn.to_qkv.weight")), nullptr, ws.dtmp);
     if (rc) return rc;
     HIP_TRY(launch_layernorm_backward(t.xin, ws.dtmp, w.ln1_w, ws.dmid, ws.dx, ws.dgb, ws.ln_partial, M, s));
     HIP_TRY(hipMemcpyAsync(G(lname(l, "0.norm.weight")), ws.dgb, kDim * 4, hipMemcpyDeviceToDevice, s));
