@@ -13,19 +13,21 @@ namespace {
 
 constexpr int kColChunks = 256;    // row chunks of the two-stage column sums (fixed order -> deterministic)
 
-// One wave per (pair, head), everything in fp32.  With S = q k^T * scale, P = softmax(S), O = P v:
+constexpr int kAttnBwdThreads = 256;
+
+// One workgroup of four waves per (pair, head), everything in fp32.  With S = q k^T * scale, P = softmax(S), O = P v:
 //   dV = P^T dO,  dP = dO v^T,  dS = P * (dP - rowsum(dP * P)),  dQ = dS k * scale,  dK = dS^T q * scale.
 template <int DH>
-__global__ __launch_bounds__(64) void attention_backward_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
+__global__ __launch_bounds__(kAttnBwdThreads) void attention_backward_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
                                                                 float* __restrict__ dqkv, int n_pair, int heads) {
   constexpr int LD = DH + 1;                  // padded row stride: column walks hit distinct banks
   __shared__ float q[kTokens * LD], k[kTokens * LD], v[kTokens * LD], go[kTokens * LD];
   __shared__ float p[kTokens * 20], ds[kTokens * 20];
-  const int item = blockIdx.x, pair = item / heads, head = item % heads, lane = threadIdx.x;
+  const int item = blockIdx.x, pair = item / heads, head = item % heads, lane = threadIdx.x;   // index inside the workgroup that owns this (pair, head)
   if (pair >= n_pair) return;
   const float* src = qkv + (size_t)pair * kTokens * (3 * kDim) + head * DH;
   const float* gsrc = dout + (size_t)pair * kTokens * kDim + head * DH;
-  for (int e = lane; e < kTokens * DH; e += 64) {
+  for (int e = lane; e < kTokens * DH; e += kAttnBwdThreads) {
     const int t = e / DH, d = e % DH;
     q[t * LD + d] = src[(size_t)t * 3 * kDim + d];
     k[t * LD + d] = src[(size_t)t * 3 * kDim + kDim + d];
@@ -34,7 +36,7 @@ __global__ __launch_bounds__(64) void attention_backward_kernel(const float* __r
   }
   __syncthreads();
   const float scale = 1.0f / sqrtf((float)DH);
-  for (int e = lane; e < kTokens * kTokens; e += 64) {   // S and dP
+  for (int e = lane; e < kTokens * kTokens; e += kAttnBwdThreads) {   // S and dP
     const int i = e / kTokens, j = e % kTokens;
     float s = 0.f, dp = 0.f;
     for (int d = 0; d < DH; ++d) { s += q[i * LD + d] * k[j * LD + d]; dp += go[i * LD + d] * v[j * LD + d]; }
@@ -56,7 +58,7 @@ __global__ __launch_bounds__(64) void attention_backward_kernel(const float* __r
   }
   __syncthreads();
   float* dst = dqkv + (size_t)pair * kTokens * (3 * kDim) + head * DH;
-  for (int e = lane; e < kTokens * DH; e += 64) {
+  for (int e = lane; e < kTokens * DH; e += kAttnBwdThreads) {
     const int t = e / DH, d = e % DH;
     float dq = 0.f, dk = 0.f, dv = 0.f;
     for (int j = 0; j < kTokens; ++j) {
@@ -200,9 +202,9 @@ hipError_t launch_attention_backward(const float* qkv, const float* dout, float*
   if (heads <= 0 || kDim % heads != 0) return hipErrorInvalidValue;
   const int dh = kDim / heads;
   const unsigned blocks = (unsigned)((long)n_pair * heads);
-  if (dh == 72) VETO_LAUNCH(attention_backward_kernel<72>, dim3(blocks), dim3(64), 0, s, qkv, dout, dqkv, n_pair, heads);
-  else if (dh == 96) VETO_LAUNCH(attention_backward_kernel<96>, dim3(blocks), dim3(64), 0, s, qkv, dout, dqkv, n_pair, heads);
-  else if (dh == 144) VETO_LAUNCH(attention_backward_kernel<144>, dim3(blocks), dim3(64), 0, s, qkv, dout, dqkv, n_pair, heads);
+  if (dh == 72) VETO_LAUNCH(attention_backward_kernel<72>, dim3(blocks), dim3(kAttnBwdThreads), 0, s, qkv, dout, dqkv, n_pair, heads);
+  else if (dh == 96) VETO_LAUNCH(attention_backward_kernel<96>, dim3(blocks), dim3(kAttnBwdThreads), 0, s, qkv, dout, dqkv, n_pair, heads);
+  else if (dh == 144) VETO_LAUNCH(attention_backward_kernel<144>, dim3(blocks), dim3(kAttnBwdThreads), 0, s, qkv, dout, dqkv, n_pair, heads);
   else return hipErrorInvalidValue;
   return hipGetLastError();
 }
