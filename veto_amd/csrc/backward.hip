@@ -1,5 +1,5 @@
-// Backward building blocks of the relation transformer (groundwork: these kernels are
-// exposed through test hooks and checked against autograd; the training path that chains them is not built yet).
+// Backward building blocks of the relation transformer; chained by veto_backward
+// (veto_abi.hip) and exposed one by one through test hooks that are checked against autograd.
 //   attention_backward   model_veto.py:85-96   (dQ, dK, dV) from dOut and the saved q, k, v of one (pair, head)
 //   layernorm_backward   model_veto.py:125-132 dx, and per-block partial sums of dgamma / dbeta
 //   gelu_backward        model_veto.py:140     dpre = dh * gelu'(pre), exact-erf GELU
@@ -13,113 +13,218 @@ namespace {
 
 constexpr int kColChunks = 256;    // row chunks of the two-stage column sums (fixed order -> deterministic)
 
-constexpr int kAttnBwdThreads = 256;
+constexpr int kAttnBwdThreads = 320;
 
-// One workgroup of four waves per (pair, head), everything in fp32.  With S = q k^T * scale, P = softmax(S), O = P v:
+// One workgroup of five waves per (pair, head), everything in fp32.  With S = q k^T * scale, P = softmax(S), O = P v:
 //   dV = P^T dO,  dP = dO v^T,  dS = P * (dP - rowsum(dP * P)),  dQ = dS k * scale,  dK = dS^T q * scale.
-template <int DH>
-__global__ __launch_bounds__(kAttnBwdThreads) void attention_backward_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
-                                                                float* __restrict__ dqkv, int n_pair, int heads) {
-  constexpr int LD = DH + 1;                  // padded row stride: column walks hit distinct banks
-  __shared__ float q[kTokens * LD], k[kTokens * LD], v[kTokens * LD], go[kTokens * LD];
-  __shared__ float p[kTokens * 20], ds[kTokens * 20];
-  const int item = blockIdx.x, pair = item / heads, head = item % heads, lane = threadIdx.x;   // index inside the workgroup that owns this (pair, head)
-  if (pair >= n_pair) return;
-  const float* src = qkv + (size_t)pair * kTokens * (3 * kDim) + head * DH;
-  const float* gsrc = dout + (size_t)pair * kTokens * kDim + head * DH;
-  for (int e = lane; e < kTokens * DH; e += kAttnBwdThreads) {
-    const int t = e / DH, d = e % DH;
-    q[t * LD + d] = src[(size_t)t * 3 * kDim + d];
-    k[t * LD + d] = src[(size_t)t * 3 * kDim + kDim + d];
-    v[t * LD + d] = src[(size_t)t * 3 * kDim + 2 * kDim + d];
-    go[t * LD + d] = gsrc[(size_t)t * kDim + d];
-  }
-  __syncthreads();
-  const float scale = 1.0f / sqrtf((float)DH);
-  for (int e = lane; e < kTokens * kTokens; e += kAttnBwdThreads) {   // S and dP
-    const int i = e / kTokens, j = e % kTokens;
-    float s = 0.f, dp = 0.f;
-    for (int d = 0; d < DH; ++d) { s += q[i * LD + d] * k[j * LD + d]; dp += go[i * LD + d] * v[j * LD + d]; }
-    p[i * 20 + j] = s * scale;
-    ds[i * 20 + j] = dp;
-  }
-  __syncthreads();
-  if (lane < kTokens) {                                   // row softmax, then dS = P * (dP - sum_j dP P)
-    float* pr = p + lane * 20;
-    float* dr = ds + lane * 20;
-    float mx = -INFINITY;
-    for (int j = 0; j < kTokens; ++j) mx = fmaxf(mx, pr[j]);
-    float sum = 0.f;
-    for (int j = 0; j < kTokens; ++j) { pr[j] = expf(pr[j] - mx); sum += pr[j]; }
-    const float inv = 1.f / sum;
-    float dot = 0.f;
-    for (int j = 0; j < kTokens; ++j) { pr[j] *= inv; dot += dr[j] * pr[j]; }
-    for (int j = 0; j < kTokens; ++j) dr[j] = pr[j] * (dr[j] - dot);
-  }
-  __syncthreads();
-  float* dst = dqkv + (size_t)pair * kTokens * (3 * kDim) + head * DH;
-  for (int e = lane; e < kTokens * DH; e += kAttnBwdThreads) {
-    const int t = e / DH, d = e % DH;
-    float dq = 0.f, dk = 0.f, dv = 0.f;
-    for (int j = 0; j < kTokens; ++j) {
-      dq += ds[t * 20 + j] * k[j * LD + d];     // dQ[t] = sum_j dS[t][j] k[j]
-      dk += ds[j * 20 + t] * q[j * LD + d];     // dK[t] = sum_i dS[i][t] q[i]
-      dv += p[j * 20 + t] * go[j * LD + d];     // dV[t] = sum_i P[i][t] dO[i]
-    }
-    dst[(size_t)t * 3 * kDim + d] = dq * scale;
-    dst[(size_t)t * 3 * kDim + kDim + d] = dk * scale;
-    dst[(size_t)t * 3 * kDim + 2 * kDim + d] = dv;
-  }
+// All five products are register-blocked 4 x 4 with 16-byte LDS reads (2 bytes of LDS traffic per FMA; the first
+// version read two scalars per FMA and was bound by the LDS array at 2.2 ms per launch):
+//   A  S, dP   [20 x 20] outputs in 25 tiles of 4 x 4, the head dimension cut into NS slices -> 2 * NS * 25 work items,
+//              partial sums in LDS, folded in slice order (deterministic)
+//   B  softmax / dS: 16 lanes per row, reductions by DPP row rotations
+//   C  dQ, dK, dV  [20 x DH] outputs: work item = (product, 4 tokens, 4 head columns), contraction over the 19 tokens
+// Token row 19 of every image is zero padding.
+// all-reduce (sum or max) over the 16 lanes of a DPP row by rotations row_ror:8/4/2/1; every lane of the row must be active
+template <int CTRL>
+__device__ __forceinline__ float dpp_rot(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
+template <bool MAX>
+__device__ __forceinline__ float row_all(float v) {
+  float o;
+  o = dpp_rot<0x128>(v); v = MAX ? fmaxf(v, o) : v + o;
+  o = dpp_rot<0x124>(v); v = MAX ? fmaxf(v, o) : v + o;
+  o = dpp_rot<0x122>(v); v = MAX ? fmaxf(v, o) : v + o;
+  o = dpp_rot<0x121>(v); v = MAX ? fmaxf(v, o) : v + o;
+  return v;
 }
 
-// LayerNorm backward over 576-wide rows, one quarter wave per row (lane q holds chunks q + 16 j as the forward):
+template <int DH>
+__global__ __launch_bounds__(kAttnBwdThreads) void attention_backward_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
+                                                                             float* __restrict__ dqkv, int n_pair, int heads) {
+  constexpr int TP = 20, LD = DH + 4, D4 = DH / 4, MAT = TP * LD;
+  constexpr int NS = DH == 144 ? 3 : 6, SL = DH / NS;       // slices of the head dimension in phase A
+  constexpr int CHUNKS = 4 * kTokens * D4, ROUNDS = (CHUNKS + kAttnBwdThreads - 1) / kAttnBwdThreads;
+  static_assert(DH % 12 == 0 && SL % 4 == 0, "head dimension");
+  __shared__ __attribute__((aligned(16))) float img[4 * MAT];          // q, k, v, dO as [20][LD]
+  __shared__ __attribute__((aligned(16))) float part[2 * NS * TP * TP];
+  __shared__ __attribute__((aligned(16))) float p[TP * TP], ds[TP * TP], dst_t[TP * TP];
+  const int tid = threadIdx.x;
+  const long total = (long)n_pair * heads;
+  const float* q = img;
+  const float* k = img + MAT;
+  const float* v = img + 2 * MAT;
+  const float* go = img + 3 * MAT;
+  for (int e = tid; e < 4 * LD; e += kAttnBwdThreads) img[(e / LD) * MAT + kTokens * LD + e % LD] = 0.f;   // padding row 19
+  // Persistent workgroups: the operands of the NEXT (pair, head) are fetched into registers while this one is computed
+  // (one workgroup per item spent 0.8 of its 2.3 ms waiting for these loads and 0.7 ms on workgroup turnover).
+  f32x4 pre[ROUNDS];
+  auto fetch = [&](long item) {
+    const int pair = (int)(item / heads), head = (int)(item % heads);
+    const float* src = qkv + (size_t)pair * kTokens * (3 * kDim) + head * DH;
+    const float* gsrc = dout + (size_t)pair * kTokens * kDim + head * DH;
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+      const int e = tid + r * kAttnBwdThreads;
+      if (e < CHUNKS) {
+        const int mat = e / (kTokens * D4), rem = e % (kTokens * D4), t = rem / D4, c = rem % D4;
+        pre[r] = mat < 3 ? *(const f32x4*)(src + (size_t)t * 3 * kDim + mat * kDim + 4 * c) : *(const f32x4*)(gsrc + (size_t)t * kDim + 4 * c);
+      }
+    }
+  };
+  // contiguous item ranges: the heads of one pair (adjacent 288-byte pieces of the same rows) follow each other on one CU
+  const long per_wg = (total + gridDim.x - 1) / gridDim.x;
+  long item = blockIdx.x * per_wg;
+  const long last = item + per_wg < total ? item + per_wg : total;
+  if (item < last) fetch(item);
+  for (; item < last; ++item) {
+  const int pair = (int)(item / heads), head = (int)(item % heads);
+  __syncthreads();                 // the previous item's phase C has finished reading the images
+#pragma unroll
+  for (int r = 0; r < ROUNDS; ++r) {
+    const int e = tid + r * kAttnBwdThreads;
+    if (e < CHUNKS) {
+      const int mat = e / (kTokens * D4), rem = e % (kTokens * D4), t = rem / D4, c = rem % D4;
+      *(f32x4*)(img + mat * MAT + t * LD + 4 * c) = pre[r];
+    }
+  }
+  if (item + 1 < last) fetch(item + 1);
+  __syncthreads();
+  // ---- A: partial S = q k^T and dP = dO v^T ---------------------------------------------------------------------------
+  for (int w = tid; w < 2 * NS * 25; w += kAttnBwdThreads) {
+    const int prod = w / (NS * 25), rem = w % (NS * 25), sl = rem / 25, tile = rem % 25;
+    const int i0 = (tile / 5) * 4, j0 = (tile % 5) * 4;
+    const float* A = (prod ? go : q) + i0 * LD + sl * SL;
+    const float* B = (prod ? v : k) + j0 * LD + sl * SL;
+    f32x4 acc[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int d = 0; d < SL; d += 4) {
+      f32x4 a[4], b[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { a[r] = *(const f32x4*)(A + r * LD + d); b[r] = *(const f32x4*)(B + r * LD + d); }
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[r][c] += (a[r][0] * b[c][0] + a[r][1] * b[c][1]) + (a[r][2] * b[c][2] + a[r][3] * b[c][3]);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) *(f32x4*)(part + (prod * NS + sl) * (TP * TP) + (i0 + r) * TP + j0) = acc[r];
+  }
+  __syncthreads();
+  // ---- B: P = softmax(S * scale) per row, dS = P * (dP - sum_j dP P); 16 lanes per row (columns j and j + 16), all 20
+  // rows at once; the row reductions are DPP rotations inside the 16-lane row (no LDS crossbar, a few cycles each)
+  const float scale = 1.0f / sqrtf((float)DH);
+  {
+    const int i = tid >> 4, j = tid & 15;
+    const bool v1 = i < kTokens, v2 = i < kTokens && j < 3;
+    float s1 = 0.f, d1 = 0.f, s2 = 0.f, d2 = 0.f;
+    if (v1) {
+#pragma unroll
+      for (int sl = 0; sl < NS; ++sl) { s1 += part[sl * (TP * TP) + i * TP + j]; d1 += part[(NS + sl) * (TP * TP) + i * TP + j]; }
+    }
+    if (v2) {
+#pragma unroll
+      for (int sl = 0; sl < NS; ++sl) { s2 += part[sl * (TP * TP) + i * TP + 16 + j]; d2 += part[(NS + sl) * (TP * TP) + i * TP + 16 + j]; }
+    }
+    s1 = v1 ? s1 * scale : -INFINITY;
+    s2 = v2 ? s2 * scale : -INFINITY;
+    const float mx = row_all<true>(fmaxf(s1, s2));
+    const float e1 = v1 ? expf(s1 - mx) : 0.f, e2 = v2 ? expf(s2 - mx) : 0.f;
+    const float sum = row_all<false>(e1 + e2), dotr = row_all<false>(e1 * d1 + e2 * d2);
+    const float inv = v1 ? 1.f / sum : 0.f, dot = dotr * inv;
+    const float p1 = e1 * inv, p2 = e2 * inv;
+    const float g1 = p1 * (d1 - dot), g2 = p2 * (d2 - dot);
+    p[i * TP + j] = p1;
+    ds[i * TP + j] = g1;
+    dst_t[j * TP + i] = g1;
+    if (j < 4) {          // columns 16 .. 19 (19 = padding, zero)
+      p[i * TP + 16 + j] = p2;
+      ds[i * TP + 16 + j] = g2;
+      dst_t[(16 + j) * TP + i] = g2;
+    }
+  }
+  __syncthreads();
+  // ---- C: dQ[t] = scale sum_j dS[t][j] k[j], dK[t] = scale sum_i dS[i][t] q[i], dV[t] = sum_i P[i][t] dO[i] ------------
+  float* dst = dqkv + (size_t)pair * kTokens * (3 * kDim) + head * DH;
+  for (int w = tid; w < 3 * 5 * D4; w += kAttnBwdThreads) {
+    const int prod = w / (5 * D4), rem = w % (5 * D4), t0 = (rem / D4) * 4, c = rem % D4;
+    const float* coef = (prod == 0 ? dst_t : prod == 1 ? ds : p) + t0;      // [contraction index][token t0 .. t0 + 3]
+    const float* mat = (prod == 0 ? k : prod == 1 ? q : go) + 4 * c;
+    f32x4 acc[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int j = 0; j < kTokens; ++j) {
+      const f32x4 cf = *(const f32x4*)(coef + j * TP);
+      const f32x4 m = *(const f32x4*)(mat + j * LD);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[r] += cf[r] * m;
+    }
+    const float f = prod < 2 ? scale : 1.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (t0 + r < kTokens) *(f32x4*)(dst + (size_t)(t0 + r) * 3 * kDim + prod * kDim + 4 * c) = acc[r] * f;
+  }
+  }  // items
+}
+
+// LayerNorm backward over 576-wide rows, half a wave per row (lane q holds the 8-byte chunks q + 32 j; 16 lanes per row
+// with 16-byte chunks needed 244 VGPRs = 2 waves / SIMD and ran at 2.9 TB/s):
 //   xhat = (x - mean) * rstd, g = dy * gamma, dx = rstd * (g - mean(g) - xhat * mean(g * xhat)) (+ dres)
-// dgamma / dbeta: a thread always owns the same 36 columns, so it adds its kLnRowsPerBlock / 16 rows in registers;
-// the 16 row slots of the block then meet in LDS once per block, and the block writes one partial row [2, 576]
+// dgamma / dbeta: a thread always owns the same 18 columns, so it adds its kLnRowsPerBlock / 8 rows in registers;
+// the 8 row slots of the block then meet in LDS once per block, and the block writes one partial row [2, 576]
 // that a two-stage column sum folds in a fixed order.
 constexpr int kLnRowsPerBlock = 64;
+constexpr int kLnLanes = 32;                       // lanes per row: 18 values per lane and tensor (9 x 8-byte accesses)
+constexpr int kLnSlots = 256 / kLnLanes;           // rows in flight per block
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-__global__ __launch_bounds__(256) void layernorm_backward_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void layernorm_backward_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                                  const float* __restrict__ gamma, const float* __restrict__ dres,
                                                                  float* __restrict__ dx, float* __restrict__ partial, int rows) {
-  __shared__ float s_dg[kDim], s_db[kDim];
-  for (int c = threadIdx.x; c < kDim; c += 256) { s_dg[c] = 0.f; s_db[c] = 0.f; }
+  __shared__ float s_dg[kDim], s_db[kDim], s_w[kDim];
+  for (int c = threadIdx.x; c < kDim; c += 256) { s_dg[c] = 0.f; s_db[c] = 0.f; s_w[c] = gamma[c]; }
   __syncthreads();
-  const int q = threadIdx.x & 15;
+  const int q = threadIdx.x & (kLnLanes - 1);
   auto gsum = [](float t) {
 #pragma unroll
-    for (int o = 8; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+    for (int o = kLnLanes / 2; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
     return t;
   };
-  f32x4 acc_g[9], acc_b[9];
+  f32x2 acc_g[9], acc_b[9];
 #pragma unroll
-  for (int j = 0; j < 9; ++j) { acc_g[j] = f32x4{0.f, 0.f, 0.f, 0.f}; acc_b[j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-  for (int it = 0; it < kLnRowsPerBlock / 16; ++it) {
-    const int row = blockIdx.x * kLnRowsPerBlock + it * 16 + (threadIdx.x >> 4);
-    if (row >= rows) continue;      // uniform per quarter wave
+  for (int j = 0; j < 9; ++j) {
+    acc_g[j] = f32x2{0.f, 0.f};
+    acc_b[j] = f32x2{0.f, 0.f};
+  }
+  for (int it = 0; it < kLnRowsPerBlock / kLnSlots; ++it) {
+    const int row = blockIdx.x * kLnRowsPerBlock + it * kLnSlots + threadIdx.x / kLnLanes;
+    if (row >= rows) continue;      // uniform per half wave
     const float* xr = x + (size_t)row * kDim;
     const float* gr = dy + (size_t)row * kDim;
-    f32x4 xv[9], gv[9];
+    f32x2 xv[9], gv[9];
     float s = 0.f;
 #pragma unroll
     for (int j = 0; j < 9; ++j) {
-      xv[j] = *(const f32x4*)(xr + 4 * (q + 16 * j));
-      gv[j] = *(const f32x4*)(gr + 4 * (q + 16 * j));
-      s += (xv[j][0] + xv[j][1]) + (xv[j][2] + xv[j][3]);
+      xv[j] = *(const f32x2*)(xr + 2 * (q + kLnLanes * j));
+      gv[j] = *(const f32x2*)(gr + 2 * (q + kLnLanes * j));
+      s += xv[j][0] + xv[j][1];
     }
     const float mean = gsum(s) * (1.f / kDim);
     float sq = 0.f;
 #pragma unroll
     for (int j = 0; j < 9; ++j)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { const float d = xv[j][e] - mean; sq += d * d; }
+      for (int e = 0; e < 2; ++e) { const float d = xv[j][e] - mean; sq += d * d; }
     const float rstd = 1.f / sqrtf(gsum(sq) * (1.f / kDim) + 1e-5f);
     float sg = 0.f, sgx = 0.f;
 #pragma unroll
     for (int j = 0; j < 9; ++j) {
-      const f32x4 w = *(const f32x4*)(gamma + 4 * (q + 16 * j));
+      const f32x2 w = *(const f32x2*)(s_w + 2 * (q + kLnLanes * j));
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
+      for (int e = 0; e < 2; ++e) {
         const float xh = (xv[j][e] - mean) * rstd;
         acc_g[j][e] += gv[j][e] * xh;
         acc_b[j][e] += gv[j][e];
@@ -134,20 +239,19 @@ __global__ __launch_bounds__(256) void layernorm_backward_kernel(const float* __
     float* dr = dx + (size_t)row * kDim;
 #pragma unroll
     for (int j = 0; j < 9; ++j) {
-      const int c = 4 * (q + 16 * j);
-      f32x4 o;
+      f32x2 o;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] = rstd * (gv[j][e] - mg - xv[j][e] * mgx);
-      if (dres) o += *(const f32x4*)(dres + (size_t)row * kDim + c);
-      *(f32x4*)(dr + c) = o;
+      for (int e = 0; e < 2; ++e) o[e] = rstd * (gv[j][e] - mg - xv[j][e] * mgx);
+      if (dres) o += *(const f32x2*)(dres + (size_t)row * kDim + 2 * (q + kLnLanes * j));
+      *(f32x2*)(dr + 2 * (q + kLnLanes * j)) = o;
     }
   }
 #pragma unroll
   for (int j = 0; j < 9; ++j)
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int c = 4 * (q + 16 * j) + e;
-      atomicAdd(&s_dg[c], acc_g[j][e]);    // 16 row slots per column, once per block
+    for (int e = 0; e < 2; ++e) {
+      const int c = 2 * (q + kLnLanes * j) + e;
+      atomicAdd(&s_dg[c], acc_g[j][e]);    // kLnSlots row slots per column, once per block
       atomicAdd(&s_db[c], acc_b[j][e]);
     }
   __syncthreads();
@@ -198,15 +302,31 @@ __global__ __launch_bounds__(256) void gelu_backward_kernel(const float* __restr
 
 }  // namespace
 
-hipError_t launch_attention_backward(const float* qkv, const float* dout, float* dqkv, int n_pair, int heads, hipStream_t s) {
-  if (heads <= 0 || kDim % heads != 0) return hipErrorInvalidValue;
-  const int dh = kDim / heads;
-  const unsigned blocks = (unsigned)((long)n_pair * heads);
-  if (dh == 72) VETO_LAUNCH(attention_backward_kernel<72>, dim3(blocks), dim3(kAttnBwdThreads), 0, s, qkv, dout, dqkv, n_pair, heads);
-  else if (dh == 96) VETO_LAUNCH(attention_backward_kernel<96>, dim3(blocks), dim3(kAttnBwdThreads), 0, s, qkv, dout, dqkv, n_pair, heads);
-  else if (dh == 144) VETO_LAUNCH(attention_backward_kernel<144>, dim3(blocks), dim3(kAttnBwdThreads), 0, s, qkv, dout, dqkv, n_pair, heads);
-  else return hipErrorInvalidValue;
+// persistent grid = what the device holds at once (CUs x resident workgroups of this instantiation), found once
+template <int DH>
+static hipError_t launch_attention_backward_dh(const float* qkv, const float* dout, float* dqkv, int n_pair, int heads, hipStream_t s) {
+  static int resident = 0;
+  if (!resident) {
+    int dev = 0, cus = 0, per_cu = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, attention_backward_kernel<DH>, kAttnBwdThreads, 0);
+    if (e != hipSuccess) return e;
+    resident = cus * (per_cu > 0 ? per_cu : 1);
+  }
+  const long total = (long)n_pair * heads;
+  const unsigned blocks = (unsigned)(total < resident ? total : resident);
+  VETO_LAUNCH(attention_backward_kernel<DH>, dim3(blocks), dim3(kAttnBwdThreads), 0, s, qkv, dout, dqkv, n_pair, heads);
   return hipGetLastError();
+}
+
+hipError_t launch_attention_backward(const float* qkv, const float* dout, float* dqkv, int n_pair, int heads, hipStream_t s) {
+  if (heads <= 0 || kDim % heads != 0 || n_pair <= 0) return hipErrorInvalidValue;
+  const int dh = kDim / heads;
+  if (dh == 72) return launch_attention_backward_dh<72>(qkv, dout, dqkv, n_pair, heads, s);
+  if (dh == 96) return launch_attention_backward_dh<96>(qkv, dout, dqkv, n_pair, heads, s);
+  if (dh == 144) return launch_attention_backward_dh<144>(qkv, dout, dqkv, n_pair, heads, s);
+  return hipErrorInvalidValue;
 }
 
 // partial rows of the LayerNorm parameter gradients + the scratch of the two-stage column sum over them

@@ -45,15 +45,30 @@ __global__ __launch_bounds__(256) void transpose_from_split_kernel(const __bf16*
 // ---- one pass over a gradient matrix dY fp32 [M, N]: split rows (A operand of the input-gradient GEMM), split rows of the
 // transpose (operand of the weight-gradient GEMM) and, optionally, per-block column sums (bias gradient, folded later).
 // 32 (m) x 64 (n) tile through LDS; the three consumers used to read dY once each.
+// XF folds the elementwise op that precedes the Linear's output in the backward chain into the load: XF_GELU multiplies by
+// gelu'(pre) (model_veto.py:140, exact erf), XF_DROP applies the counter-based dropout mask of the forward (element m * N + n).
+template <int XF>
 __global__ __launch_bounds__(256) void prep_grad_kernel(const float* __restrict__ src, long ld, int M, int N, __bf16* __restrict__ rows_out,
-                                                        __bf16* __restrict__ t_out, int Mp, float* __restrict__ col_partial) {
+                                                        __bf16* __restrict__ t_out, int Mp, float* __restrict__ col_partial,
+                                                        GradXform xf) {
   __shared__ float t[32][65];
   const int m0 = blockIdx.x * 32, n0 = blockIdx.y * 64, tid = threadIdx.x;
   const int tx = tid & 63, ty = tid >> 6;
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int m = m0 + ty * 8 + i, n = n0 + tx;
-    t[ty * 8 + i][tx] = (m < M && n < N) ? src[(size_t)m * ld + n] : 0.f;
+    float v = 0.f;
+    if (m < M && n < N) {
+      v = src[(size_t)m * ld + n];
+      if constexpr (XF == XF_GELU) {
+        const float x = xf.pre[(size_t)m * ld + n];
+        const float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752440f));
+        const float pdf = 0.39894228040143267794f * expf(-0.5f * x * x);
+        v = v * (cdf + x * pdf);
+      }
+      if constexpr (XF == XF_DROP) v = dropout_keep(xf.seed, (size_t)m * N + n, xf.thresh) ? v * xf.scale : 0.f;
+    }
+    t[ty * 8 + i][tx] = v;
   }
   __syncthreads();
   // transposed split rows: output row n receives the 32-m block [hi | lo]
@@ -325,10 +340,19 @@ hipError_t launch_transpose_from_split(const __bf16* src, long ld, int M, int K,
   return hipGetLastError();
 }
 
-hipError_t launch_prep_grad(const float* src, long ld, int M, int N, __bf16* rows_out, __bf16* t_out, int Mp, float* col_partial,
+hipError_t launch_prep_grad(const float* src, long ld, int M, int N, __bf16* rows_out, __bf16* t_out, int Mp, float* col_partial, const GradXform& xf,
                             hipStream_t s) {
   if (Mp % 32 != 0 || Mp < M || N % 32 != 0) return hipErrorInvalidValue;
-  VETO_LAUNCH(prep_grad_kernel, dim3(Mp / 32, (N + 63) / 64), dim3(256), 0, s, src, ld, M, N, rows_out, t_out, Mp, col_partial);
+  const dim3 grid(Mp / 32, (N + 63) / 64);
+  if (xf.mode == XF_GELU) {
+    if (!xf.pre) return hipErrorInvalidValue;
+    VETO_LAUNCH(prep_grad_kernel<XF_GELU>, grid, dim3(256), 0, s, src, ld, M, N, rows_out, t_out, Mp, col_partial, xf);
+  } else if (xf.mode == XF_DROP) {
+    if (ld != N) return hipErrorInvalidValue;
+    VETO_LAUNCH(prep_grad_kernel<XF_DROP>, grid, dim3(256), 0, s, src, ld, M, N, rows_out, t_out, Mp, col_partial, xf);
+  } else {
+    VETO_LAUNCH(prep_grad_kernel<XF_NONE>, grid, dim3(256), 0, s, src, ld, M, N, rows_out, t_out, Mp, col_partial, xf);
+  }
   return hipGetLastError();
 }
 

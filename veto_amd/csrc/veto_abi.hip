@@ -611,7 +611,7 @@ TrainWs carve_train(char* base, veto_handle_t h, int n_obj, int n_pair) {
 // Backward of y = x W^T (+ b) over the token rows: dW[N, K] = dY^T x, db[N] = column sums of dY (if db), dX[M, K] = dY W.
 // One pass over dY (prep_grad_kernel) produces both GEMM operands and the bias partials.
 int run_linear_backward(veto_handle_t h, hipStream_t s, const TrainWs& w, const float* dy, int M, int N, const __bf16* x_split, int K,
-                        const float* weight, float* dw, float* db, float* dx) {
+                        const float* weight, float* dw, float* db, float* dx, const GradXform& xf = GradXform()) {
   const int out_tiles = ((N + 255) / 256) * (K / 192);
   int ks = 2 * 256 / out_tiles;
   const int max_ks = (M + 32 * 64 - 1) / (32 * 64);
@@ -620,7 +620,7 @@ int run_linear_backward(veto_handle_t h, hipStream_t s, const TrainWs& w, const 
   if (ks < 1) ks = 1;
   const size_t mp = ((size_t)M + 32 * (size_t)ks - 1) / (32 * (size_t)ks) * 32 * (size_t)ks;
   if (mp > w.mp2) return fail(VETO_ERR_WORKSPACE, "weight-gradient operand buffer too small");
-  HIP_TRY(launch_prep_grad(dy, N, M, N, w.dsplit, w.at, (int)mp, db ? w.colp : nullptr, s));
+  HIP_TRY(launch_prep_grad(dy, N, M, N, w.dsplit, w.at, (int)mp, db ? w.colp : nullptr, xf, s));
   if (db) HIP_TRY(launch_column_sums(w.colp, N, (int)(mp / 32), N, db, w.col_partial, column_sums_chunks(), s));
   HIP_TRY(launch_transpose_from_split(x_split, 2 * (long)K, M, K, w.wt, (int)mp, s));
   HIP_TRY(hipMemsetAsync(dw, 0, (size_t)N * K * 4, s));
@@ -792,24 +792,28 @@ int veto_backward(veto_handle_t h, void* stream, const veto_inputs_t* in, const 
     rc = run_linear_backward(h, s, ws, ws.dx, M, kDim, t.hid, 2 * kDim, h->p(lname(l, "1.fn.net.3.weight")),
                              G(lname(l, "1.fn.net.3.weight")), G(lname(l, "1.fn.net.3.bias")), ws.dbig);
     if (rc) return rc;
-    HIP_TRY(launch_gelu_backward(t.pre, ws.dbig, ws.dbig, (size_t)M * 2 * kDim, s));
+    GradXform gelu;              // dpre = dh * gelu'(pre), folded into the operand preparation of the fc1 backward
+    gelu.mode = XF_GELU;
+    gelu.pre = t.pre;
     rc = run_linear_backward(h, s, ws, ws.dbig, M, 2 * kDim, t.a2, kDim, h->p(lname(l, "1.fn.net.0.weight")),
-                             G(lname(l, "1.fn.net.0.weight")), G(lname(l, "1.fn.net.0.bias")), ws.dtmp);
+                             G(lname(l, "1.fn.net.0.weight")), G(lname(l, "1.fn.net.0.bias")), ws.dtmp, gelu);
     if (rc) return rc;
     HIP_TRY(launch_layernorm_backward(t.xmid, ws.dtmp, w.ln2_w, ws.dx, ws.dmid, ws.dgb, ws.ln_partial, M, s));
     HIP_TRY(hipMemcpyAsync(G(lname(l, "1.norm.weight")), ws.dgb, kDim * 4, hipMemcpyDeviceToDevice, s));
     HIP_TRY(hipMemcpyAsync(G(lname(l, "1.norm.bias")), ws.dgb + kDim, kDim * 4, hipMemcpyDeviceToDevice, s));
     // x_mid = x_in + dropout(attention(LN1(x_in) Wqkv^T) Wo^T + bo): the projection sees the masked gradient
-    const float* dproj = ws.dmid;
+    GradXform drop;
     {
       const DropSite d = drop_site(opts, 3 + l);
       if (d.thresh) {
-        HIP_TRY(launch_dropout_apply(ws.dmid, ws.dtmp, (size_t)M, kDim, d.seed, d.thresh, d.scale, s));
-        dproj = ws.dtmp;
+        drop.mode = XF_DROP;
+        drop.seed = d.seed;
+        drop.thresh = d.thresh;
+        drop.scale = d.scale;
       }
     }
-    rc = run_linear_backward(h, s, ws, dproj, M, kDim, t.ao, kDim, h->p(lname(l, "0.fn.to_out.0.weight")),
-                             G(lname(l, "0.fn.to_out.0.weight")), G(lname(l, "0.fn.to_out.0.bias")), ws.dtmp);
+    rc = run_linear_backward(h, s, ws, ws.dmid, M, kDim, t.ao, kDim, h->p(lname(l, "0.fn.to_out.0.weight")),
+                             G(lname(l, "0.fn.to_out.0.weight")), G(lname(l, "0.fn.to_out.0.bias")), ws.dtmp, drop);
     if (rc) return rc;
     HIP_TRY(launch_attention_backward(t.qkv, ws.dtmp, ws.dbig, n_pair, H, s));
     rc = run_linear_backward(h, s, ws, ws.dbig, M, 3 * kDim, t.a1, kDim, h->p(lname(l, "0.fn.to_qkv.weight")),
