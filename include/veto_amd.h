@@ -340,7 +340,7 @@ int veto_debug_wgrad(void* stream, const float* dy, const float* x, float* dw, i
                      int32_t k_splits, void* workspace, size_t workspace_bytes);
 size_t veto_debug_wgrad_workspace_bytes(int32_t m, int32_t n, int32_t k, int32_t k_splits);
 
-/* ---- test hooks: backward building blocks of the transformer (not yet chained into a training path) -----------
+/* ---- test hooks: backward building blocks of the transformer (chained by veto_backward) ----------------------
  * veto_debug_attention_backward: qkv, dqkv device [n_pair*19, 1728], dout device [n_pair*19, 576]   (model_veto.py:85-96)
  * veto_debug_layernorm_backward: x, dy, dx device [rows, 576] (dres optional, added to dx), gamma [576],
  *                                dgamma_dbeta device [2, 576]; workspace of veto_debug_layernorm_backward_workspace_bytes

@@ -207,9 +207,10 @@ def test_cpu_tensors_fail_loudly():
     with pytest.raises(RuntimeError):
         model(props, pairs, None, None, roi_features=torch.from_numpy(batch["roi_features"]),
               roi_depth_features=torch.from_numpy(batch["roi_depth_features"]))
-    model.train()
-    with pytest.raises(NotImplementedError):
-        model(props, pairs, None, None)
+    model.train()          # training mode has no CPU path either
+    with pytest.raises(RuntimeError, match="HIP device"):
+        model(props, pairs, [torch.tensor([1])], None, roi_features=torch.from_numpy(batch["roi_features"]),
+              roi_depth_features=torch.from_numpy(batch["roi_depth_features"]))
 
 
 def _check_sorted_output(res, ref_scores_sorted, ref_pairs, ref_labels, ref_prob, tol=2e-6):
