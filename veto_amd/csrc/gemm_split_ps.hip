@@ -76,7 +76,21 @@ __device__ __forceinline__ void wg_barrier() {
   asm volatile("" ::: "memory");
 }
 
-template <int NTERMS, int EPI_T>
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+// 4 rows x 16 columns of 16-bit elements, delivered column-major: lane i of a 16-lane group gets column i of the 4 rows
+__device__ __forceinline__ s16x4 lds_tr16(const char* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
+}
+// one MFMA operand fragment (8 reduction indices of one row / column) from an image whose ROWS are reduction indices:
+// two transposed reads, `pitch4` = 4 image rows apart
+__device__ __forceinline__ bf16x8 lds_tr_frag(const char* p, int pitch4) {
+  const s16x4 a = lds_tr16(p), b = lds_tr16(p + pitch4);
+  const s16x8 v = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+template <int NTERMS, int EPI_T, bool TN = false>
 __global__ __launch_bounds__(64 * (NCONS + NLOAD), 3) void gemm_split_ps_kernel(GemmArgs g) {
   constexpr bool kDrop = EPI_T == EPI_RESID_DROP;          // training-only instantiation: dropout before the residual add
   constexpr int EPI = kDrop ? (int)EPI_RESID : EPI_T;
@@ -115,10 +129,34 @@ __global__ __launch_bounds__(64 * (NCONS + NLOAD), 3) void gemm_split_ps_kernel(
       const int slot = (lane & 7) ^ ((r16 >> 1) & 7);
       return (const char*)(base + (size_t)row * ld) + slot * 16;
     };
+    // TN: a stage is 32 reduction rows; an A row is the 1 KiB of one split row that covers the tile's 256 columns (one
+    // instruction, lane = LDS slot), a W row the 768 bytes of its 192 columns (an instruction covers 64 consecutive slots of
+    // the stage).  The 16-byte chunk c of image row r sits in slot c ^ tn_swz(r): the transposed reads of a 32-lane half
+    // touch 8 rows x 2 chunks and must land on 16 different bank groups.
+    auto tn_swz = [](int r) { return 2 * ((r & 3) | (((r >> 3) & 1) << 2)); };
+    const char* tnA = nullptr;   // tile's column offset applied
+    const char* tnW = nullptr;
+    int tn_rowA = 0, tn_rowW = 0;
+    int tn_xa[2] = {0, 0}, tn_wr[CPWL], tn_wx[CPWL];
+    if constexpr (TN) {
+      tn_xa[0] = (lane ^ tn_swz(lw)) << 4;          // stage row lw + 4 i: (row & 3) = lw, (row >> 3) & 1 = (i >> 1) & 1
+      tn_xa[1] = (lane ^ tn_swz(lw + 8)) << 4;
+#pragma unroll
+      for (int i = 0; i < CPWL; ++i) {
+        const int slot = (lw + NLOAD * i) * 64 + lane, r = slot / 48, cc = slot % 48;
+        tn_wr[i] = r;
+        tn_wx[i] = (cc ^ tn_swz(r)) << 4;
+      }
+    }
     auto setupA = [&](int tile) {
       const int k0 = (tile / out_tiles) * nk;   // first k-step of this tile's range
       tile %= out_tiles;
       const int tile_m = tile / g.tiles_n;
+      if constexpr (TN) {
+        tnA = (const char*)g.a + (size_t)tile_m * (BM * 4);
+        tn_rowA = k0 * BK;
+        return;
+      }
 #pragma unroll
       for (int i = 0; i < CPA; ++i) {
         const int c = lw + NLOAD * i;
@@ -131,6 +169,11 @@ __global__ __launch_bounds__(64 * (NCONS + NLOAD), 3) void gemm_split_ps_kernel(
       const int k0 = (tile / out_tiles) * nk;
       tile %= out_tiles;
       const int tile_n = tile % g.tiles_n;
+      if constexpr (TN) {
+        tnW = (const char*)g.w + (size_t)tile_n * (BN * 4);
+        tn_rowW = k0 * BK;
+        return;
+      }
 #pragma unroll
       for (int i = 0; i < CPWL; ++i) {
         const int c = lw + NLOAD * i;
@@ -141,8 +184,17 @@ __global__ __launch_bounds__(64 * (NCONS + NLOAD), 3) void gemm_split_ps_kernel(
     int itA = 0, ktA = 0, bufA = 0, itW = 0, ktW = 0, bufW = 0;
     auto issueA = [&]() {
       char* dst = smem + bufA * kABytes + lw * 1024;
+      if constexpr (TN) {
+#pragma unroll
+        for (int i = 0; i < CPA; ++i) {
+          const int row = tn_rowA + ktA * BK + lw + NLOAD * i;        // wave-uniform
+          const char* p = row < g.k_valid ? tnA + (size_t)row * (size_t)(g.lda * 2) : (const char*)g.zero;
+          glds16(p + tn_xa[(i >> 1) & 1], dst + NLOAD * i * 1024);
+        }
+      } else {
 #pragma unroll
       for (int i = 0; i < CPA; ++i) glds16(srcA[i] + (size_t)ktA * 128, dst + NLOAD * i * 1024);
+      }
       bufA = bufA == 2 ? 0 : bufA + 1;
       if (++ktA == nk) {
         ktA = 0;
@@ -151,8 +203,17 @@ __global__ __launch_bounds__(64 * (NCONS + NLOAD), 3) void gemm_split_ps_kernel(
     };
     auto issueW = [&]() {
       char* dst = smem + 3 * kABytes + bufW * kWBytes + lw * 1024;
+      if constexpr (TN) {
+#pragma unroll
+        for (int i = 0; i < CPWL; ++i) {
+          const int row = tn_rowW + ktW * BK + tn_wr[i];               // per lane: an instruction spans two image rows
+          const char* p = row < g.k_valid ? tnW + (size_t)row * (size_t)(g.ldw * 2) : (const char*)g.zero;
+          glds16(p + tn_wx[i], dst + NLOAD * i * 1024);
+        }
+      } else {
 #pragma unroll
       for (int i = 0; i < CPWL; ++i) glds16(srcW[i] + (size_t)ktW * 128, dst + NLOAD * i * 1024);
+      }
       bufW ^= 1;
       if (++ktW == nk) {
         ktW = 0;
@@ -217,6 +278,12 @@ __global__ __launch_bounds__(64 * (NCONS + NLOAD), 3) void gemm_split_ps_kernel(
   const int frag_off = fr * 128 + ((fq ^ ((fr >> 1) & 7)) << 4);
   const int a_off = (wm * 64) * 128 + frag_off;
   const int w_off = 3 * kABytes + (wn * 96) * 128 + frag_off;
+  // TN images (rows = reduction index): lane 16 g + 4 q + p of a transposed read supplies row 8 g + q (+ 4 for the second
+  // read), 8-byte half p & 1 of chunk (c + (p >> 1)) ^ tn_swz(row) -- the loader's slot rule
+  const int tn_g = lane >> 4, tn_q = (lane >> 2) & 3, tn_p = lane & 3;
+  const int tn_y = ((2 * (tn_q | ((tn_g & 1) << 2))) ^ (tn_p >> 1)) << 4;
+  const int tn_a = (8 * tn_g + tn_q) * (BM * 4) + tn_y + (tn_p & 1) * 8 + wm * 256;   // chunk bits join by XOR below
+  const int tn_w = 3 * kABytes + (8 * tn_g + tn_q) * (BN * 4) + (tn_p & 1) * 8;
 
   unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t_begin = 0, a_bar = 0, a_cmp = 0, a_epi = 0;
   (void)t0; (void)t1; (void)t2; (void)t3; (void)t_begin; (void)a_bar; (void)a_cmp; (void)a_epi;
@@ -243,12 +310,24 @@ __global__ __launch_bounds__(64 * (NCONS + NLOAD), 3) void gemm_split_ps_kernel(
       // workgroup hitting the LDS right after the barrier overlap with matrix work instead of
       // preceding it.  NTERMS == 1 skips the lo fragments.
       auto rdA = [&](int m) {
-        ah[m] = *(const bf16x8*)(sa + a_off + m * 2048);
-        if (NTERMS == 3) al[m] = *(const bf16x8*)(sa + ((a_off + m * 2048) ^ 64));
+        if constexpr (TN) {
+          const int o = tn_a ^ (((m >> 1) * 8 + (m & 1) * 2) << 4);
+          ah[m] = lds_tr_frag(sa + o, 4 * BM * 4);
+          if (NTERMS == 3) al[m] = lds_tr_frag(sa + (o ^ 64), 4 * BM * 4);
+        } else {
+          ah[m] = *(const bf16x8*)(sa + a_off + m * 2048);
+          if (NTERMS == 3) al[m] = *(const bf16x8*)(sa + ((a_off + m * 2048) ^ 64));
+        }
       };
       auto rdW = [&](int n) {
-        wh[n] = *(const bf16x8*)(sw + w_off + n * 2048);
-        if (NTERMS == 3) wl[n] = *(const bf16x8*)(sw + ((w_off + n * 2048) ^ 64));
+        if constexpr (TN) {
+          const int o = tn_w + ((((wn * 3 + (n >> 1)) * 8 + (n & 1) * 2) << 4) ^ tn_y);
+          wh[n] = lds_tr_frag(sw + o, 4 * BN * 4);
+          if (NTERMS == 3) wl[n] = lds_tr_frag(sw + (o ^ 64), 4 * BN * 4);
+        } else {
+          wh[n] = *(const bf16x8*)(sw + w_off + n * 2048);
+          if (NTERMS == 3) wl[n] = *(const bf16x8*)(sw + ((w_off + n * 2048) ^ 64));
+        }
       };
       auto mma = [&](int n, int m) {
         if (NTERMS == 3) {
@@ -271,15 +350,16 @@ __global__ __launch_bounds__(64 * (NCONS + NLOAD), 3) void gemm_split_ps_kernel(
         for (int m = 0; m < 4; ++m) mma(n, m);
       }
       if (NTERMS == 3) {  // pin the interleave: DS_READ 0x100, MFMA 0x8
-        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);   // W0 (hi, lo), A0 (hi, lo)
+        constexpr int R = TN ? 2 : 1;   // a transposed fragment is two reads
+        __builtin_amdgcn_sched_group_barrier(0x100, 4 * R, 0);   // W0 (hi, lo), A0 (hi, lo)
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
-          __builtin_amdgcn_sched_group_barrier(0x100, 2, 0); // A(m+1) or W1
+          __builtin_amdgcn_sched_group_barrier(0x100, 2 * R, 0); // A(m+1) or W1
           __builtin_amdgcn_sched_group_barrier(0x8, 3, 0);   // tile (0, m)
         }
 #pragma unroll
         for (int n = 1; n < 6; ++n) {
-          if (n < 5) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+          if (n < 5) __builtin_amdgcn_sched_group_barrier(0x100, 2 * R, 0);
           __builtin_amdgcn_sched_group_barrier(0x8, 12, 0);
         }
       }
@@ -377,7 +457,10 @@ hipError_t launch_ps_terms(GemmArgs g, int epi, int nblocks, hipStream_t s) {
     case EPI_F32: VETO_LAUNCH((gemm_split_ps_kernel<NTERMS, EPI_F32>), grid, block, 0, s, g); break;
     case EPI_RESID: VETO_LAUNCH((gemm_split_ps_kernel<NTERMS, EPI_RESID>), grid, block, 0, s, g); break;
     case EPI_GELU_SPLIT: VETO_LAUNCH((gemm_split_ps_kernel<NTERMS, EPI_GELU_SPLIT>), grid, block, 0, s, g); break;
-    case EPI_ATOMIC: VETO_LAUNCH((gemm_split_ps_kernel<NTERMS, EPI_ATOMIC>), grid, block, 0, s, g); break;
+    case EPI_ATOMIC:
+      if (g.tn) VETO_LAUNCH((gemm_split_ps_kernel<NTERMS, EPI_ATOMIC, true>), grid, block, 0, s, g);
+      else VETO_LAUNCH((gemm_split_ps_kernel<NTERMS, EPI_ATOMIC>), grid, block, 0, s, g);
+      break;
     case EPI_RESID_DROP: VETO_LAUNCH((gemm_split_ps_kernel<NTERMS, EPI_RESID_DROP>), grid, block, 0, s, g); break;
     default: return hipErrorInvalidValue;
   }
@@ -400,6 +483,7 @@ hipError_t launch_gemm_split_ps(GemmArgs g, int epi, int precision, hipStream_t 
   }
   const int ksp = epi == EPI_ATOMIC && g.k_splits > 1 ? g.k_splits : 1;
   if ((g.K / BK) % ksp != 0) return hipErrorInvalidValue;
+  if (g.tn && (epi != EPI_ATOMIC || !g.zero || g.lda <= 0 || g.ldw <= 0 || g.k_valid <= 0 || g.k_valid > g.K)) return hipErrorInvalidValue;
   const int ntiles = g.tiles_m * g.tiles_n * ksp;
   int nblocks = num_cu;  // one persistent workgroup per CU (LDS: 112 KiB each)
   if (ntiles < nblocks) nblocks = (ntiles + 7) / 8 * 8;

@@ -71,11 +71,11 @@ __global__ __launch_bounds__(256) void prep_grad_kernel(const float* __restrict_
     t[ty * 8 + i][tx] = v;
   }
   __syncthreads();
-  // transposed split rows: output row n receives the 32-m block [hi | lo]
+  // transposed split rows (optional): output row n receives the 32-m block [hi | lo]
 #pragma unroll
   for (int r = 0; r < 2; ++r) {
     const int id = tid + 256 * r, nl = id >> 3, piece = id & 7;
-    if (n0 + nl < N) {
+    if (t_out && n0 + nl < N) {
       bf16x8 out;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {

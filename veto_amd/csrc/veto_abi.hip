@@ -540,7 +540,7 @@ struct TrainWs {
   std::vector<TrainLayer> layers;
   // backward scratch
   float *dx, *dmid, *dtmp, *dbig;
-  __bf16 *dsplit, *at, *wt, *wdg;
+  __bf16 *dsplit, *wdg, *zero;
   float *ln_partial, *col_partial, *colp, *dgb, *head_partial;
   float *dpatch, *dlc, *dpos, *dpre, *xhat, *bn_out, *dbn_out, *emb, *demb, *prob, *dloc_wt, *dcls_wt, *dwcat_t;
   size_t mp2;    // padded reduction length of the weight-gradient GEMMs
@@ -583,8 +583,7 @@ TrainWs carve_train(char* base, veto_handle_t h, int n_obj, int n_pair) {
   w.dbig = (float*)take(mpad * 3 * kDim * 4);
   w.dsplit = (__bf16*)take(mpad * 6 * kDim * 2);
   w.mp2 = (M + 32 * 64 + 31) / 32 * 32;   // room for any split count up to 64
-  w.at = (__bf16*)take((size_t)gemm_rows_padded(2048) * w.mp2 * 4);
-  w.wt = (__bf16*)take((size_t)2 * kDim * w.mp2 * 4);
+  w.zero = (__bf16*)take(1024);           // what the weight-gradient GEMM reads for reduction rows past the last one
   w.wdg = (__bf16*)take((size_t)3 * kDim * kDim * 4);
   w.ln_partial = (float*)take(layernorm_backward_partial_floats((int)M) * 4);
   w.col_partial = (float*)take((size_t)column_sums_chunks() * 3 * kDim * 4);
@@ -609,7 +608,9 @@ TrainWs carve_train(char* base, veto_handle_t h, int n_obj, int n_pair) {
 }
 
 // Backward of y = x W^T (+ b) over the token rows: dW[N, K] = dY^T x, db[N] = column sums of dY (if db), dX[M, K] = dY W.
-// One pass over dY (prep_grad_kernel) produces both GEMM operands and the bias partials.
+// One pass over dY (prep_grad_kernel) produces its split rows -- the A operand of the input-gradient GEMM AND, read through
+// transposing LDS loads, of the weight-gradient GEMM (GemmArgs::tn; the saved activation x_split is its other operand as it
+// is) -- and the bias partials.  No transposed copies of dY or x exist.
 int run_linear_backward(veto_handle_t h, hipStream_t s, const TrainWs& w, const float* dy, int M, int N, const __bf16* x_split, int K,
                         const float* weight, float* dw, float* db, float* dx, const GradXform& xf = GradXform()) {
   const int out_tiles = ((N + 255) / 256) * (K / 192);
@@ -619,15 +620,15 @@ int run_linear_backward(veto_handle_t h, hipStream_t s, const TrainWs& w, const 
   if (ks > 64) ks = 64;
   if (ks < 1) ks = 1;
   const size_t mp = ((size_t)M + 32 * (size_t)ks - 1) / (32 * (size_t)ks) * 32 * (size_t)ks;
-  if (mp > w.mp2) return fail(VETO_ERR_WORKSPACE, "weight-gradient operand buffer too small");
-  HIP_TRY(launch_prep_grad(dy, N, M, N, w.dsplit, w.at, (int)mp, db ? w.colp : nullptr, xf, s));
+  if (mp > w.mp2) return fail(VETO_ERR_WORKSPACE, "weight-gradient partial buffer too small");
+  HIP_TRY(launch_prep_grad(dy, N, M, N, w.dsplit, nullptr, (int)mp, db ? w.colp : nullptr, xf, s));
   if (db) HIP_TRY(launch_column_sums(w.colp, N, (int)(mp / 32), N, db, w.col_partial, column_sums_chunks(), s));
-  HIP_TRY(launch_transpose_from_split(x_split, 2 * (long)K, M, K, w.wt, (int)mp, s));
   HIP_TRY(hipMemsetAsync(dw, 0, (size_t)N * K * 4, s));
   {
     GemmArgs g{};
-    g.a = w.at; g.w = w.wt; g.c = dw;
+    g.a = w.dsplit; g.w = x_split; g.c = dw;
     g.M = N; g.N = K; g.K = (int)mp; g.ldc = K; g.k_splits = ks;
+    g.tn = 1; g.lda = 2 * (long)N; g.ldw = 2 * (long)K; g.k_valid = M; g.zero = w.zero;
     ProfScope ps(h, s, "bwd_wgrad", 2.0 * M * (double)N * K, 0);
     HIP_TRY(launch_gemm_split(g, EPI_ATOMIC, 0, s));
   }
@@ -778,6 +779,7 @@ int veto_backward(veto_handle_t h, void* stream, const veto_inputs_t* in, const 
   const std::string T = kT;
   auto G = [&](const std::string& name) { return grads + h->params[h->index.at(name)].offset; };
   HIP_TRY(hipMemsetAsync(grads, 0, veto_grad_floats(h) * 4, s));
+  HIP_TRY(hipMemsetAsync(ws.zero, 0, 1024, s));
 
   // ---- classifier head ----------------------------------------------------------------------------------------
   HIP_TRY(hipMemsetAsync(ws.dx, 0, (size_t)M * kDim * 4, s));
@@ -851,13 +853,12 @@ int veto_backward(veto_handle_t h, void* stream, const veto_inputs_t* in, const 
       if (ks > max_ks) ks = max_ks;
       if (ks < 1) ks = 1;
       const size_t mp = ((size_t)R + 32 * (size_t)ks - 1) / (32 * (size_t)ks) * 32 * (size_t)ks;
-      if (mp > ws.mp2) return fail(VETO_ERR_WORKSPACE, "weight-gradient operand buffer too small");
-      HIP_TRY(launch_transpose_from_split(ws.pa, 2 * 2048, R, N, ws.at, (int)mp, s));
-      HIP_TRY(launch_transpose_split(ws.dpatch, K, R, K, ws.wt, (int)mp, s));
+      HIP_TRY(launch_split_rows(ws.dpatch, ws.dsplit, (size_t)R, K, s));
       HIP_TRY(hipMemsetAsync(ws.dwcat_t, 0, (size_t)N * K * 4, s));
       GemmArgs g{};
-      g.a = ws.at; g.w = ws.wt; g.c = ws.dwcat_t;
+      g.a = ws.pa; g.w = ws.dsplit; g.c = ws.dwcat_t;
       g.M = N; g.N = K; g.K = (int)mp; g.ldc = K; g.k_splits = ks;
+      g.tn = 1; g.lda = 2 * (long)N; g.ldw = 2 * (long)K; g.k_valid = R; g.zero = ws.zero;
       HIP_TRY(launch_gemm_split(g, EPI_ATOMIC, 0, s));
     }
     HIP_TRY(launch_patch_weight_grad(ws.dwcat_t, G(pe + "proj_d.weight"), G(pe + "proj_v.weight"), s));
@@ -1259,8 +1260,15 @@ static int wgrad_splits(int n, int k, int m, int k_splits) {
 
 static size_t wgrad_mp(int m, int ks) { return ((size_t)m + 32 * (size_t)ks - 1) / (32 * (size_t)ks) * 32 * (size_t)ks; }
 
+// n % 32 == 0 (every Linear of the transformer): the row-major form, both operands as the split rows the backward holds
+// anyway, transposed on their way out of LDS (GemmArgs::tn).  Otherwise: explicit transposed split copies.
+static size_t wgrad_tn_bytes(int m, int n, int k) {
+  return align_up(((size_t)m + 1) * n * 4, 256) + align_up(((size_t)m + 1) * k * 4, 256) + 1024;
+}
+
 size_t veto_debug_wgrad_workspace_bytes(int32_t m, int32_t n, int32_t k, int32_t k_splits) {
   if (m <= 0 || n <= 0 || k <= 0) return 0;
+  if (n % 32 == 0) return wgrad_tn_bytes(m, n, k);
   const size_t mp = wgrad_mp(m, wgrad_splits(n, k, m, k_splits));
   return align_up((size_t)gemm_rows_padded(n) * mp * 4, 256) + align_up((size_t)k * mp * 4, 256);
 }
@@ -1274,16 +1282,29 @@ int veto_debug_wgrad(void* stream, const float* dy, const float* x, float* dw, i
   const int ks = wgrad_splits(n, k, m, k_splits);
   const size_t mp = wgrad_mp(m, ks);
   char* base = (char*)workspace;
-  const size_t a_bytes = align_up((size_t)gemm_rows_padded(n) * mp * 4, 256);
-  __bf16* a_s = (__bf16*)base;
-  __bf16* w_s = (__bf16*)(base + a_bytes);
-  HIP_TRY(hipMemsetAsync(base, 0, a_bytes, s));   // rows n..padded stay zero
-  HIP_TRY(launch_transpose_split(dy, n, m, n, a_s, (int)mp, s));
-  HIP_TRY(launch_transpose_split(x, k, m, k, w_s, (int)mp, s));
   HIP_TRY(hipMemsetAsync(dw, 0, (size_t)n * k * 4, s));
   GemmArgs g{};
-  g.a = a_s; g.w = w_s; g.c = dw;
+  g.c = dw;
   g.M = n; g.N = k; g.K = (int)mp; g.ldc = k; g.k_splits = ks;
+  if (n % 32 == 0) {
+    const size_t a_bytes = align_up(((size_t)m + 1) * n * 4, 256), w_bytes = align_up(((size_t)m + 1) * k * 4, 256);
+    __bf16* a_s = (__bf16*)base;
+    __bf16* w_s = (__bf16*)(base + a_bytes);
+    HIP_TRY(hipMemsetAsync(base, 0, a_bytes + w_bytes + 1024, s));   // the row behind the last one is read (never used) by partial tiles
+    HIP_TRY(launch_split_rows(dy, a_s, (size_t)m, n, s));
+    HIP_TRY(launch_split_rows(x, w_s, (size_t)m, k, s));
+    g.a = a_s; g.w = w_s;
+    g.tn = 1; g.lda = 2 * (long)n; g.ldw = 2 * (long)k; g.k_valid = m;
+    g.zero = (const __bf16*)(base + a_bytes + w_bytes);
+  } else {
+    const size_t a_bytes = align_up((size_t)gemm_rows_padded(n) * mp * 4, 256);
+    __bf16* a_s = (__bf16*)base;
+    __bf16* w_s = (__bf16*)(base + a_bytes);
+    HIP_TRY(hipMemsetAsync(base, 0, a_bytes, s));   // rows n..padded stay zero
+    HIP_TRY(launch_transpose_split(dy, n, m, n, a_s, (int)mp, s));
+    HIP_TRY(launch_transpose_split(x, k, m, k, w_s, (int)mp, s));
+    g.a = a_s; g.w = w_s;
+  }
   hipError_t e = launch_gemm_split(g, EPI_ATOMIC, 0, s);
   if (e != hipSuccess) return fail(e == hipErrorInvalidValue ? VETO_ERR_INVALID : VETO_ERR_HIP, "wgrad gemm launch failed: %s", hipGetErrorString(e));
   return VETO_OK;
