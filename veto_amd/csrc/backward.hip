@@ -41,7 +41,8 @@ __device__ __forceinline__ float row_all(float v) {
 
 template <int DH>
 __global__ __launch_bounds__(kAttnBwdThreads) void attention_backward_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
-                                                                             float* __restrict__ dqkv, int n_pair, int heads) {
+                                                                             float* __restrict__ dqkv, __bf16* __restrict__ dqkv_split,
+                                                                             int n_pair, int heads) {
   constexpr int TP = 20, LD = DH + 4, D4 = DH / 4, MAT = TP * LD;
   constexpr int NS = DH == 144 ? 3 : 6, SL = DH / NS;       // slices of the head dimension in phase A
   constexpr int CHUNKS = 4 * kTokens * D4, ROUNDS = (CHUNKS + kAttnBwdThreads - 1) / kAttnBwdThreads;
@@ -163,6 +164,26 @@ __global__ __launch_bounds__(kAttnBwdThreads) void attention_backward_kernel(con
       for (int r = 0; r < 4; ++r) acc[r] += cf[r] * m;
     }
     const float f = prod < 2 ? scale : 1.f;
+    if (dqkv_split) {   // training path: straight to the split rows [M, 2 * 1728] the QKV weight / input gradient GEMMs read
+      const int col = prod * kDim + head * DH + 4 * c;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (t0 + r >= kTokens) continue;
+        const f32x4 o = acc[r] * f;
+        bf16x4 hi, lo;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          __bf16 hh, ll;
+          split_bf16(o[e], hh, ll);
+          hi[e] = hh;
+          lo[e] = ll;
+        }
+        __bf16* d = dqkv_split + ((size_t)pair * kTokens + t0 + r) * (2 * 3 * kDim) + split_index(col);
+        *(bf16x4*)d = hi;
+        *(bf16x4*)(d + 32) = lo;
+      }
+      continue;
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r)
       if (t0 + r < kTokens) *(f32x4*)(dst + (size_t)(t0 + r) * 3 * kDim + prod * kDim + 4 * c) = acc[r] * f;
@@ -316,7 +337,8 @@ __global__ __launch_bounds__(256) void gelu_backward_kernel(const float* __restr
 
 // persistent grid = what the device holds at once (CUs x resident workgroups of this instantiation), found once
 template <int DH>
-static hipError_t launch_attention_backward_dh(const float* qkv, const float* dout, float* dqkv, int n_pair, int heads, hipStream_t s) {
+static hipError_t launch_attention_backward_dh(const float* qkv, const float* dout, float* dqkv, __bf16* dqkv_split, int n_pair, int heads,
+                                               hipStream_t s) {
   static int resident = 0;
   if (!resident) {
     int dev = 0, cus = 0, per_cu = 0;
@@ -328,16 +350,16 @@ static hipError_t launch_attention_backward_dh(const float* qkv, const float* do
   }
   const long total = (long)n_pair * heads;
   const unsigned blocks = (unsigned)(total < resident ? total : resident);
-  VETO_LAUNCH(attention_backward_kernel<DH>, dim3(blocks), dim3(kAttnBwdThreads), 0, s, qkv, dout, dqkv, n_pair, heads);
+  VETO_LAUNCH(attention_backward_kernel<DH>, dim3(blocks), dim3(kAttnBwdThreads), 0, s, qkv, dout, dqkv, dqkv_split, n_pair, heads);
   return hipGetLastError();
 }
 
-hipError_t launch_attention_backward(const float* qkv, const float* dout, float* dqkv, int n_pair, int heads, hipStream_t s) {
-  if (heads <= 0 || kDim % heads != 0 || n_pair <= 0) return hipErrorInvalidValue;
+hipError_t launch_attention_backward(const float* qkv, const float* dout, float* dqkv, __bf16* dqkv_split, int n_pair, int heads, hipStream_t s) {
+  if (heads <= 0 || kDim % heads != 0 || n_pair <= 0 || (!dqkv == !dqkv_split)) return hipErrorInvalidValue;
   const int dh = kDim / heads;
-  if (dh == 72) return launch_attention_backward_dh<72>(qkv, dout, dqkv, n_pair, heads, s);
-  if (dh == 96) return launch_attention_backward_dh<96>(qkv, dout, dqkv, n_pair, heads, s);
-  if (dh == 144) return launch_attention_backward_dh<144>(qkv, dout, dqkv, n_pair, heads, s);
+  if (dh == 72) return launch_attention_backward_dh<72>(qkv, dout, dqkv, dqkv_split, n_pair, heads, s);
+  if (dh == 96) return launch_attention_backward_dh<96>(qkv, dout, dqkv, dqkv_split, n_pair, heads, s);
+  if (dh == 144) return launch_attention_backward_dh<144>(qkv, dout, dqkv, dqkv_split, n_pair, heads, s);
   return hipErrorInvalidValue;
 }
 

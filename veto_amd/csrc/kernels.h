@@ -249,7 +249,8 @@ hipError_t launch_meet_sample(const MeetSampleArgs& a, hipStream_t s);
 
 // ---- backward building blocks (backward.hip) -----------------------------------------------------------------
 // qkv, dqkv: [n_pair*19, 1728]; dout: [n_pair*19, 576] (gradient of the attention output before the out projection)
-hipError_t launch_attention_backward(const float* qkv, const float* dout, float* dqkv, int n_pair, int heads, hipStream_t s);
+// exactly one of dqkv (fp32 [n_pair*19, 1728]) and dqkv_split (split rows [n_pair*19, 2*1728]) is written
+hipError_t launch_attention_backward(const float* qkv, const float* dout, float* dqkv, __bf16* dqkv_split, int n_pair, int heads, hipStream_t s);
 // dx = LayerNorm backward of dy w.r.t. x (+ dres if given); dgamma_dbeta [2, 576]; partial: workspace of
 // layernorm_backward_partial_floats(rows) floats
 size_t layernorm_backward_partial_floats(int rows);

@@ -611,8 +611,10 @@ TrainWs carve_train(char* base, veto_handle_t h, int n_obj, int n_pair) {
 // One pass over dY (prep_grad_kernel) produces its split rows -- the A operand of the input-gradient GEMM AND, read through
 // transposing LDS loads, of the weight-gradient GEMM (GemmArgs::tn; the saved activation x_split is its other operand as it
 // is) -- and the bias partials.  No transposed copies of dY or x exist.
+// dy == nullptr: the producer (attention backward) has already written the split rows into w.dsplit; no bias then.
 int run_linear_backward(veto_handle_t h, hipStream_t s, const TrainWs& w, const float* dy, int M, int N, const __bf16* x_split, int K,
                         const float* weight, float* dw, float* db, float* dx, const GradXform& xf = GradXform()) {
+  if (!dy && db) return fail(VETO_ERR_INVALID, "a pre-split gradient cannot feed a bias gradient");
   const int out_tiles = ((N + 255) / 256) * (K / 192);
   int ks = 2 * 256 / out_tiles;
   const int max_ks = (M + 32 * 64 - 1) / (32 * 64);
@@ -621,7 +623,7 @@ int run_linear_backward(veto_handle_t h, hipStream_t s, const TrainWs& w, const 
   if (ks < 1) ks = 1;
   const size_t mp = ((size_t)M + 32 * (size_t)ks - 1) / (32 * (size_t)ks) * 32 * (size_t)ks;
   if (mp > w.mp2) return fail(VETO_ERR_WORKSPACE, "weight-gradient partial buffer too small");
-  HIP_TRY(launch_prep_grad(dy, N, M, N, w.dsplit, nullptr, (int)mp, db ? w.colp : nullptr, xf, s));
+  if (dy) HIP_TRY(launch_prep_grad(dy, N, M, N, w.dsplit, nullptr, (int)mp, db ? w.colp : nullptr, xf, s));
   if (db) HIP_TRY(launch_column_sums(w.colp, N, (int)(mp / 32), N, db, w.col_partial, column_sums_chunks(), s));
   HIP_TRY(hipMemsetAsync(dw, 0, (size_t)N * K * 4, s));
   {
@@ -817,8 +819,8 @@ int veto_backward(veto_handle_t h, void* stream, const veto_inputs_t* in, const 
     rc = run_linear_backward(h, s, ws, ws.dmid, M, kDim, t.ao, kDim, h->p(lname(l, "0.fn.to_out.0.weight")),
                              G(lname(l, "0.fn.to_out.0.weight")), G(lname(l, "0.fn.to_out.0.bias")), ws.dtmp, drop);
     if (rc) return rc;
-    HIP_TRY(launch_attention_backward(t.qkv, ws.dtmp, ws.dbig, n_pair, H, s));
-    rc = run_linear_backward(h, s, ws, ws.dbig, M, 3 * kDim, t.a1, kDim, h->p(lname(l, "0.fn.to_qkv.weight")),
+    HIP_TRY(launch_attention_backward(t.qkv, ws.dtmp, nullptr, ws.dsplit, n_pair, H, s));
+    rc = run_linear_backward(h, s, ws, nullptr, M, 3 * kDim, t.a1, kDim, h->p(lname(l, "0.fn.to_qkv.weight")),
                              G(lname(l, "0.fn.to_qkv.weight")), nullptr, ws.dtmp);
     if (rc) return rc;
     HIP_TRY(launch_layernorm_backward(t.xin, ws.dtmp, w.ln1_w, ws.dmid, ws.dx, ws.dgb, ws.ln_partial, M, s));
@@ -1312,7 +1314,7 @@ int veto_debug_wgrad(void* stream, const float* dy, const float* x, float* dw, i
 
 int veto_debug_attention_backward(void* stream, const float* qkv, const float* dout, float* dqkv, int32_t n_pair, int32_t heads) {
   if (!qkv || !dout || !dqkv || n_pair <= 0) return fail(VETO_ERR_INVALID, "bad argument");
-  hipError_t e = launch_attention_backward(qkv, dout, dqkv, n_pair, heads, (hipStream_t)stream);
+  hipError_t e = launch_attention_backward(qkv, dout, dqkv, nullptr, n_pair, heads, (hipStream_t)stream);
   if (e != hipSuccess) return fail(e == hipErrorInvalidValue ? VETO_ERR_INVALID : VETO_ERR_HIP, "attention backward: %s (heads must give a head width of 72, 96 or 144)", hipGetErrorString(e));
   return VETO_OK;
 }
