@@ -262,9 +262,8 @@ hipError_t launch_column_sums(const float* dy, long ld, int rows, int n_cols, fl
 hipError_t launch_gelu_backward(const float* pre, const float* dh, float* dpre, size_t n, hipStream_t s);
 
 // ---- training path around the GEMMs (train.hip) ---------------------------------------------------------------
-hipError_t launch_transpose_from_split(const __bf16* src, long ld, int M, int K, __bf16* dst, int Mp, hipStream_t s);
-// dY fp32 [M, N] -> split rows [M, 2N], split rows of the transpose [N, 2*Mp] and (optional) per-32-row column sums
-// col_partial [Mp/32, N] in one pass.  GradXform: the elementwise backward that precedes this Linear, applied on load
+// dY fp32 [M, N] -> split rows [M, 2N] (the operand of BOTH gradient GEMMs) and (optional) per-32-row column sums
+// col_partial [Mp/32, N] (Mp = M rounded up to 32, >= M) in one pass.  GradXform: the elementwise backward that precedes this Linear, applied on load
 // (dY itself is not rewritten): gelu'(pre) or the forward's dropout mask.
 enum GradXformMode { XF_NONE = 0, XF_GELU = 1, XF_DROP = 2 };
 struct GradXform {
@@ -274,7 +273,7 @@ struct GradXform {
   unsigned thresh = 0;
   float scale = 1.f;
 };
-hipError_t launch_prep_grad(const float* src, long ld, int M, int N, __bf16* rows_out, __bf16* t_out, int Mp, float* col_partial,
+hipError_t launch_prep_grad(const float* src, long ld, int M, int N, __bf16* rows_out, int Mp, float* col_partial,
                             const GradXform& xf, hipStream_t s);
 hipError_t launch_gelu_split(const float* pre, __bf16* dst, size_t rows, int n_cols, hipStream_t s);
 // dx[p*19, :] = dlogits[p] . W (other rows untouched); dw [n_out, 576], db [n_out]; x = token matrix [n_pair*19, 576]

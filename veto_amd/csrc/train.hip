@@ -1,6 +1,6 @@
 // Kernels of the training path around the GEMMs: what the forward needs to keep
-// activations (un-fused GELU + split, so the pre-activation survives), the transposing operand kernel for weight
-// gradients whose activation operand is stored in split rows, the backward of the classifier head, of the token
+// activations (un-fused GELU + split, so the pre-activation survives), the one-pass preparation of a gradient matrix for
+// the two GEMMs of a Linear's backward, the backward of the classifier head, of the token
 // assembly (scatter of the token gradients into the per-object tables) and of the per-object stage (the small
 // projections, BatchNorm, embeddings), and the inverse of the weight re-layouts of rowops.hip.
 // The per-object matrices are tiny (a few hundred objects x <= 1152 columns): plain fp32 kernels.
@@ -11,46 +11,14 @@ namespace veto {
 
 namespace {
 
-// ---- split rows [M, 2K] -> split rows of the transpose [K, 2*Mp] (hi and lo planes move unchanged) ---------------
-__global__ __launch_bounds__(256) void transpose_from_split_kernel(const __bf16* __restrict__ src, long ld, int M, int K,
-                                                                   __bf16* __restrict__ dst, int Mp) {
-  __shared__ __bf16 hi[32][66], lo[32][66];
-  const int m0 = blockIdx.x * 32, k0 = blockIdx.y * 64, tid = threadIdx.x;
-  const int tx = tid & 63, ty = tid >> 6;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int m = m0 + ty * 8 + i, k = k0 + tx;
-    __bf16 h = (__bf16)0.f, l = (__bf16)0.f;
-    if (m < M && k < K) {
-      const __bf16* p = src + (size_t)m * ld + split_index(k);
-      h = p[0];
-      l = p[32];
-    }
-    hi[ty * 8 + i][tx] = h;
-    lo[ty * 8 + i][tx] = l;
-  }
-  __syncthreads();
-#pragma unroll
-  for (int r = 0; r < 2; ++r) {
-    const int id = tid + 256 * r, kl = id >> 3, piece = id & 7;
-    if (k0 + kl >= K) continue;
-    bf16x8 out;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) out[e] = piece < 4 ? hi[8 * piece + e][kl] : lo[8 * (piece - 4) + e][kl];
-    __bf16* d = dst + (size_t)(k0 + kl) * (2 * (size_t)Mp) + (size_t)(m0 >> 5) * 64 + (piece < 4 ? 8 * piece : 32 + 8 * (piece - 4));
-    *(bf16x8*)d = out;
-  }
-}
-
-// ---- one pass over a gradient matrix dY fp32 [M, N]: split rows (A operand of the input-gradient GEMM), split rows of the
-// transpose (operand of the weight-gradient GEMM) and, optionally, per-block column sums (bias gradient, folded later).
-// 32 (m) x 64 (n) tile through LDS; the three consumers used to read dY once each.
+// ---- one pass over a gradient matrix dY fp32 [M, N]: split rows (the operand of the input-gradient GEMM and, read through
+// transposing LDS loads, of the weight-gradient GEMM) and, optionally, per-block column sums (bias gradient, folded later).
+// 32 (m) x 64 (n) tile through LDS.
 // XF folds the elementwise op that precedes the Linear's output in the backward chain into the load: XF_GELU multiplies by
 // gelu'(pre) (model_veto.py:140, exact erf), XF_DROP applies the counter-based dropout mask of the forward (element m * N + n).
 template <int XF>
 __global__ __launch_bounds__(256) void prep_grad_kernel(const float* __restrict__ src, long ld, int M, int N, __bf16* __restrict__ rows_out,
-                                                        __bf16* __restrict__ t_out, int Mp, float* __restrict__ col_partial,
-                                                        GradXform xf) {
+                                                        float* __restrict__ col_partial, GradXform xf) {
   __shared__ float t[32][65];
   const int m0 = blockIdx.x * 32, n0 = blockIdx.y * 64, tid = threadIdx.x;
   const int tx = tid & 63, ty = tid >> 6;
@@ -71,22 +39,6 @@ __global__ __launch_bounds__(256) void prep_grad_kernel(const float* __restrict_
     t[ty * 8 + i][tx] = v;
   }
   __syncthreads();
-  // transposed split rows (optional): output row n receives the 32-m block [hi | lo]
-#pragma unroll
-  for (int r = 0; r < 2; ++r) {
-    const int id = tid + 256 * r, nl = id >> 3, piece = id & 7;
-    if (t_out && n0 + nl < N) {
-      bf16x8 out;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        __bf16 h, l;
-        split_bf16(t[8 * (piece & 3) + e][nl], h, l);
-        out[e] = piece < 4 ? h : l;
-      }
-      __bf16* d = t_out + (size_t)(n0 + nl) * (2 * (size_t)Mp) + (size_t)(m0 >> 5) * 64 + (piece < 4 ? 8 * piece : 32 + 8 * (piece - 4));
-      *(bf16x8*)d = out;
-    }
-  }
   // split rows: row m, the two 32-column blocks of this tile; one 8-column piece per thread
   {
     const int ml = tid >> 3, piece = tid & 7;       // 32 rows x 8 pieces of 8 columns
@@ -334,24 +286,18 @@ __global__ __launch_bounds__(256) void patch_weight_grad_kernel(const float* __r
 
 }  // namespace
 
-hipError_t launch_transpose_from_split(const __bf16* src, long ld, int M, int K, __bf16* dst, int Mp, hipStream_t s) {
-  if (Mp % 32 != 0 || Mp < M) return hipErrorInvalidValue;
-  VETO_LAUNCH(transpose_from_split_kernel, dim3(Mp / 32, (K + 63) / 64), dim3(256), 0, s, src, ld, M, K, dst, Mp);
-  return hipGetLastError();
-}
-
-hipError_t launch_prep_grad(const float* src, long ld, int M, int N, __bf16* rows_out, __bf16* t_out, int Mp, float* col_partial, const GradXform& xf,
+hipError_t launch_prep_grad(const float* src, long ld, int M, int N, __bf16* rows_out, int Mp, float* col_partial, const GradXform& xf,
                             hipStream_t s) {
   if (Mp % 32 != 0 || Mp < M || N % 32 != 0) return hipErrorInvalidValue;
   const dim3 grid(Mp / 32, (N + 63) / 64);
   if (xf.mode == XF_GELU) {
     if (!xf.pre) return hipErrorInvalidValue;
-    VETO_LAUNCH(prep_grad_kernel<XF_GELU>, grid, dim3(256), 0, s, src, ld, M, N, rows_out, t_out, Mp, col_partial, xf);
+    VETO_LAUNCH(prep_grad_kernel<XF_GELU>, grid, dim3(256), 0, s, src, ld, M, N, rows_out, col_partial, xf);
   } else if (xf.mode == XF_DROP) {
     if (ld != N) return hipErrorInvalidValue;
-    VETO_LAUNCH(prep_grad_kernel<XF_DROP>, grid, dim3(256), 0, s, src, ld, M, N, rows_out, t_out, Mp, col_partial, xf);
+    VETO_LAUNCH(prep_grad_kernel<XF_DROP>, grid, dim3(256), 0, s, src, ld, M, N, rows_out, col_partial, xf);
   } else {
-    VETO_LAUNCH(prep_grad_kernel<XF_NONE>, grid, dim3(256), 0, s, src, ld, M, N, rows_out, t_out, Mp, col_partial, xf);
+    VETO_LAUNCH(prep_grad_kernel<XF_NONE>, grid, dim3(256), 0, s, src, ld, M, N, rows_out, col_partial, xf);
   }
   return hipGetLastError();
 }

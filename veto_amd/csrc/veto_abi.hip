@@ -623,7 +623,7 @@ int run_linear_backward(veto_handle_t h, hipStream_t s, const TrainWs& w, const 
   if (ks < 1) ks = 1;
   const size_t mp = ((size_t)M + 32 * (size_t)ks - 1) / (32 * (size_t)ks) * 32 * (size_t)ks;
   if (mp > w.mp2) return fail(VETO_ERR_WORKSPACE, "weight-gradient partial buffer too small");
-  if (dy) HIP_TRY(launch_prep_grad(dy, N, M, N, w.dsplit, nullptr, (int)mp, db ? w.colp : nullptr, xf, s));
+  if (dy) HIP_TRY(launch_prep_grad(dy, N, M, N, w.dsplit, (int)mp, db ? w.colp : nullptr, xf, s));
   if (db) HIP_TRY(launch_column_sums(w.colp, N, (int)(mp / 32), N, db, w.col_partial, column_sums_chunks(), s));
   HIP_TRY(hipMemsetAsync(dw, 0, (size_t)N * K * 4, s));
   {
