@@ -212,7 +212,9 @@ hipError_t launch_gemm_split(GemmArgs g, int epi, int precision, hipStream_t s) 
   if (g.lda == 0) g.lda = 2 * (long)g.K;
   g.tiles_m = (g.M + BM - 1) / BM;
   g.tiles_n = g.N / BN;
-  if (g.tn) return launch_gemm_split_ps(g, epi, precision, s);   // row-major weight-gradient form: persistent kernel only
+  // the training-only forms (split-K / atomic, row-major weight gradients, dropout before the residual) exist in the
+  // persistent kernel only
+  if (g.tn || epi == EPI_ATOMIC || epi == EPI_RESID_DROP) return launch_gemm_split_ps(g, epi, precision, s);
   // VETO_GEMM_VARIANT (A/B knob): "ps" persistent + loader waves (default), "plain" homogeneous waves.
   static const bool plain = [] {
     const char* e = getenv("VETO_GEMM_VARIANT");
