@@ -42,7 +42,7 @@ __device__ __forceinline__ float row_all(float v) {
 template <int DH>
 __global__ __launch_bounds__(kAttnBwdThreads) void attention_backward_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
                                                                              float* __restrict__ dqkv, __bf16* __restrict__ dqkv_split,
-                                                                             int n_pair, int heads) {
+                                                                             int n_pair, int heads, int cls_only) {
   constexpr int TP = 20, LD = DH + 4, D4 = DH / 4, MAT = TP * LD;
   constexpr int NS = DH == 144 ? 3 : 6, SL = DH / NS;       // slices of the head dimension in phase A
   constexpr int CHUNKS = 4 * kTokens * D4, ROUNDS = (CHUNKS + kAttnBwdThreads - 1) / kAttnBwdThreads;
@@ -63,13 +63,16 @@ __global__ __launch_bounds__(kAttnBwdThreads) void attention_backward_kernel(con
   auto fetch = [&](long item) {
     const int pair = (int)(item / heads), head = (int)(item % heads);
     const float* src = qkv + (size_t)pair * kTokens * (3 * kDim) + head * DH;
-    const float* gsrc = dout + (size_t)pair * kTokens * kDim + head * DH;
+    // cls_only (last layer, model_veto.py:23 consumes x[:, 0] only): dout is compact [n_pair, 576] (the CLS query's row), the
+    // queries and output gradients of tokens 1..18 do not exist and enter as zeros -> dQ rows 1..18 = 0, dK / dV from row 0
+    const float* gsrc = dout + (cls_only ? (size_t)pair * kDim : (size_t)pair * kTokens * kDim) + head * DH;
 #pragma unroll
     for (int r = 0; r < ROUNDS; ++r) {
       const int e = tid + r * kAttnBwdThreads;
       if (e < CHUNKS) {
         const int mat = e / (kTokens * D4), rem = e % (kTokens * D4), t = rem / D4, c = rem % D4;
-        pre[r] = mat < 3 ? *(const f32x4*)(src + (size_t)t * 3 * kDim + mat * kDim + 4 * c) : *(const f32x4*)(gsrc + (size_t)t * kDim + 4 * c);
+        if (cls_only && t > 0 && (mat == 0 || mat == 3)) pre[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+        else pre[r] = mat < 3 ? *(const f32x4*)(src + (size_t)t * 3 * kDim + mat * kDim + 4 * c) : *(const f32x4*)(gsrc + (size_t)t * kDim + 4 * c);
       }
     }
   };
@@ -203,8 +206,8 @@ constexpr int kLnSlots = 256 / kLnLanes;           // rows in flight per block
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void layernorm_backward_kernel(const float* __restrict__ x, const float* __restrict__ dy,
-                                                                 const float* __restrict__ gamma, const float* __restrict__ dres,
-                                                                 float* __restrict__ dx, float* __restrict__ partial, int rows) {
+                                                                 const float* __restrict__ gamma, const float* dres,
+                                                                 float* dx, float* __restrict__ partial, int rows) {   // dres may be dx
   __shared__ float s_dg[kDim], s_db[kDim], s_w[kDim];
   for (int c = threadIdx.x; c < kDim; c += 256) { s_dg[c] = 0.f; s_db[c] = 0.f; s_w[c] = gamma[c]; }
   __syncthreads();
@@ -338,7 +341,7 @@ __global__ __launch_bounds__(256) void gelu_backward_kernel(const float* __restr
 // persistent grid = what the device holds at once (CUs x resident workgroups of this instantiation), found once
 template <int DH>
 static hipError_t launch_attention_backward_dh(const float* qkv, const float* dout, float* dqkv, __bf16* dqkv_split, int n_pair, int heads,
-                                               hipStream_t s) {
+                                               int cls_only, hipStream_t s) {
   static int resident = 0;
   if (!resident) {
     int dev = 0, cus = 0, per_cu = 0;
@@ -350,16 +353,17 @@ static hipError_t launch_attention_backward_dh(const float* qkv, const float* do
   }
   const long total = (long)n_pair * heads;
   const unsigned blocks = (unsigned)(total < resident ? total : resident);
-  VETO_LAUNCH(attention_backward_kernel<DH>, dim3(blocks), dim3(kAttnBwdThreads), 0, s, qkv, dout, dqkv, dqkv_split, n_pair, heads);
+  VETO_LAUNCH(attention_backward_kernel<DH>, dim3(blocks), dim3(kAttnBwdThreads), 0, s, qkv, dout, dqkv, dqkv_split, n_pair, heads, cls_only);
   return hipGetLastError();
 }
 
-hipError_t launch_attention_backward(const float* qkv, const float* dout, float* dqkv, __bf16* dqkv_split, int n_pair, int heads, hipStream_t s) {
+hipError_t launch_attention_backward(const float* qkv, const float* dout, float* dqkv, __bf16* dqkv_split, int n_pair, int heads, int cls_only,
+                                     hipStream_t s) {
   if (heads <= 0 || kDim % heads != 0 || n_pair <= 0 || (!dqkv == !dqkv_split)) return hipErrorInvalidValue;
   const int dh = kDim / heads;
-  if (dh == 72) return launch_attention_backward_dh<72>(qkv, dout, dqkv, dqkv_split, n_pair, heads, s);
-  if (dh == 96) return launch_attention_backward_dh<96>(qkv, dout, dqkv, dqkv_split, n_pair, heads, s);
-  if (dh == 144) return launch_attention_backward_dh<144>(qkv, dout, dqkv, dqkv_split, n_pair, heads, s);
+  if (dh == 72) return launch_attention_backward_dh<72>(qkv, dout, dqkv, dqkv_split, n_pair, heads, cls_only, s);
+  if (dh == 96) return launch_attention_backward_dh<96>(qkv, dout, dqkv, dqkv_split, n_pair, heads, cls_only, s);
+  if (dh == 144) return launch_attention_backward_dh<144>(qkv, dout, dqkv, dqkv_split, n_pair, heads, cls_only, s);
   return hipErrorInvalidValue;
 }
 

@@ -250,7 +250,9 @@ hipError_t launch_meet_sample(const MeetSampleArgs& a, hipStream_t s);
 // ---- backward building blocks (backward.hip) -----------------------------------------------------------------
 // qkv, dqkv: [n_pair*19, 1728]; dout: [n_pair*19, 576] (gradient of the attention output before the out projection)
 // exactly one of dqkv (fp32 [n_pair*19, 1728]) and dqkv_split (split rows [n_pair*19, 2*1728]) is written
-hipError_t launch_attention_backward(const float* qkv, const float* dout, float* dqkv, __bf16* dqkv_split, int n_pair, int heads, hipStream_t s);
+// cls_only: dout is compact [n_pair, 576] (gradient of the CLS query's output only), q rows 1..18 of qkv are not read
+hipError_t launch_attention_backward(const float* qkv, const float* dout, float* dqkv, __bf16* dqkv_split, int n_pair, int heads, int cls_only,
+                                     hipStream_t s);
 // dx = LayerNorm backward of dy w.r.t. x (+ dres if given); dgamma_dbeta [2, 576]; partial: workspace of
 // layernorm_backward_partial_floats(rows) floats
 size_t layernorm_backward_partial_floats(int rows);
@@ -276,11 +278,11 @@ struct GradXform {
 hipError_t launch_prep_grad(const float* src, long ld, int M, int N, __bf16* rows_out, int Mp, float* col_partial,
                             const GradXform& xf, hipStream_t s);
 hipError_t launch_gelu_split(const float* pre, __bf16* dst, size_t rows, int n_cols, hipStream_t s);
-// dx[p*19, :] = dlogits[p] . W (other rows untouched); dw [n_out, 576], db [n_out]; x = token matrix [n_pair*19, 576]
+// dx row p = dlogits[p] . W; dw [n_out, 576], db [n_out]; row p of x and of dx at + p * ld floats (the CLS rows)
 // partial: workspace of head_backward_partial_floats(n_out) floats
 size_t head_backward_partial_floats(int n_out);
 hipError_t launch_head_backward(const float* dlogits, const float* w, const float* x, float* dx, float* dw, float* db, float* partial,
-                                int n_pair, int n_out, hipStream_t s);
+                                int n_pair, int n_out, long ld, hipStream_t s);
 hipError_t launch_assemble_backward(const float* dx, const int32_t* subj, const int32_t* obj, const float* lc, float* dpatch, float* dlc,
                                     int n_pair, hipStream_t s);
 hipError_t launch_sgemm_tn(const float* a, long lda, const float* b, long ldb, float* c, long ldc, int n, int ka, int kb, hipStream_t s);

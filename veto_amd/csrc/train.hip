@@ -90,26 +90,26 @@ __global__ __launch_bounds__(256) void gelu_split_kernel(const float* __restrict
 }
 
 // ---- classifier head: logits = cls . W^T + b, cls = row p*19 of x ------------------------------------------------
-// dx[p*19, k] = sum_c dlogits[p, c] W[c, k]  (dx zero elsewhere: set by the caller)
+// dx[p, k] = sum_c dlogits[p, c] W[c, k]  (row p at dx + p * ld)
 __global__ __launch_bounds__(576) void head_dcls_kernel(const float* __restrict__ dlogits, const float* __restrict__ w,
-                                                        float* __restrict__ dx, int n_out) {
+                                                        float* __restrict__ dx, int n_out, long ld) {
   extern __shared__ float s_g[];
   const int p = blockIdx.x, k = threadIdx.x;
   for (int c = k; c < n_out; c += 576) s_g[c] = dlogits[(size_t)p * n_out + c];
   __syncthreads();
   float acc = 0.f;
   for (int c = 0; c < n_out; ++c) acc += s_g[c] * w[(size_t)c * kDim + k];
-  dx[(size_t)p * kTokens * kDim + k] = acc;
+  dx[(size_t)p * ld + k] = acc;
 }
 
-// dW[c, k] = sum_p dlogits[p, c] x[p*19, k]: pair chunk blockIdx.y writes partial[chunk, c, k]; a fixed-order fold
+// dW[c, k] = sum_p dlogits[p, c] x[p, k] (x row p at x + p * ld): pair chunk blockIdx.y writes partial[chunk, c, k]; a fixed-order fold
 // over the chunks follows (launch_column_sums on the [chunks, n_out*576] matrix)
 __global__ __launch_bounds__(576) void head_dw_kernel(const float* __restrict__ dlogits, const float* __restrict__ x,
-                                                      float* __restrict__ partial, int n_pair, int n_out, int chunk) {
+                                                      float* __restrict__ partial, int n_pair, int n_out, int chunk, long ld) {
   const int c = blockIdx.x, k = threadIdx.x;
   const int p0 = blockIdx.y * chunk, p1 = p0 + chunk < n_pair ? p0 + chunk : n_pair;
   float acc = 0.f;
-  for (int p = p0; p < p1; ++p) acc += dlogits[(size_t)p * n_out + c] * x[(size_t)p * kTokens * kDim + k];
+  for (int p = p0; p < p1; ++p) acc += dlogits[(size_t)p * n_out + c] * x[(size_t)p * ld + k];
   partial[((size_t)blockIdx.y * n_out + c) * kDim + k] = acc;
 }
 
@@ -316,12 +316,12 @@ size_t head_backward_partial_floats(int n_out) {
 }
 
 hipError_t launch_head_backward(const float* dlogits, const float* w, const float* x, float* dx, float* dw, float* db, float* partial,
-                                int n_pair, int n_out, hipStream_t s) {
-  VETO_LAUNCH(head_dcls_kernel, dim3(n_pair), dim3(576), (size_t)n_out * 4, s, dlogits, w, dx, n_out);
+                                int n_pair, int n_out, long ld, hipStream_t s) {
+  VETO_LAUNCH(head_dcls_kernel, dim3(n_pair), dim3(576), (size_t)n_out * 4, s, dlogits, w, dx, n_out, ld);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   const int n_chunks = 64, chunk = (n_pair + n_chunks - 1) / n_chunks;
-  VETO_LAUNCH(head_dw_kernel, dim3(n_out, n_chunks), dim3(576), 0, s, dlogits, x, partial, n_pair, n_out, chunk);
+  VETO_LAUNCH(head_dw_kernel, dim3(n_out, n_chunks), dim3(576), 0, s, dlogits, x, partial, n_pair, n_out, chunk, ld);
   if ((e = hipGetLastError()) != hipSuccess) return e;
   float* scratch = partial + (size_t)n_chunks * n_out * kDim;
   if ((e = launch_column_sums(partial, (long)n_out * kDim, n_chunks, n_out * kDim, dw, scratch, 8, s)) != hipSuccess) return e;

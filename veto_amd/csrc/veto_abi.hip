@@ -745,7 +745,33 @@ int veto_forward_train(veto_handle_t h, void* stream, const veto_inputs_t* in, c
   for (int l = 0; l < L; ++l) {
     const LayerW& w = h->layers[l];
     TrainLayer& t = ws.layers[l];
-    float* xnext = l + 1 < L ? ws.layers[l + 1].xin : ws.xout;
+    if (l == L - 1) {
+      // Last layer: only x[:, 0] reaches the loss (model_veto.py:23), so -- as at inference -- keys / values cover the 19
+      // tokens, everything behind the attention runs on the CLS row of each pair.  The saved activations of this layer
+      // (ao, xmid, a2, pre, hid, ws.xout) are COMPACT: row p = pair p.  The backward mirrors this.
+      rc = run_gemm(h, s, "gemm_kv_last", t.a1, w.qkv, nullptr, nullptr, 0, t.qkv + kDim, nullptr, 3 * kDim, M, 2 * kDim, kDim, EPI_F32, 0,
+                    kDim);
+      if (rc) return rc;
+      rc = run_gemm(h, s, "gemm_q_cls", t.a1, w.qkv, nullptr, nullptr, 0, t.qkv, nullptr, (long)kTokens * 3 * kDim, n_pair, kDim, kDim,
+                    EPI_F32, (long)kTokens * 2 * kDim, 0);
+      if (rc) return rc;
+      {
+        AttnArgs a{};
+        a.qkv = t.qkv; a.n_pair = n_pair; a.heads = H; a.cls_only = 1; a.o = t.ao;
+        HIP_TRY(launch_attention(a, s));
+      }
+      rc = run_gemm(h, s, "gemm_out_cls", t.ao, w.out, w.out_b, t.xin, (long)kTokens * kDim, t.xmid, nullptr, kDim, n_pair, kDim, kDim,
+                    EPI_RESID, 0, 0, drop_site(opts, 3 + l));
+      if (rc) return rc;
+      HIP_TRY(launch_layernorm(t.xmid, kDim, w.ln2_w, w.ln2_b, t.a2, n_pair, s));
+      rc = run_gemm(h, s, "gemm_fc1_cls", t.a2, w.fc1, w.fc1_b, nullptr, 0, t.pre, nullptr, 2 * kDim, n_pair, 2 * kDim, kDim, EPI_F32);
+      if (rc) return rc;
+      HIP_TRY(launch_gelu_split(t.pre, t.hid, (size_t)n_pair, 2 * kDim, s));
+      rc = run_gemm(h, s, "gemm_fc2_cls", t.hid, w.fc2, w.fc2_b, t.xmid, kDim, ws.xout, nullptr, kDim, n_pair, kDim, 2 * kDim, EPI_RESID);
+      if (rc) return rc;
+      break;
+    }
+    float* xnext = ws.layers[l + 1].xin;
     rc = run_gemm(h, s, "gemm_qkv", t.a1, w.qkv, nullptr, nullptr, 0, t.qkv, nullptr, 3 * kDim, M, 3 * kDim, kDim, EPI_F32);
     if (rc) return rc;
     {
@@ -762,9 +788,9 @@ int veto_forward_train(veto_handle_t h, void* stream, const veto_inputs_t* in, c
     HIP_TRY(launch_gelu_split(t.pre, t.hid, (size_t)M, 2 * kDim, s));
     rc = run_gemm(h, s, "gemm_fc2", t.hid, w.fc2, w.fc2_b, t.xmid, kDim, xnext, nullptr, kDim, M, kDim, 2 * kDim, EPI_RESID);
     if (rc) return rc;
-    if (l + 1 < L) HIP_TRY(launch_layernorm(xnext, kDim, h->layers[l + 1].ln1_w, h->layers[l + 1].ln1_b, ws.layers[l + 1].a1, M, s));
+    HIP_TRY(launch_layernorm(xnext, kDim, h->layers[l + 1].ln1_w, h->layers[l + 1].ln1_b, ws.layers[l + 1].a1, M, s));
   }
-  HIP_TRY(launch_head(ws.xout, h->head_wt, h->p("rel_out.bias"), out_logits, n_pair, n_out, s, (long)kTokens * kDim));
+  HIP_TRY(launch_head(ws.xout, h->head_wt, h->p("rel_out.bias"), out_logits, n_pair, n_out, s, (long)kDim));
   return VETO_OK;
 }
 
@@ -783,26 +809,27 @@ int veto_backward(veto_handle_t h, void* stream, const veto_inputs_t* in, const 
   HIP_TRY(hipMemsetAsync(grads, 0, veto_grad_floats(h) * 4, s));
   HIP_TRY(hipMemsetAsync(ws.zero, 0, 1024, s));
 
-  // ---- classifier head ----------------------------------------------------------------------------------------
-  HIP_TRY(hipMemsetAsync(ws.dx, 0, (size_t)M * kDim * 4, s));
+  // ---- classifier head: gradient of the compact CLS rows ------------------------------------------------------------
   HIP_TRY(launch_head_backward(dlogits, h->p("rel_out.weight"), ws.xout, ws.dx, G("rel_out.weight"), G("rel_out.bias"), ws.head_partial,
-                               n_pair, n_out, s));
+                               n_pair, n_out, (long)kDim, s));
 
   // ---- transformer layers, last to first -------------------------------------------------------------------------
   for (int l = L - 1; l >= 0; --l) {
     const LayerW& w = h->layers[l];
     TrainLayer& t = ws.layers[l];
+    const bool last = l == L - 1;
+    const int R = last ? n_pair : M;     // rows behind the attention: the CLS rows only in the last layer (compact buffers)
     // x_out = x_mid + gelu(LN2(x_mid) W1^T + b1) W2^T + b2
-    rc = run_linear_backward(h, s, ws, ws.dx, M, kDim, t.hid, 2 * kDim, h->p(lname(l, "1.fn.net.3.weight")),
+    rc = run_linear_backward(h, s, ws, ws.dx, R, kDim, t.hid, 2 * kDim, h->p(lname(l, "1.fn.net.3.weight")),
                              G(lname(l, "1.fn.net.3.weight")), G(lname(l, "1.fn.net.3.bias")), ws.dbig);
     if (rc) return rc;
     GradXform gelu;              // dpre = dh * gelu'(pre), folded into the operand preparation of the fc1 backward
     gelu.mode = XF_GELU;
     gelu.pre = t.pre;
-    rc = run_linear_backward(h, s, ws, ws.dbig, M, 2 * kDim, t.a2, kDim, h->p(lname(l, "1.fn.net.0.weight")),
+    rc = run_linear_backward(h, s, ws, ws.dbig, R, 2 * kDim, t.a2, kDim, h->p(lname(l, "1.fn.net.0.weight")),
                              G(lname(l, "1.fn.net.0.weight")), G(lname(l, "1.fn.net.0.bias")), ws.dtmp, gelu);
     if (rc) return rc;
-    HIP_TRY(launch_layernorm_backward(t.xmid, ws.dtmp, w.ln2_w, ws.dx, ws.dmid, ws.dgb, ws.ln_partial, M, s));
+    HIP_TRY(launch_layernorm_backward(t.xmid, ws.dtmp, w.ln2_w, ws.dx, ws.dmid, ws.dgb, ws.ln_partial, R, s));
     HIP_TRY(hipMemcpyAsync(G(lname(l, "1.norm.weight")), ws.dgb, kDim * 4, hipMemcpyDeviceToDevice, s));
     HIP_TRY(hipMemcpyAsync(G(lname(l, "1.norm.bias")), ws.dgb + kDim, kDim * 4, hipMemcpyDeviceToDevice, s));
     // x_mid = x_in + dropout(attention(LN1(x_in) Wqkv^T) Wo^T + bo): the projection sees the masked gradient
@@ -816,14 +843,23 @@ int veto_backward(veto_handle_t h, void* stream, const veto_inputs_t* in, const 
         drop.scale = d.scale;
       }
     }
-    rc = run_linear_backward(h, s, ws, ws.dmid, M, kDim, t.ao, kDim, h->p(lname(l, "0.fn.to_out.0.weight")),
+    rc = run_linear_backward(h, s, ws, ws.dmid, R, kDim, t.ao, kDim, h->p(lname(l, "0.fn.to_out.0.weight")),
                              G(lname(l, "0.fn.to_out.0.weight")), G(lname(l, "0.fn.to_out.0.bias")), ws.dtmp, drop);
     if (rc) return rc;
-    HIP_TRY(launch_attention_backward(t.qkv, ws.dtmp, nullptr, ws.dsplit, n_pair, H, s));
+    HIP_TRY(launch_attention_backward(t.qkv, ws.dtmp, nullptr, ws.dsplit, n_pair, H, last ? 1 : 0, s));
+    const float* dres = ws.dmid;
+    if (last) {
+      // the residual gradient d x_mid lives on the CLS rows only: spread the compact rows over a zeroed token matrix
+      HIP_TRY(hipMemsetAsync(ws.dx, 0, (size_t)M * kDim * 4, s));
+      HIP_TRY(hipMemcpy2DAsync(ws.dx, (size_t)kTokens * kDim * 4, ws.dmid, (size_t)kDim * 4, (size_t)kDim * 4, (size_t)n_pair,
+                               hipMemcpyDeviceToDevice, s));
+      dres = ws.dx;
+    }
     rc = run_linear_backward(h, s, ws, nullptr, M, 3 * kDim, t.a1, kDim, h->p(lname(l, "0.fn.to_qkv.weight")),
                              G(lname(l, "0.fn.to_qkv.weight")), nullptr, ws.dtmp);
     if (rc) return rc;
-    HIP_TRY(launch_layernorm_backward(t.xin, ws.dtmp, w.ln1_w, ws.dmid, ws.dx, ws.dgb, ws.ln_partial, M, s));
+    // (in the last layer dres == ws.dx is also the output: every element is read and written by the same thread)
+    HIP_TRY(launch_layernorm_backward(t.xin, ws.dtmp, w.ln1_w, dres, ws.dx, ws.dgb, ws.ln_partial, M, s));
     HIP_TRY(hipMemcpyAsync(G(lname(l, "0.norm.weight")), ws.dgb, kDim * 4, hipMemcpyDeviceToDevice, s));
     HIP_TRY(hipMemcpyAsync(G(lname(l, "0.norm.bias")), ws.dgb + kDim, kDim * 4, hipMemcpyDeviceToDevice, s));
   }
@@ -1314,7 +1350,7 @@ int veto_debug_wgrad(void* stream, const float* dy, const float* x, float* dw, i
 
 int veto_debug_attention_backward(void* stream, const float* qkv, const float* dout, float* dqkv, int32_t n_pair, int32_t heads) {
   if (!qkv || !dout || !dqkv || n_pair <= 0) return fail(VETO_ERR_INVALID, "bad argument");
-  hipError_t e = launch_attention_backward(qkv, dout, dqkv, nullptr, n_pair, heads, (hipStream_t)stream);
+  hipError_t e = launch_attention_backward(qkv, dout, dqkv, nullptr, n_pair, heads, 0, (hipStream_t)stream);
   if (e != hipSuccess) return fail(e == hipErrorInvalidValue ? VETO_ERR_INVALID : VETO_ERR_HIP, "attention backward: %s (heads must give a head width of 72, 96 or 144)", hipGetErrorString(e));
   return VETO_OK;
 }
