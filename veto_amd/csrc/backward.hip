@@ -95,8 +95,9 @@ __global__ __launch_bounds__(kAttnBwdThreads) void attention_backward_kernel(con
   if (item + 1 < last) fetch(item + 1);
   __syncthreads();
   // ---- A: partial S = q k^T and dP = dO v^T ---------------------------------------------------------------------------
-  for (int w = tid; w < 2 * NS * 25; w += kAttnBwdThreads) {
-    const int prod = w / (NS * 25), rem = w % (NS * 25), sl = rem / 25, tile = rem % 25;
+  const int nt = cls_only ? 5 : 25;        // cls_only: only query row 0 exists -> the five tiles of the first row group
+  for (int w = tid; w < 2 * NS * nt; w += kAttnBwdThreads) {
+    const int prod = w / (NS * nt), rem = w % (NS * nt), sl = rem / nt, tile = rem % nt;
     const int i0 = (tile / 5) * 4, j0 = (tile % 5) * 4;
     const float* A = (prod ? go : q) + i0 * LD + sl * SL;
     const float* B = (prod ? v : k) + j0 * LD + sl * SL;
@@ -122,7 +123,8 @@ __global__ __launch_bounds__(kAttnBwdThreads) void attention_backward_kernel(con
   const float scale = 1.0f / sqrtf((float)DH);
   {
     const int i = tid >> 4, j = tid & 15;
-    const bool v1 = i < kTokens, v2 = i < kTokens && j < 3;
+    const int nq = cls_only ? 1 : kTokens;   // query rows that exist; the others get P = dS = 0
+    const bool v1 = i < nq, v2 = i < nq && j < 3;
     float s1 = 0.f, d1 = 0.f, s2 = 0.f, d2 = 0.f;
     if (v1) {
 #pragma unroll
@@ -159,8 +161,10 @@ __global__ __launch_bounds__(kAttnBwdThreads) void attention_backward_kernel(con
     f32x4 acc[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // cls_only: dQ rows 1..18 are zero (written as such), dK / dV reduce over the one query row
+    const int jn = !cls_only ? kTokens : prod > 0 ? 1 : t0 > 0 ? 0 : kTokens;
 #pragma unroll 4
-    for (int j = 0; j < kTokens; ++j) {
+    for (int j = 0; j < jn; ++j) {
       const f32x4 cf = *(const f32x4*)(coef + j * TP);
       const f32x4 m = *(const f32x4*)(mat + j * LD);
 #pragma unroll
