@@ -289,7 +289,140 @@ __global__ __launch_bounds__(128) void attention_mfma_kernel(AttnArgs a) {
   }
 }
 
+
+// ---- last layer, folded form -----------------------------------------------------------------
+// Only the CLS query of the last layer is consumed, and for ONE query the key / value projections can be moved off the 19
+// tokens: with a_j = LN1(x_j) (the 576-vector of token j),
+//   score[h][j] = q0_h . k_{j,h} = (W_k,h^T q0_h) . a_j = u_h . a_j,      u = a_0 . Mcat,  M_h = W_q,h^T W_k,h   (576 x 576)
+//   out         = sum_h W_o,h (sum_j p[h][j] W_v,h a_j) = sum_h N_h abar_h,  abar_h = sum_j p[h][j] a_j,  N_h = W_o,h W_v,h
+// so the [19 n_pair, 1152] key / value GEMM becomes two GEMMs over the n_pair CLS rows (u: K = 576, N = 576 H; out: K = 576 H,
+// N = 576; M_h, N_h are products of weights, built once) around this kernel: per pair, scores of the H heads against the 19
+// tokens, softmax, and the H probability-weighted token means.  One workgroup per pair; wave w owns heads w, w + 4, ...;
+// lane l owns columns l + 64 i; the token vectors are staged once in LDS as fp32 (hi + lo of the split rows the GEMMs read).
+// sum over the 16 lanes of a DPP row (row_ror 8 / 4 / 2 / 1): VALU-speed, no LDS crossbar; all lanes must be active
+template <int CTRL>
+__device__ __forceinline__ float dpp_rot16(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float row16_sum(float v) {
+  v += dpp_rot16<0x128>(v);
+  v += dpp_rot16<0x124>(v);
+  v += dpp_rot16<0x122>(v);
+  v += dpp_rot16<0x121>(v);
+  return v;
+}
+
+constexpr int kFoldMaxHeads = 12;     // heads * 19 <= 256: one softmax element per thread
+
+__global__ __launch_bounds__(256) void cls_fold_attention_kernel(const __bf16* __restrict__ a_split, const float* __restrict__ u,
+                                                                 __bf16* __restrict__ abar, int n_pair, int heads, float scale) {
+  __shared__ __attribute__((aligned(16))) float a_s[kTokens * kDim];
+  __shared__ float s_row[kFoldMaxHeads][4][kTokens];
+  __shared__ float p_s[kFoldMaxHeads][kTokens + 1];
+  const int pair = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  if (pair >= n_pair) return;
+  const __bf16* src = a_split + (size_t)pair * kTokens * (2 * kDim);
+#pragma unroll 2
+  for (int e = tid; e < kTokens * (kDim / 8); e += 256) {
+    const int j = e / (kDim / 8), q = e % (kDim / 8);
+    const __bf16* r = src + (size_t)j * (2 * kDim) + split_index(8 * q);
+    const bf16x8 hi = *(const bf16x8*)r, lo = *(const bf16x8*)(r + 32);
+    f32x4 v0, v1;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { v0[k] = (float)hi[k] + (float)lo[k]; v1[k] = (float)hi[4 + k] + (float)lo[4 + k]; }
+    *(f32x4*)(a_s + j * kDim + 8 * q) = v0;
+    *(f32x4*)(a_s + j * kDim + 8 * q + 4) = v1;
+  }
+  __syncthreads();
+  const float* up = u + (size_t)pair * heads * kDim;
+  // scores: a wave takes its heads two at a time (h, h + 4) so that a token value read from LDS serves both; partial dot
+  // products over this lane's 9 columns, then all-reduced inside the 16-lane rows by DPP rotations
+  for (int h = w; h < heads; h += 8) {
+    const int h2 = h + 4 < heads ? h + 4 : h;      // no partner: head h twice, second copy not stored
+    float acc[kTokens], acc2[kTokens];
+#pragma unroll
+    for (int j = 0; j < kTokens; ++j) { acc[j] = 0.f; acc2[j] = 0.f; }
+#pragma unroll 1
+    for (int i = 0; i < kDim / 64; ++i) {
+      const int c = lane + 64 * i;
+      const float uv = up[h * kDim + c], uv2 = up[h2 * kDim + c];
+#pragma unroll
+      for (int j = 0; j < kTokens; ++j) {
+        const float av = a_s[j * kDim + c];
+        acc[j] += uv * av;
+        acc2[j] += uv2 * av;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < kTokens; ++j) {
+      const float v = row16_sum(acc[j]), v2 = row16_sum(acc2[j]);
+      if ((lane & 15) == 0) {
+        s_row[h][lane >> 4][j] = v;
+        if (h2 != h) s_row[h2][lane >> 4][j] = v2;
+      }
+    }
+  }
+  __syncthreads();
+  for (int e = tid; e < heads * kTokens; e += 256) {     // fold the four row partials (fixed order)
+    const int h = e / kTokens, j = e % kTokens;
+    p_s[h][j] = ((s_row[h][0][j] + s_row[h][1][j]) + (s_row[h][2][j] + s_row[h][3][j])) * scale;
+  }
+  __syncthreads();
+  float pmine = 0.f;
+  const int sh = tid / kTokens, sj = tid % kTokens;        // softmax over the 19 tokens of a head (model_veto.py:91)
+  if (tid < heads * kTokens) {                              // heads <= kFoldMaxHeads: one element per thread
+    float mx = -INFINITY;
+#pragma unroll 1
+    for (int t = 0; t < kTokens; ++t) mx = fmaxf(mx, p_s[sh][t]);
+    float sum = 0.f;
+#pragma unroll 1
+    for (int t = 0; t < kTokens; ++t) sum += expf(p_s[sh][t] - mx);
+    pmine = expf(p_s[sh][sj] - mx) / sum;
+  }
+  __syncthreads();
+  if (tid < heads * kTokens) p_s[sh][sj] = pmine;
+  __syncthreads();
+  __bf16* dst = abar + (size_t)pair * (2 * (size_t)heads * kDim);
+  for (int h = w; h < heads; h += 8) {      // abar_h = sum_j p[h][j] a_j, written as split rows (the A operand of the out GEMM)
+    const int h2 = h + 4 < heads ? h + 4 : h;
+    float pj[kTokens], pj2[kTokens];
+#pragma unroll
+    for (int j = 0; j < kTokens; ++j) { pj[j] = p_s[h][j]; pj2[j] = p_s[h2][j]; }
+#pragma unroll 1
+    for (int i = 0; i < kDim / 64; ++i) {
+      const int c = lane + 64 * i;
+      float o = 0.f, o2 = 0.f;
+#pragma unroll
+      for (int j = 0; j < kTokens; ++j) {
+        const float av = a_s[j * kDim + c];
+        o += pj[j] * av;
+        o2 += pj2[j] * av;
+      }
+      __bf16 hh, ll;
+      split_bf16(o, hh, ll);
+      __bf16* d = dst + split_index(h * kDim + c);
+      d[0] = hh;
+      d[32] = ll;
+      if (h2 != h) {
+        split_bf16(o2, hh, ll);
+        d = dst + split_index(h2 * kDim + c);
+        d[0] = hh;
+        d[32] = ll;
+      }
+    }
+  }
+}
+
 }  // namespace
+
+int cls_fold_max_heads() { return kFoldMaxHeads; }
+
+hipError_t launch_cls_fold_attention(const __bf16* a_split, const float* u, __bf16* abar, int n_pair, int heads, hipStream_t s) {
+  if (heads <= 0 || heads > kFoldMaxHeads || kDim % heads != 0 || n_pair <= 0) return hipErrorInvalidValue;
+  const float scale = 1.0f / sqrtf((float)(kDim / heads));
+  VETO_LAUNCH(cls_fold_attention_kernel, dim3(n_pair), dim3(256), 0, s, a_split, u, abar, n_pair, heads, scale);
+  return hipGetLastError();
+}
 
 hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
   if (kDim % a.heads != 0) return hipErrorInvalidValue;

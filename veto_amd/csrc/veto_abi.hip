@@ -70,6 +70,9 @@ struct veto_handle_s {
   bool dirty = true;
   std::vector<LayerW> layers;
   SplitW patch_w = nullptr;
+  // last layer, folded CLS attention (attention.hip): Mcat [heads*576, 2*576], Ncat [576, 2*heads*576], and their fp32 staging
+  SplitW fold_m = nullptr, fold_n = nullptr;
+  float* fold_tmp = nullptr;
   float* patch_bias = nullptr;
   float* loc_wt = nullptr;
   float* cls_wt = nullptr;
@@ -150,6 +153,20 @@ int finalize_weights(veto_handle_t h, hipStream_t s) {
   HIP_TRY(launch_transpose_pair_proj(h->p("location_projection.0.weight"), h->loc_wt, kPosDim, s));
   HIP_TRY(launch_transpose_pair_proj(h->p("class_projection.0.weight"), h->cls_wt, h->cfg.embed_dim, s));
   HIP_TRY(launch_transpose_head(h->p("rel_out.weight"), h->head_wt, h->cfg.num_out, s));
+  if (h->cfg.heads <= cls_fold_max_heads()) {
+    // last layer: M_h = W_q,h^T W_k,h and N_h = W_o,h W_v,h (products over the head width, fp32), as GEMM weight operands
+    const int H = h->cfg.heads, dh = kDim / H;
+    const float* qkv = h->p(lname(L - 1, "0.fn.to_qkv.weight"));      // [1728, 576]: q rows, k rows, v rows
+    const float* wo = h->p(lname(L - 1, "0.fn.to_out.0.weight"));     // [576, 576]
+    for (int hd = 0; hd < H; ++hd)   // Mcat row (hd, c), column c' = sum_d Wk[hd*dh + d, c] Wq[hd*dh + d, c']
+      HIP_TRY(launch_sgemm_tn(qkv + ((size_t)kDim + hd * dh) * kDim, kDim, qkv + (size_t)hd * dh * kDim, kDim,
+                              h->fold_tmp + (size_t)hd * kDim * kDim, kDim, dh, kDim, kDim, s));
+    HIP_TRY(launch_split_rows(h->fold_tmp, h->fold_m, (size_t)H * kDim, kDim, s));
+    for (int hd = 0; hd < H; ++hd)   // Ncat row r, column (hd, c) = sum_d Wo[r, hd*dh + d] Wv[hd*dh + d, c]
+      HIP_TRY(launch_sgemm_nn(wo + hd * dh, kDim, qkv + ((size_t)2 * kDim + hd * dh) * kDim, kDim, h->fold_tmp + (size_t)hd * kDim,
+                              (long)H * kDim, kDim, kDim, dh, s));
+    HIP_TRY(launch_split_rows(h->fold_tmp, h->fold_n, (size_t)kDim, H * kDim, s));
+  }
   h->dirty = false;
   return VETO_OK;
 }
@@ -186,7 +203,10 @@ Workspace carve(char* base, int n_obj, int n_pair, int chunk) {
   w.patch_tab = (float*)take((size_t)n_obj * 16 * 2 * kDim * 4);
   w.x = (float*)take(mpad * kDim * 4);
   w.a = (__bf16*)take(mpad * 2 * kDim * 2);
-  w.big = take(mpad * 3 * kDim * 4);
+  {   // qkv of a chunk; in the last layer instead u [cpad, H*576] fp32 + abar [cpad, 2*H*576] split (folded CLS attention)
+    const size_t qkv_bytes = mpad * 3 * kDim * 4, fold_bytes = 2 * (align_up(cpad * (size_t)cls_fold_max_heads() * kDim * 4, 256));
+    w.big = take(qkv_bytes > fold_bytes ? qkv_bytes : fold_bytes);
+  }
   w.xc = (float*)take(cpad * kDim * 4);
   w.ac = (__bf16*)take(cpad * 2 * kDim * 2);
   w.hc = (__bf16*)take(cpad * 4 * kDim * 2);
@@ -303,6 +323,8 @@ int veto_create(const veto_config_t* cfg, veto_handle_t* out) {
   const size_t o_loc = dtake((size_t)kPosDim * 2 * kDim * 4);
   const size_t o_cls = dtake((size_t)E * 2 * kDim * 4);
   const size_t o_head = dtake((size_t)kDim * cfg->num_out * 4);
+  const size_t fold_el = (size_t)cfg->heads * kDim * kDim;
+  const size_t o_fm = dtake(fold_el * 4), o_fn = dtake(fold_el * 4), o_ft = dtake(fold_el * 4);
   e = hipMalloc((void**)&h->derived, doff);
   if (e != hipSuccess) { hipFree(h->raw); delete h; return fail(VETO_ERR_HIP, "hipMalloc(derived weights): %s", hipGetErrorString(e)); }
   h->layers.resize(L);
@@ -324,6 +346,9 @@ int veto_create(const veto_config_t* cfg, veto_handle_t* out) {
   h->loc_wt = (float*)(h->derived + o_loc);
   h->cls_wt = (float*)(h->derived + o_cls);
   h->head_wt = (float*)(h->derived + o_head);
+  h->fold_m = (__bf16*)(h->derived + o_fm);
+  h->fold_n = (__bf16*)(h->derived + o_fn);
+  h->fold_tmp = (float*)(h->derived + o_ft);
   *out = h;
   return VETO_OK;
 }
@@ -445,7 +470,24 @@ int veto_forward(veto_handle_t h, void* stream, const veto_inputs_t* in, void* w
       const LayerW& w = h->layers[l];
       const bool last = (l == L - 1);
       int rc;
-      if (!last) {
+      static const bool fold_off = getenv("VETO_CLS_FOLD") && !strcmp(getenv("VETO_CLS_FOLD"), "0");   // A/B knob
+      const bool fold = last && !fold_off && H <= cls_fold_max_heads();
+      if (fold) {
+        // last layer, folded (attention.hip): u = a_0 . Mcat on the CLS rows, per-pair scores / softmax / weighted token means,
+        // then out = abar . Ncat^T + b_o + x_0 -- no key / value projection of the 19 tokens
+        float* u = (float*)ws.big;
+        __bf16* abar = (__bf16*)(ws.big + align_up((size_t)gemm_rows_padded(np) * H * kDim * 4, 256));
+        rc = run_gemm(h, s, "gemm_u_cls", ws.a, h->fold_m, nullptr, nullptr, 0, u, nullptr, (long)H * kDim, np, H * kDim, kDim, EPI_F32,
+                      (long)kTokens * 2 * kDim, 0);
+        if (rc) return rc;
+        {
+          ProfScope ps(h, s, "attention_cls", 4.0 * np * H * kTokens * kDim, (double)M * kDim * 4 + (double)np * H * kDim * 8);
+          HIP_TRY(launch_cls_fold_attention(ws.a, u, abar, np, H, s));
+        }
+        rc = run_gemm(h, s, "gemm_out_cls", abar, h->fold_n, w.out_b, ws.x, (long)kTokens * kDim, ws.xc, nullptr, kDim, np, kDim,
+                      H * kDim, EPI_RESID);
+        if (rc) return rc;
+      } else if (!last) {
         rc = run_gemm(h, s, "gemm_qkv", ws.a, w.qkv, nullptr, nullptr, 0, qkv, nullptr, 3 * kDim, M, 3 * kDim, kDim, EPI_F32);
         if (rc) return rc;
       } else {
@@ -457,7 +499,7 @@ int veto_forward(veto_handle_t h, void* stream, const veto_inputs_t* in, void* w
                       kDim, EPI_F32, (long)kTokens * 2 * kDim, 0);
         if (rc) return rc;
       }
-      {
+      if (!fold) {
         AttnArgs a{};
         a.qkv = qkv; a.n_pair = np; a.heads = H; a.cls_only = last ? 1 : 0;
         a.o = last ? ws.ac : ws.a;
@@ -486,9 +528,11 @@ int veto_forward(veto_handle_t h, void* stream, const veto_inputs_t* in, void* w
       } else {
         // Only x[:, 0] of the last layer is consumed (model_veto.py:23): out-proj, FeedForward and
         // both residuals run on the CLS row of each pair (row p*19 of x -> compact row p).
-        rc = run_gemm(h, s, "gemm_out_cls", ws.ac, w.out, w.out_b, ws.x, (long)kTokens * kDim, ws.xc, nullptr, kDim, np,
-                      kDim, kDim, EPI_RESID);
-        if (rc) return rc;
+        if (!fold) {
+          rc = run_gemm(h, s, "gemm_out_cls", ws.ac, w.out, w.out_b, ws.x, (long)kTokens * kDim, ws.xc, nullptr, kDim, np,
+                        kDim, kDim, EPI_RESID);
+          if (rc) return rc;
+        }
         {
           ProfScope ps(h, s, "layernorm_cls", 0, (double)np * kDim * 8);
           HIP_TRY(launch_layernorm(ws.xc, kDim, w.ln2_w, w.ln2_b, ws.ac, np, s));
