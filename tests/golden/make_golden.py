@@ -330,24 +330,25 @@ def run_postprocessor_vote(cfg, BoxList, name, n, dataset, voting):
     print("%-24s expert voting %s: %d of %d rows kept" % (name, voting, out["rel_pair_idxs"].shape[0], len(sizes) * P_))
 
 
-def run_train_losses(P, cfg, BoxList, name, meet, beta_loss=False, dataset="VG", mode="predcls", experts=False):
+def run_train_losses(P, cfg, BoxList, name, meet, beta_loss=False, dataset="VG", mode="predcls", experts=False, layers=2, n_heads=8,
+                     num_objs=(7, 5, 9)):
     """Training-mode forward of the reference predictor (dropout off, so it is deterministic) on a small batch with
     random relation labels: stores the classifier logits it produced (forward hooks on the rel_out modules), the
     labels, and the losses it returned.  MEET: also the expert sampling (`cur_chosen_matrix`), which the reference
     draws from Python's `random` (seeded with 1, tools/relation_train_net.py:44-50), and its sample_rate_matrix."""
     import random
-    n_obj, n_rel = configure(P, cfg, mode, 2, 8, "VETOPredictor_MEET" if meet else "VETOPredictor", dataset)
+    n_obj, n_rel = configure(P, cfg, mode, layers, n_heads, "VETOPredictor_MEET" if meet else "VETOPredictor", dataset)
     cfg.ENSEMBLE_LEARNING.EXPERT_GROUP = bool(experts)
     cfg.GLOBAL_SETTING.BETA_LOSS = False
     torch.manual_seed(0)
-    num_objs = [7, 5, 9]
+    num_objs = list(num_objs)
     if meet:
         model = P.VETOPredictor_MEET(cfg, 512)
         groups = list(model.max_group_element_number_list)
-        sd = synth.meet_state_dict(0, groups, layers=2, num_obj_cls=n_obj, experts=3 if experts else 0)
+        sd = synth.meet_state_dict(0, groups, layers=layers, num_obj_cls=n_obj, experts=3 if experts else 0)
     else:
         model = P.VETOPredictor(cfg, 512)
-        sd = synth.predictor_state_dict(0, layers=2, num_obj_cls=n_obj, num_rel_cls=n_rel)
+        sd = synth.predictor_state_dict(0, layers=layers, num_obj_cls=n_obj, num_rel_cls=n_rel)
     load_sd(model, sd)
     model.train()
     for m in model.modules():
@@ -378,7 +379,7 @@ def run_train_losses(P, cfg, BoxList, name, meet, beta_loss=False, dataset="VG",
     for h in hooks:
         h.remove()
     out = {"labels": labels, "meet": int(meet), "dataset": dataset, "beta_loss": int(beta_loss), "num_objs": np.array(num_objs),
-           "mode": mode, "experts": int(bool(experts))}
+           "mode": mode, "experts": int(bool(experts)), "layers": layers, "heads": n_heads}
     # gradients of the summed losses w.r.t. every parameter (the reference's training loop sums the loss dict,
     # engine/trainer + tools/relation_train_net.py:297): stored as norm + a strided sample (full tensor when small)
     sum(res[2].values()).backward()
@@ -499,6 +500,8 @@ def main():
         run_train_losses(P, cfg, BoxList, "train_vanilla_sgcls", meet=False, mode="sgcls")
         run_train_losses(P, cfg, BoxList, "train_meet_sgcls", meet=True, mode="sgcls")
         run_train_losses(P, cfg, BoxList, "train_meet_experts", meet=True, experts=True)
+        run_train_losses(P, cfg, BoxList, "train_vanilla_l1h6_ragged", meet=False, layers=1, n_heads=6, num_objs=(2, 6, 3))
+        run_train_losses(P, cfg, BoxList, "train_meet_l3h4", meet=True, layers=3, n_heads=4, num_objs=(4, 5))
         return
     if os.environ.get("GOLDEN_ONLY") == "sggeval":   # regenerate only the evaluator fixtures
         for name in SGG_EVAL_CASES:
@@ -518,6 +521,8 @@ def main():
     run_train_losses(P, cfg, BoxList, "train_vanilla_sgcls", meet=False, mode="sgcls")
     run_train_losses(P, cfg, BoxList, "train_meet_sgcls", meet=True, mode="sgcls")
     run_train_losses(P, cfg, BoxList, "train_meet_experts", meet=True, experts=True)
+    run_train_losses(P, cfg, BoxList, "train_vanilla_l1h6_ragged", meet=False, layers=1, n_heads=6, num_objs=(2, 6, 3))
+    run_train_losses(P, cfg, BoxList, "train_meet_l3h4", meet=True, layers=3, n_heads=4, num_objs=(4, 5))
     for name in SGG_EVAL_CASES:
         run_sgg_eval(cfg, BoxList, name)
     run_postprocessor_vote(cfg, BoxList, "postvote_vg_c_n10", 10, "VG", "C")

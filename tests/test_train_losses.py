@@ -12,8 +12,9 @@ from conftest import GOLDEN_DIR
 from oracle import train_oracle as to
 from veto_amd import meet_tables
 
-CASES_VANILLA = ["train_vanilla", "train_vanilla_beta", "train_vanilla_sgcls"]
-CASES_MEET = ["train_meet_vg", "train_meet_gqa", "train_meet_sgcls"]
+# *_l1h6_ragged: one layer (first == last), 96-wide heads, images of 2 / 6 / 3 objects; *_l3h4: three layers, 144-wide heads
+CASES_VANILLA = ["train_vanilla", "train_vanilla_beta", "train_vanilla_sgcls", "train_vanilla_l1h6_ragged"]
+CASES_MEET = ["train_meet_vg", "train_meet_gqa", "train_meet_sgcls", "train_meet_l3h4"]
 CASES_EXPERTS = ["train_meet_experts"]     # EXPERT_GROUP: 3 experts per group, 15 heads
 
 
@@ -109,7 +110,8 @@ def _train_setup(name, meet, dev, forward_only=True):
     dataset = str(g["dataset"])
     n_obj_cls = 151 if dataset == "VG" else 201
     num_objs = [int(x) for x in g["num_objs"]]
-    cfg = testing.make_config(2, 8, str(g["mode"]), meet, dataset)
+    layers, heads = int(g.get("layers", 2)), int(g.get("heads", 8))
+    cfg = testing.make_config(layers, heads, str(g["mode"]), meet, dataset)
     cfg.VETO_AMD.TRAIN_FORWARD_ONLY = forward_only
     if int(g["beta_loss"]):
         cfg.GLOBAL_SETTING.BETA_LOSS = True
@@ -117,9 +119,9 @@ def _train_setup(name, meet, dev, forward_only=True):
     experts = bool(int(g.get("experts", 0)))
     cfg.ENSEMBLE_LEARNING.EXPERT_GROUP = experts
     if meet:
-        sd = synth.meet_state_dict(0, [int(x) for x in g["group_sizes"]], layers=2, num_obj_cls=n_obj_cls, experts=3 if experts else 0)
+        sd = synth.meet_state_dict(0, [int(x) for x in g["group_sizes"]], layers=layers, num_obj_cls=n_obj_cls, experts=3 if experts else 0)
     else:
-        sd = synth.predictor_state_dict(0, layers=2, num_obj_cls=n_obj_cls, num_rel_cls=51 if dataset == "VG" else 101)
+        sd = synth.predictor_state_dict(0, layers=layers, num_obj_cls=n_obj_cls, num_rel_cls=51 if dataset == "VG" else 101)
     if int(g["beta_loss"]):
         sd.pop("criterion_loss_rel.weight")       # the synthetic checkpoint stores all-ones class weights
     model = testing.make_predictor(cfg, sd, dev)
