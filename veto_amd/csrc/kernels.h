@@ -98,6 +98,7 @@ struct AssembleArgs {
   const int32_t* subj; const int32_t* obj;  // this chunk's pairs
   float* x;                 // [n_pair*19, 576]
   __bf16* a;                // LN(x), split rows [n_pair*19, 2*576]
+  float* stats;             // optional [n_pair*19, 2]: (mean, rstd) of every row; then `a` is written for tokens 17 / 18 only
   int n_pair;
   // training only: pos_drop (EMB_DROPOUT) on the assembled tokens; element (row, col) -> index row*576 + col
   unsigned long long drop_seed;
@@ -105,6 +106,12 @@ struct AssembleArgs {
   float drop_scale;
 };
 hipError_t launch_assemble(const AssembleArgs& a, hipStream_t s);
+// layer 0 in the per-object form (rowops.hip): qkv rows of tokens 0..16 from the per-object tables sw / ow [n_obj*16, 1728],
+// the row statistics and the weight-only vectors vec = [c1 | c2 | pw | qkv_cls]; and the kernel that builds vec and Wqkv diag(gamma)
+hipError_t launch_qkv0_combine(const float* sw, const float* ow, const float* stats, const float* vec, const int32_t* subj,
+                               const int32_t* obj, float* qkv, int n_pair, hipStream_t s);
+hipError_t launch_qkv0_consts(const float* wq, const float* gamma, const float* beta, const float* pos, const float* cls, float* wp,
+                              float* vec, hipStream_t s);
 // y = dropout mask of site `seed` applied to x ([rows, n_cols], index row*n_cols + col), scaled by `scale`; in place allowed
 hipError_t launch_dropout_apply(const float* x, float* y, size_t rows, int n_cols, unsigned long long seed, unsigned thresh,
                                 float scale, hipStream_t s);

@@ -284,20 +284,24 @@ __device__ __forceinline__ float group16_sum(float v) {
 }
 
 // LayerNorm (eps 1e-5, model_veto.py:125-132) of the row in registers -> split-row operand
-__device__ __forceinline__ void rowq_layernorm_store(const RowQ& r, int q, const float* __restrict__ w,
-                                                     const float* __restrict__ b, __bf16* __restrict__ dst) {
+__device__ __forceinline__ void rowq_stats(const RowQ& r, float& mean, float& rstd) {
   float s = 0.f;
 #pragma unroll
   for (int j = 0; j < 9; ++j) s += (r.v[j][0] + r.v[j][1]) + (r.v[j][2] + r.v[j][3]);
-  const float mean = group16_sum(s) * (1.f / kDim);
+  mean = group16_sum(s) * (1.f / kDim);
   float sq = 0.f;
 #pragma unroll
   for (int j = 0; j < 9; ++j)
 #pragma unroll
     for (int e = 0; e < 4; ++e) { const float d = r.v[j][e] - mean; sq += d * d; }
-  const float rstd = 1.f / sqrtf(group16_sum(sq) * (1.f / kDim) + 1e-5f);
+  rstd = 1.f / sqrtf(group16_sum(sq) * (1.f / kDim) + 1e-5f);
+}
+
+__device__ __forceinline__ void rowq_normalized_store(const RowQ& r, int q, float mean, float rstd, const float* __restrict__ w,
+                                                      const float* __restrict__ b, __bf16* __restrict__ dst) {
 #pragma unroll
   for (int j = 0; j < 9; ++j) {
+
     const int c = 4 * (q + 16 * j);
     const f32x4 wv = *(const f32x4*)(w + c), bv = *(const f32x4*)(b + c);
     bf16x4 hi, lo;
@@ -312,6 +316,14 @@ __device__ __forceinline__ void rowq_layernorm_store(const RowQ& r, int q, const
     *(bf16x4*)d = hi;
     *(bf16x4*)(d + 32) = lo;
   }
+}
+
+
+__device__ __forceinline__ void rowq_layernorm_store(const RowQ& r, int q, const float* __restrict__ w,
+                                                     const float* __restrict__ b, __bf16* __restrict__ dst) {
+  float mean, rstd;
+  rowq_stats(r, mean, rstd);
+  rowq_normalized_store(r, q, mean, rstd, w, b, dst);
 }
 
 // Token assembly (model_veto.py:56-63 with the per-object partial products of section 4 of DESIGN.md):
@@ -356,7 +368,95 @@ __global__ __launch_bounds__(256) void assemble_kernel(AssembleArgs a) {
     r.v[j] = v;
     *(f32x4*)(xr + c) = v;
   }
+  if (a.stats) {
+    // layer 0 in the per-object form (qkv0_combine_kernel): the patch-token rows and the CLS row only need their LayerNorm
+    // statistics; the two ReLU'd rows (location, class) are not linear in the per-object tables and keep the split-row path
+    float mean, rstd;
+    rowq_stats(r, mean, rstd);
+    if (q == 0) *(float2*)(a.stats + (size_t)row * 2) = float2{mean, rstd};
+    if (t > kPatchTokens) rowq_normalized_store(r, q, mean, rstd, a.ln_w, a.ln_b, a.a + (size_t)row * (2 * kDim));
+    return;
+  }
   rowq_layernorm_store(r, q, a.ln_w, a.ln_b, a.a + (size_t)row * (2 * kDim));
+}
+
+// ---- layer 0, per-object form of LayerNorm + QKV ---------------------------------------------
+// x = S[s, t] + O[o, t] + pos for the 16 patch tokens, so with W' = Wqkv diag(gamma):
+//   LN(x) Wqkv^T = rstd (x W'^T - mean c1) + c2 = rstd (SW[s, t] + OW[o, t] + pw - mean c1) + c2
+// SW = S W'^T, OW = O W'^T are per-OBJECT tables ([n_obj*16, 1728], two small GEMMs), c1 = W' 1, c2 = Wqkv beta, pw = W' pos and the
+// constant CLS row are weight-only vectors (vec = [c1 | c2 | pw | qkv_cls]).  One wave per (pair, token 0..16) row; the rows of
+// tokens 17 / 18 are written by two GEMMs over their LayerNorm'ed split rows.
+__global__ __launch_bounds__(256) void qkv0_combine_kernel(const float* __restrict__ sw, const float* __restrict__ ow,
+                                                           const float* __restrict__ stats, const float* __restrict__ vec,
+                                                           const int32_t* __restrict__ subj, const int32_t* __restrict__ obj,
+                                                           float* __restrict__ qkv, int n_pair) {
+  constexpr int N = 3 * kDim, N4 = N / 4;
+  __shared__ __attribute__((aligned(16))) float s_vec[3 * N];
+  for (int i = threadIdx.x; i < 3 * N4; i += 256) ((f32x4*)s_vec)[i] = ((const f32x4*)vec)[i];
+  __syncthreads();
+  const f32x4* c1 = (const f32x4*)s_vec;
+  const f32x4* c2 = c1 + N4;
+  const f32x4* pw = c2 + N4;
+  const int lane = threadIdx.x & 63;
+  // Workgroups are dealt round-robin to the 8 XCDs: XCD x walks the x-th contiguous eighth of the rows (one or two images), its
+  // workgroups side by side, so that the per-object rows of those images (8 MB per 36-object image) are fetched into ONE L2
+  const long rows = (long)n_pair * (kPatchTokens + 1), per_xcd = (rows + 7) / 8;
+  const long r_begin = (blockIdx.x & 7) * per_xcd, r_end = r_begin + per_xcd < rows ? r_begin + per_xcd : rows;
+  const long stride = (long)(gridDim.x >> 3) * 4;
+  for (long r = r_begin + (long)(blockIdx.x >> 3) * 4 + (threadIdx.x >> 6); r < r_end; r += stride) {
+    const int p = (int)(r / (kPatchTokens + 1)), t = (int)(r % (kPatchTokens + 1));
+    f32x4* dst = (f32x4*)(qkv + ((size_t)p * kTokens + t) * N);
+    if (t == 0) {
+      const f32x4* src = (const f32x4*)(vec + 3 * N);
+      for (int i = lane; i < N4; i += 64) dst[i] = src[i];
+      continue;
+    }
+    const float2 st = *(const float2*)(stats + ((size_t)p * kTokens + t) * 2);
+    const float mean = st.x, rstd = st.y;
+    const f32x4* a = (const f32x4*)(sw + ((size_t)subj[p] * kPatchTokens + t - 1) * N);
+    const f32x4* b = (const f32x4*)(ow + ((size_t)obj[p] * kPatchTokens + t - 1) * N);
+#pragma unroll
+    for (int k = 0; k < (N4 + 63) / 64; ++k) {
+      const int i = lane + 64 * k;
+      if (i < N4) dst[i] = rstd * ((a[i] + b[i]) + (pw[i] - mean * c1[i])) + c2[i];
+    }
+  }
+}
+
+// weight-only vectors of the per-object layer-0 form: vec = [c1 | c2 | pw | qkv_cls], each [1728]; wq = Wqkv [1728, 576], wp = Wqkv diag(gamma)
+__global__ __launch_bounds__(64) void qkv0_consts_kernel(const float* __restrict__ wq, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, const float* __restrict__ pos,
+                                                         const float* __restrict__ cls, float* __restrict__ wp, float* __restrict__ vec) {
+  const int n = blockIdx.x, lane = threadIdx.x, N = 3 * kDim;
+  // LayerNorm statistics of the constant CLS row x = cls_token + pos_embedding (every block recomputes them: 576 values)
+  double s = 0.0, sq = 0.0;
+  for (int k = lane; k < kDim; k += 64) s += (double)(cls[k] + pos[k]);
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  const double mean = s / kDim;
+  for (int k = lane; k < kDim; k += 64) { const double d = (double)(cls[k] + pos[k]) - mean; sq += d * d; }
+  for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
+  const double rstd = 1.0 / sqrt(sq / kDim + 1e-5);
+  double c1 = 0.0, c2 = 0.0, pw = 0.0, qc = 0.0;
+  for (int k = lane; k < kDim; k += 64) {
+    const float w = wq[(size_t)n * kDim + k], g = w * gamma[k];
+    wp[(size_t)n * kDim + k] = g;
+    c1 += (double)g;
+    c2 += (double)w * (double)beta[k];
+    pw += (double)g * (double)pos[k];
+    qc += (double)g * ((double)(cls[k] + pos[k]) - mean);
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    c1 += __shfl_xor(c1, o, 64);
+    c2 += __shfl_xor(c2, o, 64);
+    pw += __shfl_xor(pw, o, 64);
+    qc += __shfl_xor(qc, o, 64);
+  }
+  if (lane == 0) {
+    vec[n] = (float)c1;
+    vec[N + n] = (float)c2;
+    vec[2 * N + n] = (float)pw;
+    vec[3 * N + n] = (float)(rstd * qc + c2);
+  }
 }
 
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, long ldx,
@@ -478,6 +578,20 @@ hipError_t launch_enumerate_pairs(int n, int64_t* out, hipStream_t s) {
 
 hipError_t launch_assemble(const AssembleArgs& a, hipStream_t s) {
   VETO_LAUNCH(assemble_kernel, dim3((unsigned)(((long)a.n_pair * kTokens + 15) / 16)), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_qkv0_combine(const float* sw, const float* ow, const float* stats, const float* vec, const int32_t* subj,
+                               const int32_t* obj, float* qkv, int n_pair, hipStream_t s) {
+  const long rows = (long)n_pair * (kPatchTokens + 1);
+  const unsigned blocks = (unsigned)(rows / 4 + 8 < 4096 ? (rows / 4 + 8) / 8 * 8 : 4096);   // a multiple of 8 (XCDs)
+  VETO_LAUNCH(qkv0_combine_kernel, dim3(blocks), dim3(256), 0, s, sw, ow, stats, vec, subj, obj, qkv, n_pair);
+  return hipGetLastError();
+}
+
+hipError_t launch_qkv0_consts(const float* wq, const float* gamma, const float* beta, const float* pos, const float* cls, float* wp,
+                              float* vec, hipStream_t s) {
+  VETO_LAUNCH(qkv0_consts_kernel, dim3(3 * kDim), dim3(64), 0, s, wq, gamma, beta, pos, cls, wp, vec);
   return hipGetLastError();
 }
 

@@ -73,6 +73,9 @@ struct veto_handle_s {
   // last layer, folded CLS attention (attention.hip): Mcat [heads*576, 2*576], Ncat [576, 2*heads*576], and their fp32 staging
   SplitW fold_m = nullptr, fold_n = nullptr;
   float* fold_tmp = nullptr;
+  // layer 0, per-object form of LayerNorm + QKV (rowops.hip): Wqkv diag(gamma) as a GEMM operand, vec = [c1 | c2 | pw | qkv_cls]
+  SplitW q0_w = nullptr;
+  float* q0_vec = nullptr;
   float* patch_bias = nullptr;
   float* loc_wt = nullptr;
   float* cls_wt = nullptr;
@@ -153,6 +156,12 @@ int finalize_weights(veto_handle_t h, hipStream_t s) {
   HIP_TRY(launch_transpose_pair_proj(h->p("location_projection.0.weight"), h->loc_wt, kPosDim, s));
   HIP_TRY(launch_transpose_pair_proj(h->p("class_projection.0.weight"), h->cls_wt, h->cfg.embed_dim, s));
   HIP_TRY(launch_transpose_head(h->p("rel_out.weight"), h->head_wt, h->cfg.num_out, s));
+  {   // layer 0: Wqkv diag(gamma) and the weight-only vectors of the per-object form (fold_tmp holds >= 1728 x 576 floats)
+    const std::string T0 = kT;
+    HIP_TRY(launch_qkv0_consts(h->p(lname(0, "0.fn.to_qkv.weight")), h->layers[0].ln1_w, h->layers[0].ln1_b, h->p(T0 + "pos_embedding"),
+                               h->p(T0 + "cls_token"), h->fold_tmp, h->q0_vec, s));
+    HIP_TRY(launch_split_rows(h->fold_tmp, h->q0_w, 3 * kDim, kDim, s));
+  }
   if (h->cfg.heads <= cls_fold_max_heads()) {
     // last layer: M_h = W_q,h^T W_k,h and N_h = W_o,h W_v,h (products over the head width, fp32), as GEMM weight operands
     const int H = h->cfg.heads, dh = kDim / H;
@@ -180,6 +189,9 @@ struct Workspace {
   __bf16* a;        // LN(x) / attention output, split [mpad, 2*576]
   char* big;        // qkv fp32 [mpad,1728]; later the MLP hidden, split [mpad, 2*1152]
   float* xc;
+  __bf16* ptab_split;   // layer 0, per-object form: patch_tab as split rows [prow, 2*1152]
+  float *sw, *ow;       // ... its products with Wqkv diag(gamma), fp32 [prow, 1728] each
+  float* stats;         // ... (mean, rstd) of the layer-0 token rows [mpad, 2]
   __bf16 *ac, *hc;  // CLS-compact operands, split [cpad, 2*576] / [cpad, 2*1152]
   size_t total;
 };
@@ -208,6 +220,10 @@ Workspace carve(char* base, int n_obj, int n_pair, int chunk) {
     w.big = take(qkv_bytes > fold_bytes ? qkv_bytes : fold_bytes);
   }
   w.xc = (float*)take(cpad * kDim * 4);
+  w.ptab_split = (__bf16*)take(prow * 2 * 2 * kDim * 2);
+  w.sw = (float*)take(prow * 3 * kDim * 4);
+  w.ow = (float*)take(prow * 3 * kDim * 4);
+  w.stats = (float*)take(mpad * 2 * 4);
   w.ac = (__bf16*)take(cpad * 2 * kDim * 2);
   w.hc = (__bf16*)take(cpad * 4 * kDim * 2);
   w.total = off;
@@ -325,6 +341,7 @@ int veto_create(const veto_config_t* cfg, veto_handle_t* out) {
   const size_t o_head = dtake((size_t)kDim * cfg->num_out * 4);
   const size_t fold_el = (size_t)cfg->heads * kDim * kDim;
   const size_t o_fm = dtake(fold_el * 4), o_fn = dtake(fold_el * 4), o_ft = dtake(fold_el * 4);
+  const size_t o_q0w = dtake((size_t)3 * kDim * kDim * 4), o_q0v = dtake((size_t)4 * 3 * kDim * 4);
   e = hipMalloc((void**)&h->derived, doff);
   if (e != hipSuccess) { hipFree(h->raw); delete h; return fail(VETO_ERR_HIP, "hipMalloc(derived weights): %s", hipGetErrorString(e)); }
   h->layers.resize(L);
@@ -349,6 +366,8 @@ int veto_create(const veto_config_t* cfg, veto_handle_t* out) {
   h->fold_m = (__bf16*)(h->derived + o_fm);
   h->fold_n = (__bf16*)(h->derived + o_fn);
   h->fold_tmp = (float*)(h->derived + o_ft);
+  h->q0_w = (__bf16*)(h->derived + o_q0w);
+  h->q0_vec = (float*)(h->derived + o_q0v);
   *out = h;
   return VETO_OK;
 }
@@ -448,6 +467,21 @@ int veto_forward(veto_handle_t h, void* stream, const veto_inputs_t* in, void* w
                       n_obj * 16, 2 * kDim, 2048, EPI_F32);
     if (rc) return rc;
   }
+  // Layer 0 in the per-object form: LayerNorm + QKV of the 16 patch tokens of every pair come from two
+  // per-object tables SW = S W'^T, OW = O W'^T (S | O = the halves of patch_tab, W' = Wqkv diag(gamma)) -- a GEMM over the
+  // n_obj*16 object rows instead of the n_pair*19 token rows.  Needs a layer behind it that reads LN1 rows as usual (L >= 2).
+  static const bool tables_off = getenv("VETO_QKV0_TABLES") && !strcmp(getenv("VETO_QKV0_TABLES"), "0");   // A/B knob
+  const bool qkv0_tables = L >= 2 && !tables_off;
+  if (qkv0_tables) {
+    const int R = n_obj * 16;
+    HIP_TRY(launch_split_rows(ws.patch_tab, ws.ptab_split, (size_t)R, 2 * kDim, s));
+    int rc = run_gemm(h, s, "gemm_qkv0_tab", ws.ptab_split, h->q0_w, nullptr, nullptr, 0, ws.sw, nullptr, 3 * kDim, R, 3 * kDim, kDim,
+                      EPI_F32, (long)2 * 2 * kDim, 0);
+    if (rc) return rc;
+    rc = run_gemm(h, s, "gemm_qkv0_tab", ws.ptab_split + 2 * kDim, h->q0_w, nullptr, nullptr, 0, ws.ow, nullptr, 3 * kDim, R, 3 * kDim, kDim,
+                  EPI_F32, (long)2 * 2 * kDim, 0);
+    if (rc) return rc;
+  }
 
   // ---- pairs, in chunks that bound the workspace ----------------------------------------------
   for (int c0 = 0; c0 < n_pair; c0 += chunk) {
@@ -461,7 +495,8 @@ int veto_forward(veto_handle_t h, void* stream, const veto_inputs_t* in, void* w
       a.pos_embedding = h->p(T + "pos_embedding");
       a.ln_w = h->layers[0].ln1_w; a.ln_b = h->layers[0].ln1_b;
       a.subj = ws.subj + c0; a.obj = ws.obj + c0; a.x = ws.x; a.a = ws.a; a.n_pair = np;
-      ProfScope ps(h, s, "assemble_tokens", 0, (double)M * kDim * (4 + 4) + (double)np * 18 * 2 * kDim * 4);
+      a.stats = qkv0_tables ? ws.stats : nullptr;
+      ProfScope ps(h, s, "assemble_tokens", 0, (double)M * kDim * (qkv0_tables ? 4 : 8) + (double)np * 18 * 2 * kDim * 4);
       HIP_TRY(launch_assemble(a, s));
     }
     if (dbg && dbg->tokens)
@@ -487,6 +522,16 @@ int veto_forward(veto_handle_t h, void* stream, const veto_inputs_t* in, void* w
         rc = run_gemm(h, s, "gemm_out_cls", abar, h->fold_n, w.out_b, ws.x, (long)kTokens * kDim, ws.xc, nullptr, kDim, np, kDim,
                       H * kDim, EPI_RESID);
         if (rc) return rc;
+      } else if (l == 0 && qkv0_tables) {
+        {
+          ProfScope ps(h, s, "qkv0_combine", 0, (double)np * 17 * 3 * kDim * 4 * 3);
+          HIP_TRY(launch_qkv0_combine(ws.sw, ws.ow, ws.stats, h->q0_vec, ws.subj + c0, ws.obj + c0, qkv, np, s));
+        }
+        for (int t = kTokens - 2; t < kTokens; ++t) {   // the ReLU'd location / class rows: LayerNorm'ed split rows x Wqkv as usual
+          rc = run_gemm(h, s, "gemm_qkv0_lc", ws.a + (size_t)t * 2 * kDim, w.qkv, nullptr, nullptr, 0, qkv + (size_t)t * 3 * kDim, nullptr,
+                        (long)kTokens * 3 * kDim, np, 3 * kDim, kDim, EPI_F32, (long)kTokens * 2 * kDim, 0);
+          if (rc) return rc;
+        }
       } else if (!last) {
         rc = run_gemm(h, s, "gemm_qkv", ws.a, w.qkv, nullptr, nullptr, 0, qkv, nullptr, 3 * kDim, M, 3 * kDim, kDim, EPI_F32);
         if (rc) return rc;
