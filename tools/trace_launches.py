@@ -1,0 +1,41 @@
+"""Per-launch view of a rocprofv3 kernel trace: the split-GEMM kernel runs every Linear of the step, so its `--stats`
+average mixes shapes.  This prints, for each GEMM dispatch position inside a forward step (steps start at
+pair_indices_kernel), the instantiation and the mean duration over the steps of the trace -- the rocprof-side numbers
+that bench.py's per-launch hipEvent times (kernels_ms_per_step / launches) are to be compared with.
+usage: python tools/trace_launches.py <kernel_trace.csv>   (launch order = the run_gemm calls of veto_forward, veto_abi.hip)"""
+import csv
+import re
+import sys
+from collections import defaultdict
+
+ORDER_L4 = ["gemm_patch", "gemm_qkv0_tab (S)", "gemm_qkv0_tab (O)", "gemm_qkv0_lc (t17)", "gemm_qkv0_lc (t18)", "gemm_out", "gemm_fc1",
+            "gemm_fc2", "gemm_qkv", "gemm_out", "gemm_fc1", "gemm_fc2", "gemm_qkv", "gemm_out", "gemm_fc1", "gemm_fc2", "gemm_u_cls",
+            "gemm_out_cls", "gemm_fc1_cls", "gemm_fc2_cls"]
+
+
+def main(path):
+    rows = list(csv.DictReader(open(path)))
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    steps, cur = [], None
+    for r in rows:
+        name = r["Kernel_Name"]
+        if "pair_indices_kernel" in name:
+            cur = []
+            steps.append(cur)
+        elif cur is not None and "gemm_split_ps_kernel" in name:
+            inst = re.search(r"gemm_split_ps_kernel<([^>]*)>", name).group(1)
+            cur.append((inst, (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3))
+    n = max(len(s) for s in steps)
+    steps = [s for s in steps if len(s) == n]
+    acc = defaultdict(list)
+    for s in steps:
+        for i, (inst, us) in enumerate(s):
+            acc[(i, inst)].append(us)
+    print("%d forward steps, %d GEMM launches each (4-layer order: %s)" % (len(steps), n, "yes" if n == len(ORDER_L4) else "n/a"))
+    for (i, inst), v in sorted(acc.items()):
+        label = ORDER_L4[i] if n == len(ORDER_L4) else ""
+        print("  launch %2d  gemm_split_ps_kernel<%s>  mean %8.1f us  (min %8.1f, max %8.1f)  %s" % (i, inst, sum(v) / len(v), min(v), max(v), label))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])
