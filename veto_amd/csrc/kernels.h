@@ -107,7 +107,9 @@ struct AssembleArgs {
 };
 hipError_t launch_assemble(const AssembleArgs& a, hipStream_t s);
 // layer 0 in the per-object form (rowops.hip): qkv rows of tokens 0..16 from the per-object tables sw / ow [n_obj*16, 1728],
-// the row statistics and the weight-only vectors vec = [c1 | c2 | pw | qkv_cls]; and the kernel that builds vec and Wqkv diag(gamma)
+// the row statistics and the weight-only vectors vec = [c2 | b0 | qkv_cls]; the kernel that builds vec and Wqkv diag(gamma);
+// and the row-centred split rows of the two halves of patch_tab [rows, 1152] -> [rows, 2*1152]
+hipError_t launch_centre_split(const float* patch_tab, __bf16* dst, int rows, hipStream_t s);
 hipError_t launch_qkv0_combine(const float* sw, const float* ow, const float* stats, const float* vec, const int32_t* subj,
                                const int32_t* obj, float* qkv, int n_pair, hipStream_t s);
 hipError_t launch_qkv0_consts(const float* wq, const float* gamma, const float* beta, const float* pos, const float* cls, float* wp,

@@ -381,22 +381,24 @@ __global__ __launch_bounds__(256) void assemble_kernel(AssembleArgs a) {
 }
 
 // ---- layer 0, per-object form of LayerNorm + QKV ---------------------------------------------
-// x = S[s, t] + O[o, t] + pos for the 16 patch tokens, so with W' = Wqkv diag(gamma):
-//   LN(x) Wqkv^T = rstd (x W'^T - mean c1) + c2 = rstd (SW[s, t] + OW[o, t] + pw - mean c1) + c2
-// SW = S W'^T, OW = O W'^T are per-OBJECT tables ([n_obj*16, 1728], two small GEMMs), c1 = W' 1, c2 = Wqkv beta, pw = W' pos and the
-// constant CLS row are weight-only vectors (vec = [c1 | c2 | pw | qkv_cls]).  One wave per (pair, token 0..16) row; the rows of
-// tokens 17 / 18 are written by two GEMMs over their LayerNorm'ed split rows.
+// x = S[s, t] + O[o, t] + pos for the 16 patch tokens, and the row mean of a sum is the sum of the row means, so with
+// W' = Wqkv diag(gamma) and every term centred on its own row mean (Sc = S - mean(S) etc.):
+//   LN(x) Wqkv^T = rstd (x - mean(x)) W'^T + c2 = rstd (SW[s, t] + OW[o, t]) + c2,
+//   SW = Sc W'^T + b0 (b0 = W' (pos - mean(pos))),  OW = Oc W'^T,  c2 = Wqkv beta
+// SW / OW are per-OBJECT tables ([n_obj*16, 1728], two small GEMMs over centred split rows, centre_split_kernel), c2, b0 and
+// the constant CLS row are weight-only vectors (vec = [c2 | b0 | qkv_cls]); only rstd depends on the pair.  The consumer is
+// the layer-0 attention itself (attention.hip, TAB) or, for head widths without an MFMA attention, qkv0_combine_kernel, which
+// materialises the qkv rows of tokens 0..16: one wave per row.  The rows of tokens 17 / 18 (ReLU'd, not linear in the tables)
+// are written by two GEMMs over their LayerNorm'ed split rows.
 __global__ __launch_bounds__(256) void qkv0_combine_kernel(const float* __restrict__ sw, const float* __restrict__ ow,
                                                            const float* __restrict__ stats, const float* __restrict__ vec,
                                                            const int32_t* __restrict__ subj, const int32_t* __restrict__ obj,
                                                            float* __restrict__ qkv, int n_pair) {
   constexpr int N = 3 * kDim, N4 = N / 4;
-  __shared__ __attribute__((aligned(16))) float s_vec[3 * N];
-  for (int i = threadIdx.x; i < 3 * N4; i += 256) ((f32x4*)s_vec)[i] = ((const f32x4*)vec)[i];
+  __shared__ __attribute__((aligned(16))) float s_vec[N];
+  for (int i = threadIdx.x; i < N4; i += 256) ((f32x4*)s_vec)[i] = ((const f32x4*)vec)[i];
   __syncthreads();
-  const f32x4* c1 = (const f32x4*)s_vec;
-  const f32x4* c2 = c1 + N4;
-  const f32x4* pw = c2 + N4;
+  const f32x4* c2 = (const f32x4*)s_vec;
   const int lane = threadIdx.x & 63;
   // Workgroups are dealt round-robin to the 8 XCDs: XCD x walks the x-th contiguous eighth of the rows (one or two images), its
   // workgroups side by side, so that the per-object rows of those images (8 MB per 36-object image) are fetched into ONE L2
@@ -407,55 +409,85 @@ __global__ __launch_bounds__(256) void qkv0_combine_kernel(const float* __restri
     const int p = (int)(r / (kPatchTokens + 1)), t = (int)(r % (kPatchTokens + 1));
     f32x4* dst = (f32x4*)(qkv + ((size_t)p * kTokens + t) * N);
     if (t == 0) {
-      const f32x4* src = (const f32x4*)(vec + 3 * N);
+      const f32x4* src = (const f32x4*)(vec + 2 * N);
       for (int i = lane; i < N4; i += 64) dst[i] = src[i];
       continue;
     }
-    const float2 st = *(const float2*)(stats + ((size_t)p * kTokens + t) * 2);
-    const float mean = st.x, rstd = st.y;
+    const float rstd = stats[((size_t)p * kTokens + t) * 2 + 1];
     const f32x4* a = (const f32x4*)(sw + ((size_t)subj[p] * kPatchTokens + t - 1) * N);
     const f32x4* b = (const f32x4*)(ow + ((size_t)obj[p] * kPatchTokens + t - 1) * N);
 #pragma unroll
     for (int k = 0; k < (N4 + 63) / 64; ++k) {
       const int i = lane + 64 * k;
-      if (i < N4) dst[i] = rstd * ((a[i] + b[i]) + (pw[i] - mean * c1[i])) + c2[i];
+      if (i < N4) dst[i] = rstd * (a[i] + b[i]) + c2[i];
     }
   }
 }
 
-// weight-only vectors of the per-object layer-0 form: vec = [c1 | c2 | pw | qkv_cls], each [1728]; wq = Wqkv [1728, 576], wp = Wqkv diag(gamma)
+// patch_tab fp32 [rows, 1152] (subject half | object half) -> split rows [rows, 2*1152] of the halves, each centred on its own
+// row mean: the A operands of the two table GEMMs.  A quarter wave per half row.
+__global__ __launch_bounds__(256) void centre_split_kernel(const float* __restrict__ src, __bf16* __restrict__ dst, int rows) {
+  const long hr = (long)blockIdx.x * 16 + (threadIdx.x >> 4);     // half-row index
+  if (hr >= 2L * rows) return;
+  const int q = threadIdx.x & 15;
+  const float* xr = src + (size_t)hr * kDim;                       // row hr / 2, half hr & 1: contiguous in [rows, 1152]
+  RowQ r;
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < 9; ++j) {
+    r.v[j] = *(const f32x4*)(xr + 4 * (q + 16 * j));
+    s += (r.v[j][0] + r.v[j][1]) + (r.v[j][2] + r.v[j][3]);
+  }
+  const float mean = group16_sum(s) * (1.f / kDim);
+  __bf16* d0 = dst + (size_t)hr * (2 * kDim);                      // split row of [rows, 2*1152]: half h starts at element h * 1152
+#pragma unroll
+  for (int j = 0; j < 9; ++j) {
+    const int c = 4 * (q + 16 * j);
+    bf16x4 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      __bf16 h, l;
+      split_bf16(r.v[j][e] - mean, h, l);
+      hi[e] = h;
+      lo[e] = l;
+    }
+    __bf16* d = d0 + split_index(c);
+    *(bf16x4*)d = hi;
+    *(bf16x4*)(d + 32) = lo;
+  }
+}
+
+// weight-only vectors of the per-object layer-0 form: vec = [c2 | b0 | qkv_cls], each [1728]; wq = Wqkv [1728, 576], wp = Wqkv diag(gamma)
 __global__ __launch_bounds__(64) void qkv0_consts_kernel(const float* __restrict__ wq, const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, const float* __restrict__ pos,
                                                          const float* __restrict__ cls, float* __restrict__ wp, float* __restrict__ vec) {
   const int n = blockIdx.x, lane = threadIdx.x, N = 3 * kDim;
-  // LayerNorm statistics of the constant CLS row x = cls_token + pos_embedding (every block recomputes them: 576 values)
-  double s = 0.0, sq = 0.0;
-  for (int k = lane; k < kDim; k += 64) s += (double)(cls[k] + pos[k]);
-  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-  const double mean = s / kDim;
+  // row mean of pos_embedding, and the LayerNorm statistics of the constant CLS row x = cls_token + pos_embedding (every block
+  // recomputes them: 576 values)
+  double s = 0.0, sp = 0.0, sq = 0.0;
+  for (int k = lane; k < kDim; k += 64) { s += (double)(cls[k] + pos[k]); sp += (double)pos[k]; }
+  for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); sp += __shfl_xor(sp, o, 64); }
+  const double mean = s / kDim, mean_pos = sp / kDim;
   for (int k = lane; k < kDim; k += 64) { const double d = (double)(cls[k] + pos[k]) - mean; sq += d * d; }
   for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
   const double rstd = 1.0 / sqrt(sq / kDim + 1e-5);
-  double c1 = 0.0, c2 = 0.0, pw = 0.0, qc = 0.0;
+  double c2 = 0.0, b0 = 0.0, qc = 0.0;
   for (int k = lane; k < kDim; k += 64) {
     const float w = wq[(size_t)n * kDim + k], g = w * gamma[k];
     wp[(size_t)n * kDim + k] = g;
-    c1 += (double)g;
     c2 += (double)w * (double)beta[k];
-    pw += (double)g * (double)pos[k];
+    b0 += (double)g * ((double)pos[k] - mean_pos);
     qc += (double)g * ((double)(cls[k] + pos[k]) - mean);
   }
   for (int o = 32; o > 0; o >>= 1) {
-    c1 += __shfl_xor(c1, o, 64);
     c2 += __shfl_xor(c2, o, 64);
-    pw += __shfl_xor(pw, o, 64);
+    b0 += __shfl_xor(b0, o, 64);
     qc += __shfl_xor(qc, o, 64);
   }
   if (lane == 0) {
-    vec[n] = (float)c1;
-    vec[N + n] = (float)c2;
-    vec[2 * N + n] = (float)pw;
-    vec[3 * N + n] = (float)(rstd * qc + c2);
+    vec[n] = (float)c2;
+    vec[N + n] = (float)b0;
+    vec[2 * N + n] = (float)(rstd * qc + c2);
   }
 }
 
@@ -586,6 +618,11 @@ hipError_t launch_qkv0_combine(const float* sw, const float* ow, const float* st
   const long rows = (long)n_pair * (kPatchTokens + 1);
   const unsigned blocks = (unsigned)(rows / 4 + 8 < 4096 ? (rows / 4 + 8) / 8 * 8 : 4096);   // a multiple of 8 (XCDs)
   VETO_LAUNCH(qkv0_combine_kernel, dim3(blocks), dim3(256), 0, s, sw, ow, stats, vec, subj, obj, qkv, n_pair);
+  return hipGetLastError();
+}
+
+hipError_t launch_centre_split(const float* patch_tab, __bf16* dst, int rows, hipStream_t s) {
+  VETO_LAUNCH(centre_split_kernel, dim3((unsigned)((2L * rows + 15) / 16)), dim3(256), 0, s, patch_tab, dst, rows);
   return hipGetLastError();
 }
 

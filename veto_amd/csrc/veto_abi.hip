@@ -73,7 +73,7 @@ struct veto_handle_s {
   // last layer, folded CLS attention (attention.hip): Mcat [heads*576, 2*576], Ncat [576, 2*heads*576], and their fp32 staging
   SplitW fold_m = nullptr, fold_n = nullptr;
   float* fold_tmp = nullptr;
-  // layer 0, per-object form of LayerNorm + QKV (rowops.hip): Wqkv diag(gamma) as a GEMM operand, vec = [c1 | c2 | pw | qkv_cls]
+  // layer 0, per-object form of LayerNorm + QKV (rowops.hip): Wqkv diag(gamma) as a GEMM operand, vec = [c2 | b0 | qkv_cls]
   SplitW q0_w = nullptr;
   float* q0_vec = nullptr;
   float* patch_bias = nullptr;
@@ -341,7 +341,7 @@ int veto_create(const veto_config_t* cfg, veto_handle_t* out) {
   const size_t o_head = dtake((size_t)kDim * cfg->num_out * 4);
   const size_t fold_el = (size_t)cfg->heads * kDim * kDim;
   const size_t o_fm = dtake(fold_el * 4), o_fn = dtake(fold_el * 4), o_ft = dtake(fold_el * 4);
-  const size_t o_q0w = dtake((size_t)3 * kDim * kDim * 4), o_q0v = dtake((size_t)4 * 3 * kDim * 4);
+  const size_t o_q0w = dtake((size_t)3 * kDim * kDim * 4), o_q0v = dtake((size_t)3 * 3 * kDim * 4);
   e = hipMalloc((void**)&h->derived, doff);
   if (e != hipSuccess) { hipFree(h->raw); delete h; return fail(VETO_ERR_HIP, "hipMalloc(derived weights): %s", hipGetErrorString(e)); }
   h->layers.resize(L);
@@ -474,8 +474,8 @@ int veto_forward(veto_handle_t h, void* stream, const veto_inputs_t* in, void* w
   const bool qkv0_tables = L >= 2 && !tables_off;
   if (qkv0_tables) {
     const int R = n_obj * 16;
-    HIP_TRY(launch_split_rows(ws.patch_tab, ws.ptab_split, (size_t)R, 2 * kDim, s));
-    int rc = run_gemm(h, s, "gemm_qkv0_tab", ws.ptab_split, h->q0_w, nullptr, nullptr, 0, ws.sw, nullptr, 3 * kDim, R, 3 * kDim, kDim,
+    HIP_TRY(launch_centre_split(ws.patch_tab, ws.ptab_split, R, s));
+    int rc = run_gemm(h, s, "gemm_qkv0_tab", ws.ptab_split, h->q0_w, h->q0_vec + 3 * kDim, nullptr, 0, ws.sw, nullptr, 3 * kDim, R, 3 * kDim, kDim,
                       EPI_F32, (long)2 * 2 * kDim, 0);
     if (rc) return rc;
     rc = run_gemm(h, s, "gemm_qkv0_tab", ws.ptab_split + 2 * kDim, h->q0_w, nullptr, nullptr, 0, ws.ow, nullptr, 3 * kDim, R, 3 * kDim, kDim,
