@@ -98,7 +98,10 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a, int dh, int 
 
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
-template <int DH>
+// TAB: layer 0 in the per-object form -- q / k / v of the 16 patch tokens never exist in memory: their chunks are formed on load
+// from the two per-object table rows (L2 / Infinity Cache), the row's rstd and c2 (AttnArgs::sw ...).  (Giving each XCD a
+// contiguous eighth of the items, so that an image's table rows meet in one L2, measured neutral.)
+template <int DH, bool TAB = false>
 __global__ __launch_bounds__(128) void attention_mfma_kernel(AttnArgs a) {
   constexpr int DHP = (DH + 15) / 16 * 16;  // contraction extent of QK^T (zero padded)
   constexpr int RB = DHP * 2;               // bytes per row of the Q / K images (bf16)
@@ -130,13 +133,29 @@ __global__ __launch_bounds__(128) void attention_mfma_kernel(AttnArgs a) {
 
   // ---- global -> registers (all loads in flight), then -> bf16 hi/lo LDS images ----------------
   f32x4 ld[ROUNDS][2];
+  f32x4 ldb[TAB ? ROUNDS : 1][2];     // TAB: the object-side table row of a patch token
+  float rs[TAB ? ROUNDS : 1];         // TAB: rstd of the token row
+  const float* tab_s = nullptr;
+  const float* tab_o = nullptr;
+  if constexpr (TAB) {
+    tab_s = a.sw + (size_t)a.subj[pair] * kPatchTokens * (3 * kDim) + head * DH;
+    tab_o = a.ow + (size_t)a.obj[pair] * kPatchTokens * (3 * kDim) + head * DH;
+  }
 #pragma unroll
   for (int r = 0; r < ROUNDS; ++r) {
     const int e = lane + 64 * r;
     const int mat = e / PER_MAT, rem = e % PER_MAT, i = rem / CH, c = rem % CH;
     const bool need = e < 3 * PER_MAT && !(a.cls_only && mat == 0 && i > 0);
-    if (need) {
-      const float* src = src0 + (size_t)i * (3 * kDim) + mat * kDim + c * 8;
+    if (TAB && need && i >= 1 && i <= kPatchTokens) {
+      const size_t off = (size_t)(i - 1) * (3 * kDim) + mat * kDim + c * 8;
+      ld[r][0] = *(const f32x4*)(tab_s + off);
+      ld[r][1] = *(const f32x4*)(tab_s + off + 4);
+      ldb[TAB ? r : 0][0] = *(const f32x4*)(tab_o + off);
+      ldb[TAB ? r : 0][1] = *(const f32x4*)(tab_o + off + 4);
+      rs[TAB ? r : 0] = a.stats[((size_t)pair * kTokens + i) * 2 + 1];
+    } else if (need) {
+      const float* src = TAB && i == 0 ? a.vec + 2 * (3 * kDim) + head * DH + mat * kDim + c * 8
+                                       : src0 + (size_t)i * (3 * kDim) + mat * kDim + c * 8;
       ld[r][0] = *(const f32x4*)src;
       ld[r][1] = *(const f32x4*)(src + 4);
     } else {
@@ -149,6 +168,12 @@ __global__ __launch_bounds__(128) void attention_mfma_kernel(AttnArgs a) {
     const int e = lane + 64 * r;
     if (e >= 3 * PER_MAT) continue;
     const int mat = e / PER_MAT, rem = e % PER_MAT, i = rem / CH, c = rem % CH;
+    if (TAB && i >= 1 && i <= kPatchTokens) {     // rstd (SW + OW) + c2 (c2: 3 * DH floats per head, L1-resident)
+      const float* c2 = a.vec + head * DH + mat * kDim + c * 8;
+      const f32x4 c20 = *(const f32x4*)c2, c21 = *(const f32x4*)(c2 + 4);
+      ld[r][0] = rs[TAB ? r : 0] * (ld[r][0] + ldb[TAB ? r : 0][0]) + c20;
+      ld[r][1] = rs[TAB ? r : 0] * (ld[r][1] + ldb[TAB ? r : 0][1]) + c21;
+    }
     bf16x8 hi, lo;
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
@@ -424,17 +449,33 @@ hipError_t launch_cls_fold_attention(const __bf16* a_split, const float* u, __bf
   return hipGetLastError();
 }
 
+static bool attn_force_valu() {
+  static const bool f = getenv("VETO_ATTN_VALU") != nullptr;  // A/B knob for the parity tests
+  return f;
+}
+
+bool attention_reads_tables(int heads) {
+  if (heads <= 0 || kDim % heads != 0 || attn_force_valu()) return false;
+  const int dh = kDim / heads;
+  return dh == 72 || dh == 96;
+}
+
 hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
   if (kDim % a.heads != 0) return hipErrorInvalidValue;
   const int dh = kDim / a.heads;
-  static const bool force_valu = getenv("VETO_ATTN_VALU") != nullptr;  // A/B knob for the parity tests
+  const bool force_valu = attn_force_valu();
   if (!force_valu && (dh == 72 || dh == 96)) {
     const long items = (long)a.n_pair * a.heads;
     const unsigned blocks = (unsigned)((items + 1) / 2);
-    if (dh == 72) VETO_LAUNCH(attention_mfma_kernel<72>, dim3(blocks), dim3(128), 0, s, a);
+    if (a.sw) {
+      if (!a.ow || !a.stats || !a.vec || !a.subj || !a.obj || a.cls_only) return hipErrorInvalidValue;
+      if (dh == 72) VETO_LAUNCH((attention_mfma_kernel<72, true>), dim3(blocks), dim3(128), 0, s, a);
+      else VETO_LAUNCH((attention_mfma_kernel<96, true>), dim3(blocks), dim3(128), 0, s, a);
+    } else if (dh == 72) VETO_LAUNCH(attention_mfma_kernel<72>, dim3(blocks), dim3(128), 0, s, a);
     else VETO_LAUNCH(attention_mfma_kernel<96>, dim3(blocks), dim3(128), 0, s, a);
     return hipGetLastError();
   }
+  if (a.sw) return hipErrorInvalidValue;
   if (dh % 4 != 0) return hipErrorInvalidValue;
   const int ldh = dh + 4;
   const size_t lds = (size_t)kWavesPerBlock * (3 * kTokens * ldh + kTokens * 20) * sizeof(float);

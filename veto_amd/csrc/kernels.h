@@ -126,8 +126,18 @@ struct AttnArgs {
   const float* qkv;        // [n_pair*19, 1728]
   __bf16* o;               // split rows [rows, 2*576]; rows = n_pair*19, or n_pair when cls_only
   int n_pair, heads, cls_only;
+  // layer 0, per-object form (rowops.hip): when sw != nullptr the rows of tokens 1..16 are formed on load as
+  // rstd * (sw[subj*16 + t-1] + ow[obj*16 + t-1]) + c2, token 0 is the constant row vec + 2*1728, and only the rows of tokens
+  // 17 / 18 are read from qkv.  MFMA head widths (72, 96) only: launch_attention returns hipErrorInvalidValue otherwise.
+  const float* sw = nullptr;
+  const float* ow = nullptr;
+  const float* stats = nullptr;   // [n_pair*19, 2]: (mean, rstd)
+  const float* vec = nullptr;     // [c2 | b0 | qkv_cls], each [1728]
+  const int32_t* subj = nullptr;
+  const int32_t* obj = nullptr;
 };
 hipError_t launch_attention(const AttnArgs& a, hipStream_t s);
+bool attention_reads_tables(int heads);   // whether launch_attention takes the per-object form for this head count
 // Folded CLS-only attention of the last layer: a_split = LN1(x) split rows [n_pair*19, 2*576], u fp32 [n_pair, heads*576]
 // (= a_0 . Mcat), abar split rows [n_pair, 2*heads*576] (probability-weighted token means per head)
 int cls_fold_max_heads();

@@ -523,7 +523,7 @@ int veto_forward(veto_handle_t h, void* stream, const veto_inputs_t* in, void* w
                       H * kDim, EPI_RESID);
         if (rc) return rc;
       } else if (l == 0 && qkv0_tables) {
-        {
+        if (!attention_reads_tables(H)) {   // head widths without an MFMA attention: materialise the rows of tokens 0..16
           ProfScope ps(h, s, "qkv0_combine", 0, (double)np * 17 * 3 * kDim * 4 * 3);
           HIP_TRY(launch_qkv0_combine(ws.sw, ws.ow, ws.stats, h->q0_vec, ws.subj + c0, ws.obj + c0, qkv, np, s));
         }
@@ -548,6 +548,9 @@ int veto_forward(veto_handle_t h, void* stream, const veto_inputs_t* in, void* w
         AttnArgs a{};
         a.qkv = qkv; a.n_pair = np; a.heads = H; a.cls_only = last ? 1 : 0;
         a.o = last ? ws.ac : ws.a;
+        if (l == 0 && qkv0_tables && attention_reads_tables(H)) {   // q / k / v of the patch tokens are formed on load
+          a.sw = ws.sw; a.ow = ws.ow; a.stats = ws.stats; a.vec = h->q0_vec; a.subj = ws.subj + c0; a.obj = ws.obj + c0;
+        }
         const double nq = last ? 1 : kTokens;
         ProfScope ps(h, s, last ? "attention_cls" : "attention", 4.0 * np * nq * kTokens * kDim,
                      (double)M * 3 * kDim * 4 + (double)np * nq * kDim * 4);
