@@ -141,7 +141,7 @@ def main():
         passes = 3 if args.precision == "precise" else 1
         hbm_gbps = {k: round(prof[k]["bytes_per_launch"] / (kern[k]["avg_ms"] * 1e-3) / 1e9, 1)
                     for k in ("attention", "attention_cls", "layernorm") if k in prof and prof[k]["bytes_per_launch"]}
-        gather_bytes = float(n_pairs) * 19 * 576 * 8
+        gather_bytes = prof["assemble_tokens"]["bytes_per_launch"]      # bytes the kernel writes, as the library accounts them
         gather_gbps = gather_bytes / (kern["assemble_tokens"]["avg_ms"] * 1e-3) / 1e9
         traffic = None
         try:  # PMC-derived HBM bytes per launch of the dominant kernel at THIS workload (profiles/r01_traffic.json)
@@ -168,8 +168,13 @@ def main():
             # north_star: "HBM GB/s on the gather and MFMA utilisation on the attention GEMMs"
             "gather": {"bound": "hbm", "kernel": "assemble_tokens", "achieved": gather_gbps, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                        "frac": gather_gbps / PEAK_HBM_GBS,
-                       "note": "pair gather + token assembly: algorithmic bytes = the [pairs, 19, 576] fp32 stream plus its LayerNorm'ed "
-                               "split-bf16 copy (8 B per element written); the per-object tables it reads stay in L2"},
+                       "bytes": gather_bytes,
+                       "gathered_bytes": float(n_pairs) * 18 * 2 * 576 * 4,
+                       "moved_gbps": (gather_bytes + float(n_pairs) * 18 * 2 * 576 * 4) / (kern["assemble_tokens"]["avg_ms"] * 1e-3) / 1e9,
+                       "note": "pair gather + token assembly: bytes = what the kernel writes (the [pairs, 19, 576] fp32 token rows plus, "
+                               "with layer 0 in the per-object form, the row statistics and the split rows of two of the 19 tokens; "
+                               "otherwise plus the LayerNorm'ed split copy of every row); the per-object rows it gathers (gathered_bytes; moved_gbps counts them too) come from L2 / Infinity Cache. "
+                               "Pure write streams top out near 3.5 TB/s on this part (DESIGN.md section 7)"},
             "gemm_all": {"kernel": "gemm_split_ps_kernel, all launches of a step", "ms_per_step": round(gemm_ms, 4),
                          "achieved": gemm_flops / (gemm_ms * 1e-3) / 1e12, "unit": "TFLOP/s",
                          "frac": gemm_flops / (gemm_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS},

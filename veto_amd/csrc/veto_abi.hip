@@ -496,7 +496,9 @@ int veto_forward(veto_handle_t h, void* stream, const veto_inputs_t* in, void* w
       a.ln_w = h->layers[0].ln1_w; a.ln_b = h->layers[0].ln1_b;
       a.subj = ws.subj + c0; a.obj = ws.obj + c0; a.x = ws.x; a.a = ws.a; a.n_pair = np;
       a.stats = qkv0_tables ? ws.stats : nullptr;
-      ProfScope ps(h, s, "assemble_tokens", 0, (double)M * kDim * (qkv0_tables ? 4 : 8) + (double)np * 18 * 2 * kDim * 4);
+      // bytes = what the kernel WRITES (its HBM stream; the per-object rows it gathers are cache-resident): the fp32 token rows
+      // plus either their LayerNorm'ed split copy, or -- per-object layer 0 -- the row statistics and the split rows of tokens 17, 18
+      ProfScope ps(h, s, "assemble_tokens", 0, (double)M * kDim * 4 + (qkv0_tables ? (double)M * 8 + 2.0 * np * kDim * 4 : (double)M * kDim * 4));
       HIP_TRY(launch_assemble(a, s));
     }
     if (dbg && dbg->tokens)
