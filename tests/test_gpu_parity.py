@@ -517,3 +517,34 @@ def test_wgrad_gemm_against_fp64(m, n, k, ks):
     scale = (dy.abs().double().t() @ x.abs().double()).clamp_min(1e-6)
     rel = ((dw.double() - ref).abs() / scale).max().item()
     assert rel < 2e-5, (m, n, k, ks, rel)
+
+
+def test_restructured_first_and_last_layer_match_the_plain_path(tmp_path):
+    """The per-object form of layer 0 (VETO_QKV0_TABLES) and the folded last layer (VETO_CLS_FOLD) are exact algebra: the
+    logits with both switched off (plain LayerNorm -> QKV GEMM -> attention in every layer) agree with the default path far
+    inside the parity tolerance.  The knobs are read once per process, hence two child processes."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, numpy as np, torch; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "from conftest import load_golden\n"
+            "from veto_amd import testing\n"
+            "from veto_amd.pairs import prepare_test_pairs\n"
+            "g, sd, batch = load_golden('predcls_n36_l4h8')\n"
+            "dev = torch.device('cuda:0')\n"
+            "model = testing.make_predictor(testing.make_config(4, 8), sd, dev)\n"
+            "props = testing.make_proposals(batch, 'predcls', dev)\n"
+            "pairs = prepare_test_pairs(dev, props)\n"
+            "with torch.no_grad():\n"
+            "    out = model(props, pairs, None, None, roi_features=torch.from_numpy(batch['roi_features']).to(dev),\n"
+            "                roi_depth_features=torch.from_numpy(batch['roi_depth_features']).to(dev))\n"
+            "np.save(sys.argv[1], torch.cat(list(out[1])).cpu().numpy())\n") % (root, os.path.join(root, "tests"))
+    outs = []
+    for tag, env in (("default", {}), ("plain", {"VETO_QKV0_TABLES": "0", "VETO_CLS_FOLD": "0"})):
+        path = str(tmp_path / (tag + ".npy"))
+        subprocess.run([sys.executable, "-c", code, path], check=True, env=dict(os.environ, **env), timeout=600)
+        outs.append(np.load(path))
+    g, _, _ = load_golden("predcls_n36_l4h8")
+    assert np.abs(outs[0] - outs[1]).max() < 1e-4
+    assert np.abs(outs[0] - g["rel_dists"]).max() <= LOGIT_TOL and np.abs(outs[1] - g["rel_dists"]).max() <= LOGIT_TOL
