@@ -7,6 +7,8 @@
 #include "common.h"
 #include "kernels.h"
 
+#include <cstdlib>
+
 namespace veto {
 
 namespace {
@@ -198,6 +200,246 @@ __global__ __launch_bounds__(kAttnBwdThreads) void attention_backward_kernel(con
   }  // items
 }
 
+// ---- MFMA form (head widths 72 and 96, all 19 queries) ----------------------------------------------------------------
+// One wave per (pair, head), all five products on v_mfma_f32_32x32x16_bf16 in the 3-term split-bf16 scheme of the forward
+// (attention.hip).  Both orientations of the scores are computed, because an accumulator serves as the A operand of the next
+// product only along its ROW index:
+//   lane = query:  S^T = K Q^T, dP^T = V dO^T  -> softmax statistics (max, 1/sum, D = sum_j P dP) in-lane, dS [query x key]
+//                  = the A operand of dQ = dS K
+//   lane = key:    S = Q K^T, dP = dO V^T      -> P, dS rebuilt with the statistics (through LDS): the A operands of
+//                  dV = P^T dO and dK = dS^T Q
+// The B operands (K, dO, Q with the TOKEN as contraction index) are read from the same row-major hi / lo images the score
+// products use, through ds_read_b64_tr_b16 (4 tokens x 16 columns per 16-lane group, column-major): no transposed copies.
+// Element e of k-step s of an accumulator-operand is token 16 s + 8 (e >> 2) + 4 h + (e & 3) (h = lane >> 5), which is the
+// order the transposed reads are issued in.  Image row 19 is zero and stands in for tokens 19..31.
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef short bw_s16x4 __attribute__((ext_vector_type(4)));
+typedef short bw_s16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ bf16x8 lds_tr_pair(const char* p0, const char* p1) {
+  const bw_s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bw_s16x4*)p0);
+  const bw_s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bw_s16x4*)p1);
+  const bw_s16x8 v = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+template <int DH>
+__global__ __launch_bounds__(128) void attention_backward_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
+                                                                      float* __restrict__ dqkv, __bf16* __restrict__ dqkv_split,
+                                                                      int n_pair, int heads, int cls_only) {
+  constexpr int DHP = (DH + 15) / 16 * 16;   // contraction extent of the score products (zero padded)
+  constexpr int RB = DHP * 2;                // bytes per image row (bf16)
+  constexpr int NT = (DH + 31) / 32;         // 32-wide output tiles over the head dimension
+  constexpr int PLANE = 20 * RB;             // 19 token rows + the zero row
+  constexpr int WAVE_LDS = 8 * PLANE + 3 * 32 * 4 + 64;   // q, k, v, dO (hi, lo), the statistics, slack for the padded tr reads
+  constexpr int CH = DH / 8, PER_MAT = kTokens * CH, ROUNDS = (4 * PER_MAT + 63) / 64;
+  static_assert(DH % 8 == 0 && kTokens * DH * 4 <= 2 * PLANE, "layout");
+  __shared__ __attribute__((aligned(16))) char smem[2 * WAVE_LDS];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const long gw = (long)blockIdx.x * 2 + w, total = (long)n_pair * heads;
+  const bool active = gw < total;
+  const long item = active ? gw : total - 1;
+  const int pair = (int)(item / heads), head = (int)(item % heads);
+  char* base = smem + w * WAVE_LDS;
+  auto plane = [&](int mat, int lo) { return base + (2 * mat + lo) * PLANE; };   // mat: 0 q, 1 k, 2 v, 3 dO
+  float* stat = (float*)(base + 8 * PLANE);                                       // [3][32]: max, 1 / sum, D
+  const float* src0 = qkv + (size_t)pair * kTokens * (3 * kDim) + head * DH;
+  // cls_only (last layer): dout is compact [n_pair, 576]; the queries / output gradients of tokens 1..18 enter as zeros
+  const float* gsrc = dout + (cls_only ? (size_t)pair * kDim : (size_t)pair * kTokens * kDim) + head * DH;
+
+  // ---- global -> registers (all loads in flight) -> bf16 hi / lo images -------------------------------------------------
+  f32x4 ld[ROUNDS][2];
+#pragma unroll
+  for (int r = 0; r < ROUNDS; ++r) {
+    const int e = lane + 64 * r;
+    const int mat = e / PER_MAT, rem = e % PER_MAT, i = rem / CH, c = rem % CH;
+    if (cls_only && i > 0 && (mat == 0 || mat == 3)) {
+      ld[r][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+      ld[r][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    } else if (e < 4 * PER_MAT) {
+      const float* src = mat < 3 ? src0 + (size_t)i * (3 * kDim) + mat * kDim + c * 8 : gsrc + (size_t)i * kDim + c * 8;
+      ld[r][0] = *(const f32x4*)src;
+      ld[r][1] = *(const f32x4*)(src + 4);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < ROUNDS; ++r) {
+    const int e = lane + 64 * r;
+    if (e >= 4 * PER_MAT) continue;
+    const int mat = e / PER_MAT, rem = e % PER_MAT, i = rem / CH, c = rem % CH;
+    bf16x8 hi, lo;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      __bf16 hh, ll;
+      split_bf16(ld[r][t >> 2][t & 3], hh, ll);
+      hi[t] = hh;
+      lo[t] = ll;
+    }
+    *(bf16x8*)(plane(mat, 0) + i * RB + c * 16) = hi;
+    *(bf16x8*)(plane(mat, 1) + i * RB + c * 16) = lo;
+  }
+  for (int idx = lane; idx < 8 * (RB / 4); idx += 64)      // the zero row of every plane
+    *(uint32_t*)(base + (idx / (RB / 4)) * PLANE + kTokens * RB + 4 * (idx % (RB / 4))) = 0u;
+  if (DHP > DH) {                                            // the contraction padding of the token rows
+    for (int idx = lane; idx < 8 * kTokens; idx += 64) {
+      char* dst = base + (idx / kTokens) * PLANE + (idx % kTokens) * RB + DH * 2;
+#pragma unroll
+      for (int t = 0; t < (DHP - DH) / 2; ++t) *(uint32_t*)(dst + 4 * t) = 0u;
+    }
+  }
+  for (int idx = lane; idx < 16; idx += 64) *(uint32_t*)(base + 8 * PLANE + 3 * 32 * 4 + 4 * idx) = 0u;   // slack behind the last plane
+  __syncthreads();
+
+  // ---- the four score products ---------------------------------------------------------------------------------------------
+  const int r = lane & 31, h = lane >> 5;
+  const int rr = r < kTokens ? r : kTokens;        // lanes beyond the 19 tokens take the zero row
+  f32x16 st, dpt, sk, dpk;                         // S^T, dP^T (lane = query) ; S, dP (lane = key)
+#pragma unroll
+  for (int t = 0; t < 16; ++t) { st[t] = 0.f; dpt[t] = 0.f; sk[t] = 0.f; dpk[t] = 0.f; }
+#pragma unroll
+  for (int s = 0; s < DHP / 16; ++s) {
+    const int off = rr * RB + (16 * s + 8 * h) * 2;
+    const bf16x8 qh = *(const bf16x8*)(plane(0, 0) + off), ql = *(const bf16x8*)(plane(0, 1) + off);
+    const bf16x8 kh = *(const bf16x8*)(plane(1, 0) + off), kl = *(const bf16x8*)(plane(1, 1) + off);
+    const bf16x8 vh = *(const bf16x8*)(plane(2, 0) + off), vl = *(const bf16x8*)(plane(2, 1) + off);
+    const bf16x8 gh = *(const bf16x8*)(plane(3, 0) + off), gl = *(const bf16x8*)(plane(3, 1) + off);
+    st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl, qh, st, 0, 0, 0);      // rows = keys, columns = queries
+    st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, ql, st, 0, 0, 0);
+    st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qh, st, 0, 0, 0);
+    dpt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, gh, dpt, 0, 0, 0);
+    dpt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, gl, dpt, 0, 0, 0);
+    dpt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, gh, dpt, 0, 0, 0);
+    sk = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ql, kh, sk, 0, 0, 0);      // rows = queries, columns = keys
+    sk = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qh, kl, sk, 0, 0, 0);
+    sk = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qh, kh, sk, 0, 0, 0);
+    dpk = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gl, vh, dpk, 0, 0, 0);
+    dpk = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gh, vl, dpk, 0, 0, 0);
+    dpk = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gh, vh, dpk, 0, 0, 0);
+  }
+
+  // ---- lane = query: softmax over the keys (16 registers here + 16 in lane ^ 32), D, dS ------------------------------------
+  const float scale = 1.0f / sqrtf((float)DH);
+  auto tok = [&](int t) { return (t & 3) + 8 * (t >> 2) + 4 * h; };      // token of accumulator register t
+  bf16x8 dsh[2], dsl[2];                                                // dS [query x key] as the A operand of dQ
+  {
+    float p[16];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      p[t] = tok(t) < kTokens ? st[t] * scale : -INFINITY;
+      mx = fmaxf(mx, p[t]);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      p[t] = expf(p[t] - mx);
+      sum += p[t];
+    }
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.f / sum;
+    float dsum = 0.f;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      p[t] *= inv;
+      dsum += p[t] * dpt[t];
+    }
+    dsum += __shfl_xor(dsum, 32, 64);
+    if (h == 0) { stat[r] = mx; stat[32 + r] = inv; stat[64 + r] = dsum; }
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      __bf16 hh, ll;
+      split_bf16(p[t] * (dpt[t] - dsum), hh, ll);
+      dsh[t >> 3][t & 7] = hh;
+      dsl[t >> 3][t & 7] = ll;
+    }
+  }
+  __syncthreads();
+  // ---- lane = key: P and dS from the statistics of each register's query --------------------------------------------------
+  bf16x8 pkh[2], pkl[2], dkh[2], dkl[2];                                // P^T, dS^T [key x query] as A operands of dV, dK
+#pragma unroll
+  for (int t = 0; t < 16; ++t) {
+    const int i = tok(t);
+    const float pv = (r < kTokens && i < kTokens) ? expf(sk[t] * scale - stat[i]) * stat[32 + i] : 0.f;
+    const float dv = pv * (dpk[t] - stat[64 + i]);
+    __bf16 hh, ll;
+    split_bf16(pv, hh, ll);
+    pkh[t >> 3][t & 7] = hh;
+    pkl[t >> 3][t & 7] = ll;
+    split_bf16(dv, hh, ll);
+    dkh[t >> 3][t & 7] = hh;
+    dkl[t >> 3][t & 7] = ll;
+  }
+
+  // ---- dQ = dS K, dK = dS^T Q, dV = P^T dO: B operands by transposed reads of the row-major images --------------------------
+  const int g4 = lane >> 4, tq = (lane >> 2) & 3, tp = lane & 3;
+  auto tr_b = [&](int mat, int lo, int n, int s) {          // B fragment: columns 32 n + (lane & 31), tokens of k-step s
+    const char* pl = plane(mat, lo) + (32 * n + 16 * (g4 & 1) + 4 * tp) * 2;
+    int t0 = 16 * s + 4 * h + tq, t1 = t0 + 8;
+    t0 = t0 < kTokens ? t0 : kTokens;
+    t1 = t1 < kTokens ? t1 : kTokens;
+    return lds_tr_pair(pl + t0 * RB, pl + t1 * RB);
+  };
+  float* o_lds = (float*)plane(2, 0);                        // [19][DH] fp32 staging in the (dead) V planes
+  float* dst = dqkv ? dqkv + (size_t)pair * kTokens * (3 * kDim) + head * DH : nullptr;
+#pragma unroll
+  for (int prod = 0; prod < 3; ++prod) {
+    const int bmat = prod == 0 ? 1 : prod == 1 ? 0 : 3;      // B = K, Q, dO
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      f32x16 o;
+#pragma unroll
+      for (int t = 0; t < 16; ++t) o[t] = 0.f;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const bf16x8 bh = tr_b(bmat, 0, n, s), bl = tr_b(bmat, 1, n, s);
+        const bf16x8 ah = prod == 0 ? dsh[s] : prod == 1 ? dkh[s] : pkh[s];
+        const bf16x8 al = prod == 0 ? dsl[s] : prod == 1 ? dkl[s] : pkl[s];
+        o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, o, 0, 0, 0);
+        o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, o, 0, 0, 0);
+        o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, o, 0, 0, 0);
+      }
+      const int d = 32 * n + r;
+      if (d < DH) {
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+          const int i = tok(t);
+          if (i < kTokens) o_lds[i * DH + d] = o[t] * (prod < 2 ? scale : 1.f);
+        }
+      }
+    }
+    __syncthreads();
+    if (active) {
+      for (int e = lane; e < kTokens * CH; e += 64) {
+        const int i = e / CH, c = e % CH;
+        const f32x4 v0 = *(const f32x4*)(o_lds + i * DH + c * 8), v1 = *(const f32x4*)(o_lds + i * DH + c * 8 + 4);
+        if (dqkv_split) {
+          bf16x8 hi, lo;
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            __bf16 hh, ll;
+            split_bf16(v0[t], hh, ll);
+            hi[t] = hh;
+            lo[t] = ll;
+            split_bf16(v1[t], hh, ll);
+            hi[4 + t] = hh;
+            lo[4 + t] = ll;
+          }
+          __bf16* d2 = dqkv_split + ((size_t)pair * kTokens + i) * (2 * 3 * kDim) + split_index(prod * kDim + head * DH + c * 8);
+          *(bf16x8*)d2 = hi;
+          *(bf16x8*)(d2 + 32) = lo;
+        } else {
+          float* d2 = dst + (size_t)i * (3 * kDim) + prod * kDim + c * 8;
+          *(f32x4*)d2 = v0;
+          *(f32x4*)(d2 + 4) = v1;
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+
 // LayerNorm backward over 576-wide rows, half a wave per row (lane q holds the 8-byte chunks q + 32 j; 16 lanes per row
 // with 16-byte chunks needed 244 VGPRs = 2 waves / SIMD and ran at 2.9 TB/s):
 //   xhat = (x - mean) * rstd, g = dy * gamma, dx = rstd * (g - mean(g) - xhat * mean(g * xhat)) (+ dres)
@@ -365,6 +607,13 @@ hipError_t launch_attention_backward(const float* qkv, const float* dout, float*
                                      hipStream_t s) {
   if (heads <= 0 || kDim % heads != 0 || n_pair <= 0 || (!dqkv == !dqkv_split)) return hipErrorInvalidValue;
   const int dh = kDim / heads;
+  static const bool force_valu = getenv("VETO_ATTN_BWD_VALU") != nullptr;      // A/B knob
+  if (!force_valu && (dh == 72 || dh == 96)) {
+    const unsigned blocks = (unsigned)(((long)n_pair * heads + 1) / 2);
+    if (dh == 72) VETO_LAUNCH(attention_backward_mfma_kernel<72>, dim3(blocks), dim3(128), 0, s, qkv, dout, dqkv, dqkv_split, n_pair, heads, cls_only);
+    else VETO_LAUNCH(attention_backward_mfma_kernel<96>, dim3(blocks), dim3(128), 0, s, qkv, dout, dqkv, dqkv_split, n_pair, heads, cls_only);
+    return hipGetLastError();
+  }
   if (dh == 72) return launch_attention_backward_dh<72>(qkv, dout, dqkv, dqkv_split, n_pair, heads, cls_only, s);
   if (dh == 96) return launch_attention_backward_dh<96>(qkv, dout, dqkv, dqkv_split, n_pair, heads, cls_only, s);
   if (dh == 144) return launch_attention_backward_dh<144>(qkv, dout, dqkv, dqkv_split, n_pair, heads, cls_only, s);
