@@ -315,15 +315,6 @@ __global__ __launch_bounds__(128) void attention_mfma_kernel(AttnArgs a) {
 }
 
 
-// ---- last layer, folded form (DESIGN.md section 4) -----------------------------------------------------------------
-// Only the CLS query of the last layer is consumed, and for ONE query the key / value projections can be moved off the 19
-// tokens: with a_j = LN1(x_j) (the 576-vector of token j),
-//   score[h][j] = q0_h . k_{j,h} = (W_k,h^T q0_h) . a_j = u_h . a_j,      u = a_0 . Mcat,  M_h = W_q,h^T W_k,h   (576 x 576)
-//   out         = sum_h W_o,h (sum_j p[h][j] W_v,h a_j) = sum_h N_h abar_h,  abar_h = sum_j p[h][j] a_j,  N_h = W_o,h W_v,h
-// so the [19 n_pair, 1152] key / value GEMM becomes two GEMMs over the n_pair CLS rows (u: K = 576, N = 576 H; out: K = 576 H,
-// N = 576; M_h, N_h are products of weights, built once) around this kernel: per pair, scores of the H heads against the 19
-// tokens, softmax, and the H probability-weighted token means.  One workgroup per pair; wave w owns heads w, w + 4, ...;
-// lane l owns columns l + 64 i; the token vectors are staged once in LDS as fp32 (hi + lo of the split rows the GEMMs read).
 // sum over the 16 lanes of a DPP row (row_ror 8 / 4 / 2 / 1): VALU-speed, no LDS crossbar; all lanes must be active
 template <int CTRL>
 __device__ __forceinline__ float dpp_rot16(float v) {
@@ -337,6 +328,15 @@ __device__ __forceinline__ float row16_sum(float v) {
   return v;
 }
 
+// ---- last layer, folded form (DESIGN.md section 4) -----------------------------------------------------------------
+// Only the CLS query of the last layer is consumed, and for ONE query the key / value projections can be moved off the 19
+// tokens: with a_j = LN1(x_j) (the 576-vector of token j),
+//   score[h][j] = q0_h . k_{j,h} = (W_k,h^T q0_h) . a_j = u_h . a_j,      u = a_0 . Mcat,  M_h = W_q,h^T W_k,h   (576 x 576)
+//   out         = sum_h W_o,h (sum_j p[h][j] W_v,h a_j) = sum_h N_h abar_h,  abar_h = sum_j p[h][j] a_j,  N_h = W_o,h W_v,h
+// so the [19 n_pair, 1152] key / value GEMM becomes two GEMMs over the n_pair CLS rows (u: K = 576, N = 576 H; out: K = 576 H,
+// N = 576; M_h, N_h are products of weights, built once) around this kernel: per pair, scores of the H heads against the 19
+// tokens, softmax, and the H probability-weighted token means.  One workgroup per pair; wave w owns heads w, w + 4, ...;
+// lane l owns columns l + 64 i; the token vectors are staged once in LDS as fp32 (hi + lo of the split rows the GEMMs read).
 constexpr int kFoldMaxHeads = 12;     // heads * 19 <= 256: one softmax element per thread
 
 __global__ __launch_bounds__(256) void cls_fold_attention_kernel(const __bf16* __restrict__ a_split, const float* __restrict__ u,
