@@ -336,27 +336,47 @@ __device__ __forceinline__ float row16_sum(float v) {
 // so the [19 n_pair, 1152] key / value GEMM becomes two GEMMs over the n_pair CLS rows (u: K = 576, N = 576 H; out: K = 576 H,
 // N = 576; M_h, N_h are products of weights, built once) around this kernel: per pair, scores of the H heads against the 19
 // tokens, softmax, and the H probability-weighted token means.  One workgroup per pair; wave w owns heads w, w + 4, ...;
-// lane l owns columns l + 64 i; the token vectors are staged once in LDS as fp32 (hi + lo of the split rows the GEMMs read).
+// lane l owns columns l + 64 i; the token vectors a_j = LN1(x_j) are computed here from the residual stream and staged in LDS.
 constexpr int kFoldMaxHeads = 12;     // heads * 19 <= 256: one softmax element per thread
 
-__global__ __launch_bounds__(256) void cls_fold_attention_kernel(const __bf16* __restrict__ a_split, const float* __restrict__ u,
+__global__ __launch_bounds__(256) void cls_fold_attention_kernel(const float* __restrict__ x, const float* __restrict__ ln_w,
+                                                                 const float* __restrict__ ln_b, const float* __restrict__ u,
                                                                  __bf16* __restrict__ abar, int n_pair, int heads, float scale) {
   __shared__ __attribute__((aligned(16))) float a_s[kTokens * kDim];
   __shared__ float s_row[kFoldMaxHeads][4][kTokens];
   __shared__ float p_s[kFoldMaxHeads][kTokens + 1];
   const int pair = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   if (pair >= n_pair) return;
-  const __bf16* src = a_split + (size_t)pair * kTokens * (2 * kDim);
-#pragma unroll 2
-  for (int e = tid; e < kTokens * (kDim / 8); e += 256) {
-    const int j = e / (kDim / 8), q = e % (kDim / 8);
-    const __bf16* r = src + (size_t)j * (2 * kDim) + split_index(8 * q);
-    const bf16x8 hi = *(const bf16x8*)r, lo = *(const bf16x8*)(r + 32);
-    f32x4 v0, v1;
+  // a_j = LayerNorm1(x_j) of this pair's 19 token rows, computed here (the last layer has no LayerNorm launch of its own for
+  // them): a quarter wave per row, 9 16-byte chunks per lane, two-pass statistics as in layernorm_kernel
+  {
+    const int q = tid & 15;
+    const float* xp = x + (size_t)pair * kTokens * kDim;
+    for (int j = tid >> 4; j < kTokens; j += 16) {
+      f32x4 v[9];
+      float sm = 0.f;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { v0[k] = (float)hi[k] + (float)lo[k]; v1[k] = (float)hi[4 + k] + (float)lo[4 + k]; }
-    *(f32x4*)(a_s + j * kDim + 8 * q) = v0;
-    *(f32x4*)(a_s + j * kDim + 8 * q + 4) = v1;
+      for (int i = 0; i < 9; ++i) {
+        v[i] = *(const f32x4*)(xp + (size_t)j * kDim + 4 * (q + 16 * i));
+        sm += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+      }
+      const float mean = row16_sum(sm) * (1.f / kDim);
+      float sq = 0.f;
+#pragma unroll
+      for (int i = 0; i < 9; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float d = v[i][e] - mean; sq += d * d; }
+      const float rstd = 1.f / sqrtf(row16_sum(sq) * (1.f / kDim) + 1e-5f);
+#pragma unroll
+      for (int i = 0; i < 9; ++i) {
+        const int c = 4 * (q + 16 * i);
+        const f32x4 g = *(const f32x4*)(ln_w + c), bb = *(const f32x4*)(ln_b + c);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * g[e] + bb[e];
+        *(f32x4*)(a_s + j * kDim + c) = o;
+      }
+    }
   }
   __syncthreads();
   const float* up = u + (size_t)pair * heads * kDim;
@@ -442,10 +462,11 @@ __global__ __launch_bounds__(256) void cls_fold_attention_kernel(const __bf16* _
 
 int cls_fold_max_heads() { return kFoldMaxHeads; }
 
-hipError_t launch_cls_fold_attention(const __bf16* a_split, const float* u, __bf16* abar, int n_pair, int heads, hipStream_t s) {
+hipError_t launch_cls_fold_attention(const float* x, const float* ln_w, const float* ln_b, const float* u, __bf16* abar, int n_pair, int heads,
+                                     hipStream_t s) {
   if (heads <= 0 || heads > kFoldMaxHeads || kDim % heads != 0 || n_pair <= 0) return hipErrorInvalidValue;
   const float scale = 1.0f / sqrtf((float)(kDim / heads));
-  VETO_LAUNCH(cls_fold_attention_kernel, dim3(n_pair), dim3(256), 0, s, a_split, u, abar, n_pair, heads, scale);
+  VETO_LAUNCH(cls_fold_attention_kernel, dim3(n_pair), dim3(256), 0, s, x, ln_w, ln_b, u, abar, n_pair, heads, scale);
   return hipGetLastError();
 }
 

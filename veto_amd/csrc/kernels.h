@@ -138,10 +138,12 @@ struct AttnArgs {
 };
 hipError_t launch_attention(const AttnArgs& a, hipStream_t s);
 bool attention_reads_tables(int heads);   // whether launch_attention takes the per-object form for this head count
-// Folded CLS-only attention of the last layer: a_split = LN1(x) split rows [n_pair*19, 2*576], u fp32 [n_pair, heads*576]
-// (= a_0 . Mcat), abar split rows [n_pair, 2*heads*576] (probability-weighted token means per head)
+// Folded CLS-only attention of the last layer: x = residual stream [n_pair*19, 576] (LayerNorm1 with ln_w / ln_b is applied
+// inside), u fp32 [n_pair, heads*576] (= LN1(x_0) . Mcat), abar split rows [n_pair, 2*heads*576] (probability-weighted
+// token means per head)
 int cls_fold_max_heads();
-hipError_t launch_cls_fold_attention(const __bf16* a_split, const float* u, __bf16* abar, int n_pair, int heads, hipStream_t s);
+hipError_t launch_cls_fold_attention(const float* x, const float* ln_w, const float* ln_b, const float* u, __bf16* abar, int n_pair, int heads,
+                                     hipStream_t s);
 
 // cls row p at cls + p*ld (ld = 576 for compact CLS rows, 19*576 to read row 0 of every pair of a token matrix)
 hipError_t launch_head(const float* cls, const float* wt, const float* bias, float* out, int n_pair,

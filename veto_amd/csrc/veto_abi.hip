@@ -514,12 +514,15 @@ int veto_forward(veto_handle_t h, void* stream, const veto_inputs_t* in, void* w
         // then out = abar . Ncat^T + b_o + x_0 -- no key / value projection of the 19 tokens
         float* u = (float*)ws.big;
         __bf16* abar = (__bf16*)(ws.big + align_up((size_t)gemm_rows_padded(np) * H * kDim * 4, 256));
-        rc = run_gemm(h, s, "gemm_u_cls", ws.a, h->fold_m, nullptr, nullptr, 0, u, nullptr, (long)H * kDim, np, H * kDim, kDim, EPI_F32,
-                      (long)kTokens * 2 * kDim, 0);
+        {   // LayerNorm1 of the CLS rows (row p*19 of x -> compact split row p): the A operand of the u GEMM
+          ProfScope ps(h, s, "layernorm_cls", 0, (double)np * kDim * 8);
+          HIP_TRY(launch_layernorm(ws.x, (long)kTokens * kDim, w.ln1_w, w.ln1_b, ws.ac, np, s));
+        }
+        rc = run_gemm(h, s, "gemm_u_cls", ws.ac, h->fold_m, nullptr, nullptr, 0, u, nullptr, (long)H * kDim, np, H * kDim, kDim, EPI_F32);
         if (rc) return rc;
         {
           ProfScope ps(h, s, "attention_cls", 4.0 * np * H * kTokens * kDim, (double)M * kDim * 4 + (double)np * H * kDim * 8);
-          HIP_TRY(launch_cls_fold_attention(ws.a, u, abar, np, H, s));
+          HIP_TRY(launch_cls_fold_attention(ws.x, w.ln1_w, w.ln1_b, u, abar, np, H, s));
         }
         rc = run_gemm(h, s, "gemm_out_cls", abar, h->fold_n, w.out_b, ws.x, (long)kTokens * kDim, ws.xc, nullptr, kDim, np, kDim,
                       H * kDim, EPI_RESID);
@@ -572,8 +575,13 @@ int veto_forward(veto_handle_t h, void* stream, const veto_inputs_t* in, void* w
         if (rc) return rc;
         {
           const LayerW& nx = h->layers[l + 1];
-          ProfScope ps(h, s, "layernorm", 0, (double)M * kDim * 8);
-          HIP_TRY(launch_layernorm(ws.x, kDim, nx.ln1_w, nx.ln1_b, ws.a, M, s));
+          static const bool fold_off1 = getenv("VETO_CLS_FOLD") && !strcmp(getenv("VETO_CLS_FOLD"), "0");
+          if (l + 1 == L - 1 && !fold_off1 && H <= cls_fold_max_heads()) {
+            // the folded last layer LayerNorms its token rows itself
+          } else {
+            ProfScope ps(h, s, "layernorm", 0, (double)M * kDim * 8);
+            HIP_TRY(launch_layernorm(ws.x, kDim, nx.ln1_w, nx.ln1_b, ws.a, M, s));
+          }
         }
       } else {
         // Only x[:, 0] of the last layer is consumed (model_veto.py:23): out-proj, FeedForward and
