@@ -330,7 +330,10 @@ __device__ __forceinline__ void rowq_layernorm_store(const RowQ& r, int q, const
 // one quarter wave per token row.  Reads of the per-object tables hit L2 / Infinity Cache (each object
 // row is re-used by 2(N-1) pairs); the writes (x fp32 + LN(x) split) are the HBM stream.
 __global__ __launch_bounds__(256) void assemble_kernel(AssembleArgs a) {
-  const long row = (long)blockIdx.x * 16 + (threadIdx.x >> 4);
+  // Workgroups are dealt round-robin to the 8 XCDs; XCD x takes the x-th contiguous eighth of the token rows, i.e. the pairs of
+  // one or two images, whose per-object rows (2.65 MB per 36-object image) then stay in THAT XCD's 4 MB L2.
+  const long per_xcd = gridDim.x >> 3;
+  const long row = ((long)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3)) * 16 + (threadIdx.x >> 4);
   if (row >= (long)a.n_pair * kTokens) return;
   const int q = threadIdx.x & 15;
   const int p = (int)(row / kTokens), t = (int)(row % kTokens);
@@ -609,7 +612,8 @@ hipError_t launch_enumerate_pairs(int n, int64_t* out, hipStream_t s) {
 }
 
 hipError_t launch_assemble(const AssembleArgs& a, hipStream_t s) {
-  VETO_LAUNCH(assemble_kernel, dim3((unsigned)(((long)a.n_pair * kTokens + 15) / 16)), dim3(256), 0, s, a);
+  const long blocks = ((long)a.n_pair * kTokens + 15) / 16;
+  VETO_LAUNCH(assemble_kernel, dim3((unsigned)((blocks + 7) / 8 * 8)), dim3(256), 0, s, a);
   return hipGetLastError();
 }
 
