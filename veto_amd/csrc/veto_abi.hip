@@ -472,6 +472,8 @@ int veto_forward(veto_handle_t h, void* stream, const veto_inputs_t* in, void* w
   // n_obj*16 object rows instead of the n_pair*19 token rows.  Needs a layer behind it that reads LN1 rows as usual (L >= 2).
   static const bool tables_off = getenv("VETO_QKV0_TABLES") && !strcmp(getenv("VETO_QKV0_TABLES"), "0");   // A/B knob
   const bool qkv0_tables = L >= 2 && !tables_off;
+  static const bool fold_off = getenv("VETO_CLS_FOLD") && !strcmp(getenv("VETO_CLS_FOLD"), "0");           // A/B knob
+  const bool fold_last = !fold_off && H <= cls_fold_max_heads();   // last layer in the folded CLS form (attention.hip)
   if (qkv0_tables) {
     const int R = n_obj * 16;
     HIP_TRY(launch_centre_split(ws.patch_tab, ws.ptab_split, R, s));
@@ -507,8 +509,7 @@ int veto_forward(veto_handle_t h, void* stream, const veto_inputs_t* in, void* w
       const LayerW& w = h->layers[l];
       const bool last = (l == L - 1);
       int rc;
-      static const bool fold_off = getenv("VETO_CLS_FOLD") && !strcmp(getenv("VETO_CLS_FOLD"), "0");   // A/B knob
-      const bool fold = last && !fold_off && H <= cls_fold_max_heads();
+      const bool fold = last && fold_last;
       if (fold) {
         // last layer, folded (attention.hip): u = a_0 . Mcat on the CLS rows, per-pair scores / softmax / weighted token means,
         // then out = abar . Ncat^T + b_o + x_0 -- no key / value projection of the 19 tokens
@@ -575,8 +576,7 @@ int veto_forward(veto_handle_t h, void* stream, const veto_inputs_t* in, void* w
         if (rc) return rc;
         {
           const LayerW& nx = h->layers[l + 1];
-          static const bool fold_off1 = getenv("VETO_CLS_FOLD") && !strcmp(getenv("VETO_CLS_FOLD"), "0");
-          if (l + 1 == L - 1 && !fold_off1 && H <= cls_fold_max_heads()) {
+          if (l + 1 == L - 1 && fold_last) {
             // the folded last layer LayerNorms its token rows itself
           } else {
             ProfScope ps(h, s, "layernorm", 0, (double)M * kDim * 8);
