@@ -548,3 +548,21 @@ def test_restructured_first_and_last_layer_match_the_plain_path(tmp_path):
     g, _, _ = load_golden("predcls_n36_l4h8")
     assert np.abs(outs[0] - outs[1]).max() < 1e-4
     assert np.abs(outs[0] - g["rel_dists"]).max() <= LOGIT_TOL and np.abs(outs[1] - g["rel_dists"]).max() <= LOGIT_TOL
+
+
+def test_oracle_parity_large_feature_scale():
+    """ROI maps 40x larger and shifted (row means far from zero): the per-object form of layer 0 subtracts row means before its
+    GEMMs and must stay as accurate as LayerNorm on the assembled tokens."""
+    from oracle import veto_oracle as vo
+    from veto_amd import synth, testing
+    dev = _dev()
+    sd = synth.predictor_state_dict(5, layers=3)
+    batch = synth.synthetic_batch(13, 2, [8, 5], relu_like=True)
+    for key in ("roi_features", "roi_depth_features"):
+        batch[key] = (batch[key] * 40.0 + 15.0).astype(np.float32)
+    model = testing.make_predictor(testing.make_config(3, 8), sd, dev)
+    out, _ = _run(model, batch, "predcls", dev)
+    ref, _, _ = vo.forward(sd, vo.OracleConfig(layers=3, heads=8), batch)
+    err = (torch.cat(list(out[1])).cpu() - ref).abs().max().item()
+    print("scaled features: logit max-abs-err %.2e (|logit| max %.2f)" % (err, ref.abs().max().item()))
+    assert err <= LOGIT_TOL, err
