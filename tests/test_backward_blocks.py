@@ -1,7 +1,6 @@
 """Backward building blocks of the relation transformer (groundwork) against torch
 autograd in float64 on the CPU -- autograd over these standard ops IS what the reference's backward computes
 (model_veto.py uses nn.LayerNorm, nn.GELU, softmax attention)."""
-import numpy as np
 import pytest
 import torch
 

@@ -2,8 +2,6 @@
 the real reference, (2) the CPU oracle on other seeded inputs, (3) size-independent properties at
 BASELINE.json's full size.  Tolerance: 1e-3 max-abs on fp32 logits (north_star), pair indexing
 bit-exact."""
-import ctypes
-
 import numpy as np
 import pytest
 import torch

@@ -4,7 +4,6 @@ the write-side bandwidth (the 2 x N x 256 x 64 x 4 output bytes are the algorith
 ROIs' footprints of the maps, at most that much again for 8x8 outputs with 2x2 samples)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np
 import torch
 from veto_amd import synth, testing
 from veto_amd.poolers import make_roi_box_feature_extractor

@@ -9,7 +9,7 @@ import os
 # mapped BEFORE libveto_amd.so so that the library's NEEDED libamdhip64.so.7 resolves to that same copy;
 # the other order maps two runtimes into the process and the second one finds no device.
 import torch  # noqa: F401
-from ctypes import (POINTER, Structure, byref, c_char_p, c_double, c_float, c_int, c_int32, c_int64,
+from ctypes import (POINTER, Structure, byref, c_char_p, c_double, c_int, c_int32, c_int64,
                     c_size_t, c_void_p)
 
 _LIB = None

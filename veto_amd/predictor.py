@@ -12,7 +12,6 @@ There is no PyTorch or CPU fallback; if the library is missing, or the inputs ar
 device, forward raises.
 """
 import ctypes
-import math
 import warnings
 
 import torch

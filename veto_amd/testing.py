@@ -3,7 +3,7 @@ synthetic weights and wrap a synthetic batch in BoxLists.  No oracle code lives 
 import numpy as np
 import torch
 
-from . import meet_tables, predictor, synth
+from . import meet_tables, predictor
 from .config import default_config
 from .structures import BoxList
 
