@@ -130,12 +130,12 @@ struct ProfScope {
       if (!h->event_pool.empty()) { *e = h->event_pool.back(); h->event_pool.pop_back(); }
       else if (hipEventCreate(e) != hipSuccess) return;
     }
-    hipEventRecord(r.start, s);
+    (void)hipEventRecord(r.start, s);      // profiling is best effort: a failed record shows up as a missing timing
     h->prof_recs.push_back(r);
     rec = (int)h->prof_recs.size() - 1;
   }
   ~ProfScope() {
-    if (rec >= 0) hipEventRecord(h->prof_recs[rec].stop, s);
+    if (rec >= 0) (void)hipEventRecord(h->prof_recs[rec].stop, s);
   }
 };
 
@@ -343,7 +343,7 @@ int veto_create(const veto_config_t* cfg, veto_handle_t* out) {
   const size_t o_fm = dtake(fold_el * 4), o_fn = dtake(fold_el * 4), o_ft = dtake(fold_el * 4);
   const size_t o_q0w = dtake((size_t)3 * kDim * kDim * 4), o_q0v = dtake((size_t)3 * 3 * kDim * 4);
   e = hipMalloc((void**)&h->derived, doff);
-  if (e != hipSuccess) { hipFree(h->raw); delete h; return fail(VETO_ERR_HIP, "hipMalloc(derived weights): %s", hipGetErrorString(e)); }
+  if (e != hipSuccess) { (void)hipFree(h->raw); delete h; return fail(VETO_ERR_HIP, "hipMalloc(derived weights): %s", hipGetErrorString(e)); }
   h->layers.resize(L);
   for (int l = 0; l < L; ++l) {
     LayerW& w = h->layers[l];
@@ -374,10 +374,11 @@ int veto_create(const veto_config_t* cfg, veto_handle_t* out) {
 
 int veto_destroy(veto_handle_t h) {
   if (!h) return VETO_OK;
-  for (ProfRec& r : h->prof_recs) { hipEventDestroy(r.start); hipEventDestroy(r.stop); }
-  for (hipEvent_t e : h->event_pool) hipEventDestroy(e);
-  hipFree(h->raw);
-  hipFree(h->derived);
+  // teardown: nothing useful can be done with a failure here
+  for (ProfRec& r : h->prof_recs) { (void)hipEventDestroy(r.start); (void)hipEventDestroy(r.stop); }
+  for (hipEvent_t e : h->event_pool) (void)hipEventDestroy(e);
+  (void)hipFree(h->raw);
+  (void)hipFree(h->derived);
   delete h;
   return VETO_OK;
 }
