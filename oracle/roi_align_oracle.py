@@ -12,6 +12,8 @@ pysgg/modeling/poolers.py imports torchvision, which is absent.  What pins this 
   * analytic known answers in tests/test_roi_align.py: on an affine feature map f(y, x) = a*y + b*x + c
     bilinear sampling is exact, so every interior bin must equal f at the bin centre; constant maps,
     hand-computed border / out-of-map samples, and the FPN level boundaries of the LevelMapper formula;
+  * the one published known-answer vector of this kernel lineage (maskrcnn-benchmark's legacy ROIAlign, kept by detectron2 as
+    `aligned=False` and pinned there as `old_results`: arange(25) as 5 x 5, box (1, 1, 3, 3), 4 x 4 bins), reproduced exactly;
   * the backward restatement is checked to be the exact adjoint of the forward (ROIAlign is linear in the map).
 
 All arithmetic is float32 in the reference's operation order (numpy does not fuse multiply-adds),

@@ -46,6 +46,29 @@ def test_affine_map_interior_bins_equal_the_map_at_the_bin_centre():
         assert np.abs(out[r] - want).max() < 1e-4, r
 
 
+# The one published known-answer vector for the LEGACY ("aligned=False") ROIAlign that this lineage of kernels shares
+# (maskrcnn-benchmark's ROIAlign_cuda.cu -> pysgg/csrc; detectron2 keeps it as `aligned=False` and pins it in
+# tests/layers/test_roi_align.py::test_roialign as `old_results`): image arange(25) as 5 x 5, box (1, 1, 3, 3), scale 1, 4 x 4 bins.
+LEGACY_KAT = np.array([[7.5, 8.0, 8.5, 9.0], [10.0, 10.5, 11.0, 11.5], [12.5, 13.0, 13.5, 14.0], [15.0, 15.5, 16.0, 16.5]], dtype=F)
+
+
+def test_oracle_reproduces_the_published_legacy_known_answer():
+    feat = np.arange(25, dtype=F).reshape(1, 1, 5, 5)
+    rois = np.array([[0, 1, 1, 3, 3]], dtype=F)
+    for ratio in (1, 2):      # the vector holds for every sampling ratio: the image is affine
+        assert np.array_equal(ro.roi_align(feat, rois, 1.0, pooled=4, sampling_ratio=ratio)[0, 0], LEGACY_KAT), ratio
+
+
+@pytest.mark.gpu
+def test_hip_roi_align_reproduces_the_published_legacy_known_answer():
+    from veto_amd.poolers import ROIAlign
+    dev = torch.device("cuda:0")
+    feat = torch.arange(25, dtype=torch.float32).reshape(1, 1, 5, 5).to(dev)
+    rois = torch.tensor([[0, 1, 1, 3, 3]], dtype=torch.float32, device=dev)
+    got = ROIAlign((4, 4), 1.0, 2)(feat, rois).cpu().numpy()[0, 0]
+    assert np.array_equal(got, LEGACY_KAT)
+
+
 def test_constant_map_and_malformed_roi():
     feat = np.full((1, 3, 10, 12), 7.5, dtype=F)
     rois = np.array([[0, 4, 4, 30, 20], [0, 20, 20, 10, 10], [0, 5, 5, 5, 5]], dtype=F)  # 2nd/3rd: x2<x1, zero size -> 1x1
