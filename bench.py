@@ -182,7 +182,8 @@ def main():
             "mfma_issued": {"kernel": dom, "passes_per_flop": passes, "issued_tflops": achieved * passes,
                             "frac_of_bf16_peak": achieved * passes / PEAK_BF16_TFLOPS,
                             "note": "matrix-pipe rate actually issued by the dominant GEMM; SQ_VALU_MFMA_BUSY_CYCLES from the PMC pass "
-                                    "is in profiles/ (busy fraction of kernel cycles)"},
+                                    "is in profiles/ (busy fraction of kernel cycles); the vendor bf16 GEMM (hipBLASLt) given the same "
+                                    "issued flops at this shape reaches 1.12 PFLOP/s on the same part (tools/vendor_gemm_probe.py, DESIGN.md section 7)"},
             "whole_path": {"ref_flops_per_pair": f_ref, "tflops_ref_equivalent": value * f_ref / 1e12,
                            "frac_of_bf16_peak": value * f_ref / 1e12 / PEAK_BF16_TFLOPS / world},
             "kernels_ms_per_step": {k: round(v["ms_per_step"], 4) for k, v in sorted(kern.items(), key=lambda kv: -kv[1]["ms_per_step"])},
