@@ -4,6 +4,11 @@
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+`python bench.py --gpus N` with N > 1 and no torch.distributed environment launches the N ranks itself
+(a child `python -m torch.distributed.run`, started BEFORE the parent touches a GPU; the parent only relays
+rank 0's JSON line and the exit code).  The line carries `ranks_seen` (the RCCL world size) and every
+rank's device ordinal.
+
 One step = one eval forward of the predictor (through the C ABI) over one resident synthetic batch:
 BASELINE.json configs[1] -- 12 images x 36 objects = 15120 ordered pairs, d=576 tokens, 8 heads,
 4 layers, 51 predicates.  Weak scaling: every rank processes its own 12-image batch; for N > 1 each
@@ -13,6 +18,8 @@ Prints ONE JSON line on rank 0.
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -24,6 +31,11 @@ import torch  # noqa: E402
 
 PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
 PEAK_HBM_GBS = 8000.0
+# precision modes of the library (include/veto_amd.h): what the Linears compute in, and how many bf16-rate MFMA
+# passes one algorithmic FLOP costs in each
+DTYPE_OF = {"precise": "bf16x3 (split-bf16 MFMA, fp32 accumulate)", "fast": "bf16"}
+MFMA_PASSES = {"precise": 3.0, "fast": 1.0}
+DEFAULT_PRECISION = "precise"
 
 
 def flops_per_pair(layers, heads):
@@ -38,63 +50,113 @@ def flops_per_pair(layers, heads):
     return patch + loc + cls + layers * (qkv + att + out + mlp) + head
 
 
+def self_launch(args):
+    """--gpus N > 1 outside torch.distributed.run: start the N ranks as a child process group and relay.
+    Nothing here initialises a GPU (torch.cuda.device_count() does not, on this image), so the parent
+    never has to exec or fork a process that holds one."""
+    dry = os.environ.get("VETO_BENCH_DRYRUN") == "1"
+    have = torch.cuda.device_count()
+    if not dry and have < args.gpus:
+        print("bench.py --gpus %d: this node exposes %d GPU(s); nothing was run" % (args.gpus, have), file=sys.stderr)
+        return 2
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    lines = [ln for ln in proc.stdout.splitlines() if ln.strip()]
+    result = [ln for ln in lines if ln.startswith('{"metric"')]
+    for ln in lines:
+        if ln not in result:
+            print(ln, file=sys.stderr)
+    if proc.returncode != 0 or not result:
+        print("bench.py: the %d-rank child exited with code %d%s" % (args.gpus, proc.returncode, "" if result else " and printed no result line"),
+              file=sys.stderr)
+        return proc.returncode or 1
+    print(result[-1], flush=True)
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--images", type=int, default=12)
     ap.add_argument("--objs", type=int, default=36)
     ap.add_argument("--layers", type=int, default=4)
     ap.add_argument("--heads", type=int, default=8)
-    ap.add_argument("--precision", default="precise", choices=["precise", "fast"])
+    ap.add_argument("--precision", default=DEFAULT_PRECISION, choices=sorted(DTYPE_OF))
     ap.add_argument("--chunk", type=int, default=0, help="VETO_AMD.MAX_CHUNK_PAIRS (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the extra L6/H6 and other-precision lines (N = 1 only)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
-    assert torch.cuda.is_available(), "bench.py needs an MI355X"
-    dev = torch.device("cuda", local_rank)
-    torch.cuda.set_device(dev)
+    if args.gpus != world and not (args.gpus == 1 and world == 1):
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with --nproc-per-node %d" % (args.gpus, world, args.gpus))
+    dry = os.environ.get("VETO_BENCH_DRYRUN") == "1"   # CPU test of the launch / rendezvous / gather plumbing: gloo, no model
+    if not dry:
+        assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    dev = torch.device("cpu") if dry else torch.device("cuda", local_rank)
+    if not dry:
+        torch.cuda.set_device(dev)
     dist = None
     force_dist = os.environ.get("VETO_BENCH_FORCE_DIST") == "1"  # exercise the RCCL path with one rank (testing)
     if world > 1 or force_dist:
         import torch.distributed as dist
         if force_dist and "RANK" not in os.environ:
             os.environ.update(RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
-        dist.init_process_group("nccl", device_id=dev)
+        if dry:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     from veto_amd import distributed as vdist
-    from veto_amd import synth, testing
-    from veto_amd.pairs import prepare_test_pairs
 
-    sd = synth.predictor_state_dict(0, layers=args.layers)
-    model = testing.make_predictor(testing.make_config(args.layers, args.heads, precision=args.precision,
-                                                       max_chunk_pairs=args.chunk), sd, dev)
-    batch = synth.synthetic_batch(7 + rank, args.images, args.objs)
-    props = testing.make_proposals(batch, "predcls", dev)
-    pairs = prepare_test_pairs(dev, props)
-    rgb = torch.from_numpy(batch["roi_features"]).to(dev)
-    dep = torch.from_numpy(batch["roi_depth_features"]).to(dev)
-    n_pairs = sum(int(p.shape[0]) for p in pairs)
+    if dry:
+        n_pairs = args.images * args.objs * (args.objs - 1)
+        fake = torch.full((n_pairs, 51), float(rank))
 
-    def step():
-        with torch.no_grad():
-            out = model(props, pairs, None, None, roi_features=rgb, roi_depth_features=dep)
-        logits = torch.cat(list(out[1]), 0) if dist is not None else out[1]
-        if dist is not None:
-            logits = vdist.all_gather_logits(logits, equal_counts=True, force=force_dist)
-        return logits
+        def step():
+            return vdist.all_gather_logits(fake, equal_counts=True, force=force_dist) if dist is not None else fake
 
-    def fence():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
+        def fence():
+            if dist is not None:
+                dist.barrier()
+    else:
+        from veto_amd import synth, testing
+        from veto_amd.pairs import prepare_test_pairs
+        sd = synth.predictor_state_dict(0, layers=args.layers)
+        model = testing.make_predictor(testing.make_config(args.layers, args.heads, precision=args.precision,
+                                                           max_chunk_pairs=args.chunk), sd, dev)
+        batch = synth.synthetic_batch(7 + rank, args.images, args.objs)
+        props = testing.make_proposals(batch, "predcls", dev)
+        pairs = prepare_test_pairs(dev, props)
+        rgb = torch.from_numpy(batch["roi_features"]).to(dev)
+        dep = torch.from_numpy(batch["roi_depth_features"]).to(dev)
+        n_pairs = sum(int(p.shape[0]) for p in pairs)
+
+        def step():
+            with torch.no_grad():
+                out = model(props, pairs, None, None, roi_features=rgb, roi_depth_features=dep)
+            logits = torch.cat(list(out[1]), 0) if dist is not None else out[1]
+            if dist is not None:
+                logits = vdist.all_gather_logits(logits, equal_counts=True, force=force_dist)
+            return logits
+
+        def fence():
+            if dist is not None:
+                dist.barrier()
+            torch.cuda.synchronize(dev)
 
     for _ in range(args.warmup):
         step()
@@ -104,10 +166,29 @@ def main():
         last = step()
     fence()
     elapsed = time.perf_counter() - t0
+    ranks_seen, devices = 1, [0 if dry else torch.cuda.current_device()]
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        ranks_seen = dist.get_world_size()
+        d = torch.tensor([-1 if dry else torch.cuda.current_device()], dtype=torch.int64, device=dev)
+        alld = torch.empty(ranks_seen, dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(alld, d)
+        devices = [int(x) for x in alld.tolist()]
+        gathered_rows = int(last.shape[0])
+        assert gathered_rows == n_pairs * ranks_seen, (gathered_rows, n_pairs, ranks_seen)
+
+    if dry:
+        if rank == 0:
+            print(json.dumps({"metric": "DRY RUN of the launch path (gloo, CPU, no model): not a measurement", "value": 0.0,
+                              "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                              "ms_per_step": elapsed / args.steps * 1e3, "ranks_seen": ranks_seen, "devices": devices,
+                              "gathered_rows": int(last.shape[0]), "dry_run": True}), flush=True)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     # ---- per-kernel device time (hipEvents on the launch stream, inside the library) -------------
     eng = model._engine
@@ -131,40 +212,43 @@ def main():
                         if v["flops_per_launch"] else None)
                 for k, v in prof.items()}
         gemms = {k: v for k, v in kern.items() if k.startswith("gemm_")}
-        # the dominant kernel = the GEMM launch with the longest duration (the QKV projection of a full layer; the same
-        # gemm_split_ps_kernel runs every Linear, `gemm_all` below is the rate over all of its launches in a step)
+        # the dominant kernel = the GEMM launch with the longest duration (the QKV projection of a full layer; ONE kernel
+        # template runs every Linear, `gemm_all` below is the rate over all of its launches in a step)
         dom = max(gemms, key=lambda k: gemms[k]["avg_ms"])
         achieved = gemms[dom]["tflops"]
         gemm_ms = sum(v["ms_per_step"] for v in gemms.values())
         gemm_flops = sum(prof[k]["flops_per_launch"] * kern[k]["launches_per_step"] for k in gemms)
+        # FLOPs the step actually executes (algorithmic 2*M*N*K of every launch, attention contractions included)
+        exec_flops = sum(prof[k]["flops_per_launch"] * kern[k]["launches_per_step"] for k in kern if prof[k]["flops_per_launch"])
         f_ref = flops_per_pair(args.layers, args.heads)
-        passes = 3 if args.precision == "precise" else 1
+        passes = MFMA_PASSES[args.precision]
         hbm_gbps = {k: round(prof[k]["bytes_per_launch"] / (kern[k]["avg_ms"] * 1e-3) / 1e9, 1)
                     for k in ("attention", "attention_cls", "layernorm") if k in prof and prof[k]["bytes_per_launch"]}
         gather_bytes = prof["assemble_tokens"]["bytes_per_launch"]      # bytes the kernel writes, as the library accounts them
         gather_gbps = gather_bytes / (kern["assemble_tokens"]["avg_ms"] * 1e-3) / 1e9
-        traffic = None
-        try:  # PMC-derived HBM bytes per launch of the dominant kernel at THIS workload (profiles/r01_traffic.json)
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
-            if dom in tj and (args.images, args.objs, args.layers, args.heads, args.precision) == (12, 36, 4, 8, "precise"):
-                traffic = tj[dom]["hbm_bytes_per_launch"]
+        traffic, attention_pmc = None, None
+        try:  # PMC-derived numbers for THIS workload, written by tools/pmc_traffic.py from the profile tag named inside
+            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+            if tj.get("workload") == [args.images, args.objs, args.layers, args.heads, args.precision]:
+                traffic = tj["kernels"].get(dom, {}).get("hbm_bytes_per_launch")
+                attention_pmc = tj.get("attention")
         except (OSError, ValueError, KeyError):
             pass
         res = {
             "metric": "relation-pairs/sec (PredCls, 36 obj/img)", "value": value, "unit": "pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16x3 (split-bf16 MFMA, fp32 accumulate)" if args.precision == "precise" else "bf16",
-            "data": "synthetic",
+            "dtype": DTYPE_OF[args.precision], "data": "synthetic",
             "config": {"workload": "BASELINE.json configs[1]: synthetic PredCls, %d img x %d obj = %d pairs/GPU, d=576, "
                                    "%d heads, %d layers, 51 predicates" % (args.images, args.objs, n_pairs, args.heads, args.layers),
                        "images_per_gpu": args.images, "objects_per_image": args.objs, "pairs_per_gpu": n_pairs,
                        "layers": args.layers, "heads": args.heads, "precision": args.precision,
                        "parallelism": "image-sharded x%d, RCCL all-gather of logits" % world if world > 1 else "single GPU"},
+            "ranks_seen": ranks_seen, "devices": devices,
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": PEAK_BF16_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic,
-                         "note": "achieved = algorithmic 2*M*N*K of one launch / its mean hipEvent duration; the "
-                                 "precise mode issues 3 bf16 MFMA passes per algorithmic FLOP"},
+                         "note": "achieved = algorithmic 2*M*N*K of one launch / its mean hipEvent duration; this precision mode "
+                                 "issues %.4g bf16-equivalent MFMA passes per algorithmic FLOP" % passes},
             # north_star: "HBM GB/s on the gather and MFMA utilisation on the attention GEMMs"
             "gather": {"bound": "hbm", "kernel": "assemble_tokens", "achieved": gather_gbps, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                        "frac": gather_gbps / PEAK_HBM_GBS,
@@ -172,26 +256,30 @@ def main():
                        "gathered_bytes": float(n_pairs) * 18 * 2 * 576 * 4,
                        "moved_gbps": (gather_bytes + float(n_pairs) * 18 * 2 * 576 * 4) / (kern["assemble_tokens"]["avg_ms"] * 1e-3) / 1e9,
                        "note": "pair gather + token assembly: bytes = what the kernel writes (the [pairs, 19, 576] fp32 token rows plus, "
-                               "with layer 0 in the per-object form, the row statistics and the split rows of two of the 19 tokens; "
-                               "otherwise plus the LayerNorm'ed split copy of every row); the per-object rows it gathers (gathered_bytes; moved_gbps counts them too) come from L2 / Infinity Cache. "
-                               "Pure write streams top out near 3.5 TB/s on this part (DESIGN.md section 7)"},
-            "gemm_all": {"kernel": "gemm_split_ps_kernel, all launches of a step", "ms_per_step": round(gemm_ms, 4),
+                               "with layer 0 in the per-object form, the row statistics and the split rows of two of the 19 tokens); "
+                               "the per-object rows it gathers (gathered_bytes; moved_gbps counts them too) come from L2 / Infinity Cache"},
+            "attention": attention_pmc,
+            "gemm_all": {"kernel": "all GEMM launches of a step", "ms_per_step": round(gemm_ms, 4),
                          "achieved": gemm_flops / (gemm_ms * 1e-3) / 1e12, "unit": "TFLOP/s",
                          "frac": gemm_flops / (gemm_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS},
             "hbm_kernels_gbps": hbm_gbps,
             "mfma_issued": {"kernel": dom, "passes_per_flop": passes, "issued_tflops": achieved * passes,
                             "frac_of_bf16_peak": achieved * passes / PEAK_BF16_TFLOPS,
-                            "note": "matrix-pipe rate actually issued by the dominant GEMM; SQ_VALU_MFMA_BUSY_CYCLES from the PMC pass "
-                                    "is in profiles/ (busy fraction of kernel cycles); the vendor bf16 GEMM (hipBLASLt) given the same "
-                                    "issued flops at this shape reaches 1.12 PFLOP/s on the same part (tools/vendor_gemm_probe.py, DESIGN.md section 7)"},
-            "whole_path": {"ref_flops_per_pair": f_ref, "tflops_ref_equivalent": value * f_ref / 1e12,
-                           "frac_of_bf16_peak": value * f_ref / 1e12 / PEAK_BF16_TFLOPS / world},
+                            "note": "matrix-pipe work actually issued by the dominant GEMM, in bf16-rate units (an e4m3 K=128 MFMA "
+                                    "counts half of its FLOPs: it runs at twice the bf16 rate)"},
+            "whole_path": {"executed_flops_per_pair": exec_flops / n_pairs, "tflops_executed": value * exec_flops / n_pairs / 1e12,
+                           "frac_of_bf16_peak": value * exec_flops / n_pairs / 1e12 / PEAK_BF16_TFLOPS / world,
+                           "ref_flops_per_pair": f_ref, "tflops_ref_equivalent": value * f_ref / 1e12,
+                           "note": "frac uses the FLOPs the restructured path executes (SURVEY.md 8d); the reference-equivalent "
+                                   "figure (what the unrestructured formulation would need for the same pairs) is the labelled extra"},
             "kernels_ms_per_step": {k: round(v["ms_per_step"], 4) for k, v in sorted(kern.items(), key=lambda kv: -kv[1]["ms_per_step"])},
             "gemm_tflops": {k: round(v["tflops"], 1) for k, v in gemms.items()},
         }
         if world == 1 and not args.no_cpu_baseline:
             gl = list(last.split([int(p.shape[0]) for p in pairs])) if torch.is_tensor(last) else last
             res["cpu_baseline"], res["logit_max_abs_err"] = cpu_baseline(sd, args, batch, gl, pairs)
+        if world == 1 and not args.no_extra:
+            res["extra"] = extra_lines(args, dev, batch, sd)
         # RCCL writes its version banner through C stdio, which (when stdout is a file or pipe) only
         # drains at exit, i.e. AFTER a Python print: drain it first so that the JSON is the last line.
         import ctypes
@@ -201,6 +289,57 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def extra_lines(args, dev, batch, sd):
+    """Context next to the headline, N = 1 only, short runs: (1) the architecture the reference ships
+    (configs/VETO_final.yaml: 6 layers x 6 heads) on the same 12 x 36 batch; (2) the other precision modes on the
+    headline workload with their logit error against the headline mode's CPU-checked logits."""
+    from oracle import veto_oracle as vo
+    from veto_amd import synth, testing
+    from veto_amd.pairs import prepare_test_pairs
+    out = {}
+    props = testing.make_proposals(batch, "predcls", dev)
+    pairs = prepare_test_pairs(dev, props)
+    rgb = torch.from_numpy(batch["roi_features"]).to(dev)
+    dep = torch.from_numpy(batch["roi_depth_features"]).to(dev)
+    n_pairs = sum(int(p.shape[0]) for p in pairs)
+
+    def timed(model, steps=20):
+        with torch.no_grad():
+            for _ in range(3):
+                o = model(props, pairs, None, None, roi_features=rgb, roi_depth_features=dep)
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                o = model(props, pairs, None, None, roi_features=rgb, roi_depth_features=dep)
+            torch.cuda.synchronize(dev)
+        dt = (time.perf_counter() - t0) / steps
+        return dt, torch.cat(list(o[1]), 0).cpu()
+
+    # one image of the batch through the CPU oracle = the error yardstick of every line below
+    n = args.objs
+    img0 = {"num_objs": [n], "boxes": batch["boxes"][:n], "labels": batch["labels"][:n],
+            "roi_features": batch["roi_features"][:n], "roi_depth_features": batch["roi_depth_features"][:n]}
+    ppi = n * (n - 1)
+    sd6 = synth.predictor_state_dict(0, layers=6)
+    m6 = testing.make_predictor(testing.make_config(6, 6, precision=args.precision), sd6, dev)
+    dt, lg = timed(m6)
+    ref6, _, _ = vo.forward(sd6, vo.OracleConfig(layers=6, heads=6), img0)
+    out["l6h6"] = {"workload": "the reference's shipped architecture (6 layers x 6 heads) on the same 12 x %d batch" % n,
+                   "pairs_per_s": n_pairs / dt, "ms_per_step": dt * 1e3, "precision": args.precision,
+                   "logit_max_abs_err_image0": float((lg[:ppi] - ref6).abs().max())}
+    del m6
+    ref, _, _ = vo.forward(sd, vo.OracleConfig(layers=args.layers, heads=args.heads), img0)
+    for prec in sorted(DTYPE_OF):
+        if prec == args.precision:
+            continue
+        m = testing.make_predictor(testing.make_config(args.layers, args.heads, precision=prec), sd, dev)
+        dt, lg = timed(m)
+        out["precision_" + prec] = {"dtype": DTYPE_OF[prec], "pairs_per_s": n_pairs / dt, "ms_per_step": dt * 1e3,
+                                    "logit_max_abs_err_image0": float((lg[:ppi] - ref).abs().max())}
+        del m
+    return out
 
 
 def usable_cores():

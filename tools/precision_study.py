@@ -1,0 +1,112 @@
+"""CPU emulation of candidate GEMM operand schemes for the transformer Linears (test tooling).
+
+Runs the fp32 oracle with the four Linears of every encoder layer replaced by an emulation of a
+split-operand MFMA scheme and reports the logit max-abs-error against the reference goldens.
+Schemes:
+  bf16x3   : hi/lo bf16, A_hi W_hi + A_lo W_hi + A_hi W_lo                       (round-1 product path)
+  f16x3    : the same with fp16 planes
+  f16+e4m3 : fp16 main product, both cross terms with e4m3 operands (fixed power-of-two scales)
+  f16+e2m3 : fp16 main product, cross terms in fp6 e2m3 with a power-of-two scale per 32 k's
+  f16      : single fp16 pass        bf16 : single bf16 pass
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, "tests"))
+from oracle import veto_oracle as vo  # noqa: E402
+from conftest import load_golden  # noqa: E402
+
+
+def q_e4m3(x, scale):
+    y = (x * scale).clamp(-448.0, 448.0)
+    return y.to(torch.float8_e4m3fn).float() / scale
+
+
+def q_e2m3_block(x, block=32):
+    """fp6 e2m3 (max 7.5, steps 0.125 below 2, 0.25 to 4, 0.5 to 7.5) with an E8M0 scale per `block` k's."""
+    shp = x.shape
+    xb = x.reshape(*shp[:-1], shp[-1] // block, block)
+    amax = xb.abs().amax(-1, keepdim=True).clamp_min(1e-30)
+    e = torch.ceil(torch.log2(amax / 7.5))
+    s = torch.exp2(e)
+    y = xb / s
+    a = y.abs()
+    step = torch.where(a < 2, 0.125, torch.where(a < 4, 0.25, 0.5))
+    q = (torch.round(a / step) * step).clamp(max=7.5) * torch.sign(y)
+    return (q * s).reshape(shp)
+
+
+def make_mm(scheme):
+    def split(x, dt):
+        hi = x.to(dt).float()
+        return hi, x - hi
+
+    def mm(a, w):  # a [M, K], w [N, K]
+        if scheme == "fp32":
+            return a @ w.t()
+        if scheme in ("bf16", "f16"):
+            dt = torch.bfloat16 if scheme == "bf16" else torch.float16
+            return a.to(dt).float() @ w.to(dt).float().t()
+        if scheme in ("bf16x3", "f16x3"):
+            dt = torch.bfloat16 if scheme == "bf16x3" else torch.float16
+            ah, al = split(a, dt)
+            wh, wl = split(w, dt)
+            al, wl = al.to(dt).float(), wl.to(dt).float()
+            return ah @ wh.t() + al @ wh.t() + ah @ wl.t()
+        ah, al = split(a, torch.float16)
+        wh, wl = split(w, torch.float16)
+        main = ah @ wh.t()
+        if scheme == "f16+e4m3":
+            sa_h, sw_h = 16.0, 1024.0
+            sa_l, sw_l = 2.0 ** 15, 2.0 ** 21
+            cross = q_e4m3(al, sa_l) @ q_e4m3(wh, sw_h).t() + q_e4m3(ah, sa_h) @ q_e4m3(wl, sw_l).t()
+        elif scheme == "f16+e2m3":
+            cross = q_e2m3_block(al) @ q_e2m3_block(wh).t() + q_e2m3_block(ah) @ q_e2m3_block(wl).t()
+        elif scheme == "f16+e4m3/1":   # only the activation correction (weights single fp16)
+            cross = q_e4m3(al, 2.0 ** 15) @ q_e4m3(wh, 1024.0).t()
+        else:
+            raise ValueError(scheme)
+        return main + cross
+    return mm
+
+
+def run(name, scheme):
+    g, sd, batch = load_golden(name)
+    cfg = vo.OracleConfig(layers=g["_layers"], heads=g["_heads"])
+    mm = make_mm(scheme)
+    orig = vo.encoder_layer
+
+    def enc(sd_, cfg_, x, l, dtype):
+        t = cfg_.prefix + "fusion_transformer.transformer.layers.%d." % l
+        H = cfg_.heads
+        b, n, D = x.shape
+        dh = D // H
+        T = lambda k: vo._t(sd_[t + k], dtype)
+        y = vo.layer_norm(x, T("0.norm.weight"), T("0.norm.bias"))
+        qkv = mm(y.reshape(-1, D), T("0.fn.to_qkv.weight")).reshape(b, n, 3 * D)
+        q, k, v = [z.reshape(b, n, H, dh).permute(0, 2, 1, 3) for z in qkv.chunk(3, dim=-1)]
+        attn = torch.softmax((q @ k.transpose(-1, -2)) * (dh ** -0.5), dim=-1)
+        out = (attn @ v).permute(0, 2, 1, 3).reshape(b * n, D)
+        x = (mm(out, T("0.fn.to_out.0.weight")) + T("0.fn.to_out.0.bias")).reshape(b, n, D) + x
+        y = vo.layer_norm(x, T("1.norm.weight"), T("1.norm.bias"))
+        h = vo.gelu_erf(mm(y.reshape(-1, D), T("1.fn.net.0.weight")) + T("1.fn.net.0.bias"))
+        y = mm(h, T("1.fn.net.3.weight")) + T("1.fn.net.3.bias")
+        return y.reshape(b, n, D) + x
+
+    vo.encoder_layer = enc
+    try:
+        logits, _, _ = vo.forward(sd, cfg, batch)
+    finally:
+        vo.encoder_layer = orig
+    return float(np.abs(logits.numpy() - g["rel_dists"]).max())
+
+
+if __name__ == "__main__":
+    names = sys.argv[1:] or ["predcls_n10_l4h8", "predcls_n36_l4h8", "predcls_n36_l6h6"]
+    for scheme in ["fp32", "bf16x3", "f16x3", "f16+e4m3", "f16+e2m3", "f16+e4m3/1", "f16", "bf16"]:
+        print("%-12s" % scheme, "  ".join("%s %.2e" % (n, run(n, scheme)) for n in names), flush=True)
