@@ -296,6 +296,12 @@ __global__ __launch_bounds__(128) void attention_mfma_kernel(AttnArgs a) {
     const int i = e / CH, c = e % CH;
     const f32x4 v0 = *(const f32x4*)(o_lds + i * DH + c * 8);
     const f32x4 v1 = *(const f32x4*)(o_lds + i * DH + c * 8 + 4);
+    const size_t row = a.cls_only ? (size_t)pair : (size_t)pair * kTokens + i;
+    if (a.o_fmt == FMT_MIXED) {   // wave-uniform
+      store_act4<FMT_MIXED>(a.o + row * (2 * kDim), head * DH + c * 8, v0);
+      store_act4<FMT_MIXED>(a.o + row * (2 * kDim), head * DH + c * 8 + 4, v1);
+      continue;
+    }
     bf16x8 hi, lo;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -307,7 +313,6 @@ __global__ __launch_bounds__(128) void attention_mfma_kernel(AttnArgs a) {
       hi[4 + t] = hh;
       lo[4 + t] = ll;
     }
-    const size_t row = a.cls_only ? (size_t)pair : (size_t)pair * kTokens + i;
     __bf16* dst = a.o + row * (2 * kDim) + split_index(head * DH + c * 8);
     *(bf16x8*)dst = hi;
     *(bf16x8*)(dst + 32) = lo;

@@ -38,6 +38,71 @@ __device__ __forceinline__ void split_bf16(float x, __bf16& hi, __bf16& lo) {
   lo = (__bf16)(x - (float)hi);
 }
 
+// ------------------------------------------------------------------------------------------------
+// "Mixed row" operand format (precision mode VETO_MIXED): fp16 main product + e4m3 correction terms.
+//
+// x = h + l with h = fp16(x): 11 significand bits in h, the residual l is 2^-11 |x| or smaller.  For a product
+// sum_k a_k w_k the main term sum ah wh runs on v_mfma_f32_16x16x32_f16, and the two first-order corrections
+// sum (al wh + ah wl) are 2^-11 of it, so 4 significand bits of each factor are enough for a 2^-16 result: they run as
+// ONE v_mfma_scale_f32_16x16x128_f8f6f4 with e4m3 operands (128 = 64 k's x the two corrections), which issues at twice
+// the bf16 rate.  Matrix-pipe time per 64 k's and output block: 64 cycles against 96 for the 3-term split-bf16 product
+// (profiles/r02_mfma_mix_probe.txt); measured logit error 5-7e-5 against 2-3e-5 (tools/precision_study.py).
+//
+// A logical row of K fp32 values (K % 64 == 0) is 4K bytes, in blocks of 64 k's = 256 B:
+//   [ h: 64 x fp16 (128 B) | X: 64 x e4m3 (64 B) | Y: 64 x e4m3 (64 B) ]
+//   activation rows: X = e4m3(2^15 (a - h)),  Y = e4m3(2^4 a)
+//   weight rows:     X = e4m3(2^e h),         Y = e4m3(2^(e+11) (w - h)),   e per tensor (kept on the device)
+// so that sum X_a X_w + Y_a Y_w = 2^(15+e) (al wh + ah wl); the MFMA's E8M0 scale operand undoes the 2^(15+e).
+// e4m3 conversions do NOT saturate on gfx950 (480 -> NaN, profiles/r02_mfma_mix_probe.txt): values are clamped to +-448.
+// One GEMM stage (128 B of a row) is either the h part or the X|Y part of a block: same addressing as the split rows.
+enum OperandFmt { FMT_SPLIT = 0, FMT_MIXED = 1 };
+constexpr int kMixActExp = 15;        // activation residual scale 2^15, activation value scale 2^4
+constexpr int kMixActHiExp = 4;
+constexpr int kMixWLoShift = kMixActExp - kMixActHiExp;   // weight residual scale = weight value scale x 2^11
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+
+__device__ __forceinline__ float clamp448(float x) { return __builtin_amdgcn_fmed3f(x, -448.f, 448.f); }
+__device__ __forceinline__ uint32_t pack_e4m3x4(float a, float b, float c, float d) {
+  int r = __builtin_amdgcn_cvt_pk_fp8_f32(clamp448(a), clamp448(b), 0, false);
+  r = __builtin_amdgcn_cvt_pk_fp8_f32(clamp448(c), clamp448(d), r, true);
+  return (uint32_t)r;
+}
+// byte offset of column k's fp16 inside a mixed row; its X byte is at mixed_x_offset(k), its Y byte 64 further
+__host__ __device__ __forceinline__ int mixed_h_offset(int k) { return ((k >> 6) << 8) + ((k & 63) << 1); }
+__host__ __device__ __forceinline__ int mixed_x_offset(int k) { return ((k >> 6) << 8) + 128 + (k & 63); }
+
+// 4 consecutive columns (col % 4 == 0) of an ACTIVATION row in either operand format; `row` = first byte of the row
+template <int FMT>
+__device__ __forceinline__ void store_act4(__bf16* row, int col, f32x4 v) {
+  if constexpr (FMT == FMT_SPLIT) {
+    bf16x4 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      __bf16 h, l;
+      split_bf16(v[e], h, l);
+      hi[e] = h;
+      lo[e] = l;
+    }
+    __bf16* d = row + split_index(col);
+    *(bf16x4*)d = hi;
+    *(bf16x4*)(d + 32) = lo;
+  } else {
+    char* base = (char*)row;
+    f16x4 h;
+    float l[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      h[e] = (_Float16)v[e];
+      l[e] = (v[e] - (float)h[e]) * (float)(1 << kMixActExp);
+    }
+    *(f16x4*)(base + mixed_h_offset(col)) = h;
+    char* x = base + mixed_x_offset(col);
+    *(uint32_t*)x = pack_e4m3x4(l[0], l[1], l[2], l[3]);
+    constexpr float ys = (float)(1 << kMixActHiExp);
+    *(uint32_t*)(x + 64) = pack_e4m3x4(v[0] * ys, v[1] * ys, v[2] * ys, v[3] * ys);
+  }
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -23,6 +23,11 @@
 // tile ((i*8 + b%8)*32 + b/8): the 32 workgroups of an XCD work on 32 consecutive tiles (N fastest),
 // i.e. on ~3.5 activation panels x all weight panels, which is what their shared L2 then holds.
 //
+// NTERMS == 2 is the VETO_MIXED instantiation (operands in the mixed-row format of common.h): the stages of a tile alternate
+// between the fp16 part of a 64-k block (two v_mfma_f32_16x16x32_f16 per output block) and its e4m3 part (one
+// v_mfma_scale_f32_16x16x128_f8f6f4 whose E8M0 scale undoes the operands' power-of-two scaling).  Loaders, LDS image,
+// fragment reads and barriers are the same: a stage is 128 bytes of every row in either format.
+//
 // -DVETO_GEMM_STAMPS builds a diagnostic copy that accumulates s_memtime deltas per phase (barrier
 // wait / MFMA phase / epilogue; loader: vmcnt wait / barrier / issue) and prints their means.
 #include "common.h"
@@ -76,6 +81,11 @@ __device__ __forceinline__ void wg_barrier() {
   asm volatile("" ::: "memory");
 }
 
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+template <int V> struct IntTag { static constexpr int value = V; };
+
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 // 4 rows x 16 columns of 16-bit elements, delivered column-major: lane i of a 16-lane group gets column i of the 4 rows
@@ -93,6 +103,8 @@ __device__ __forceinline__ bf16x8 lds_tr_frag(const char* p, int pitch4) {
 template <int NTERMS, int EPI_T, bool TN = false>
 __global__ __launch_bounds__(64 * (NCONS + NLOAD), 3) void gemm_split_ps_kernel(GemmArgs g) {
   constexpr bool kDrop = EPI_T == EPI_RESID_DROP;          // training-only instantiation: dropout before the residual add
+  constexpr bool kMixed = NTERMS == 2;                     // fp16 + e4m3 operands (mixed rows)
+  static_assert(!(kMixed && TN), "the mixed-row format has no transposed (weight-gradient) form");
   constexpr int EPI = kDrop ? (int)EPI_RESID : EPI_T;
   __shared__ __attribute__((aligned(16))) char smem[kLdsBytes];
 
@@ -285,6 +297,9 @@ __global__ __launch_bounds__(64 * (NCONS + NLOAD), 3) void gemm_split_ps_kernel(
   const int tn_a = (8 * tn_g + tn_q) * (BM * 4) + tn_y + (tn_p & 1) * 8 + wm * 256;   // chunk bits join by XOR below
   const int tn_w = 3 * kABytes + (8 * tn_g + tn_q) * (BN * 4) + (tn_p & 1) * 8;
 
+  // E8M0 scale of the e4m3 MFMA: the operands carry 2^(15 + e), e = the weight tensor's exponent (device memory)
+  const int mix_scale = kMixed ? (127 - kMixActExp - __builtin_amdgcn_readfirstlane(*g.w_exp)) * 0x01010101 : 0;
+  (void)mix_scale;
   unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t_begin = 0, a_bar = 0, a_cmp = 0, a_epi = 0;
   (void)t0; (void)t1; (void)t2; (void)t3; (void)t_begin; (void)a_bar; (void)a_cmp; (void)a_epi;
   STAMP(t_begin);
@@ -299,7 +314,10 @@ __global__ __launch_bounds__(64 * (NCONS + NLOAD), 3) void gemm_split_ps_kernel(
       for (int m = 0; m < 4; ++m) acc[n][m] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     bf16x8 ah[4], al[4], wh[6], wl[6];
-    for (int kt = 0; kt < nk; ++kt, ++s, s3 = s3 == 2 ? 0 : s3 + 1) {
+    i32x4 fa0[4], fa1[4], fw0[6], fw1[6];   // kMixed: slot g | slot 4+g of the stage row = the 32-byte e4m3 operand, or two fp16 fragments
+    // one stage; KIND (kMixed only): 0 = the fp16 part of a 64-k block, 1 = its e4m3 part
+    auto stage = [&](auto kind_tag) {
+      constexpr int KIND = decltype(kind_tag)::value;
       STAMP(t0);
       wg_barrier();
       STAMP(t1);
@@ -310,7 +328,10 @@ __global__ __launch_bounds__(64 * (NCONS + NLOAD), 3) void gemm_split_ps_kernel(
       // workgroup hitting the LDS right after the barrier overlap with matrix work instead of
       // preceding it.  NTERMS == 1 skips the lo fragments.
       auto rdA = [&](int m) {
-        if constexpr (TN) {
+        if constexpr (kMixed) {
+          fa0[m] = *(const i32x4*)(sa + a_off + m * 2048);
+          fa1[m] = *(const i32x4*)(sa + ((a_off + m * 2048) ^ 64));
+        } else if constexpr (TN) {
           const int o = tn_a ^ (((m >> 1) * 8 + (m & 1) * 2) << 4);
           ah[m] = lds_tr_frag(sa + o, 4 * BM * 4);
           if (NTERMS == 3) al[m] = lds_tr_frag(sa + (o ^ 64), 4 * BM * 4);
@@ -320,7 +341,10 @@ __global__ __launch_bounds__(64 * (NCONS + NLOAD), 3) void gemm_split_ps_kernel(
         }
       };
       auto rdW = [&](int n) {
-        if constexpr (TN) {
+        if constexpr (kMixed) {
+          fw0[n] = *(const i32x4*)(sw + w_off + n * 2048);
+          fw1[n] = *(const i32x4*)(sw + ((w_off + n * 2048) ^ 64));
+        } else if constexpr (TN) {
           const int o = tn_w + ((((wn * 3 + (n >> 1)) * 8 + (n & 1) * 2) << 4) ^ tn_y);
           wh[n] = lds_tr_frag(sw + o, 4 * BN * 4);
           if (NTERMS == 3) wl[n] = lds_tr_frag(sw + (o ^ 64), 4 * BN * 4);
@@ -330,11 +354,21 @@ __global__ __launch_bounds__(64 * (NCONS + NLOAD), 3) void gemm_split_ps_kernel(
         }
       };
       auto mma = [&](int n, int m) {
-        if (NTERMS == 3) {
-          acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[n], ah[m], acc[n][m], 0, 0, 0);
-          acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[n], al[m], acc[n][m], 0, 0, 0);
+        if constexpr (kMixed) {
+          if constexpr (KIND == 0) {
+            acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, fw0[n]), __builtin_bit_cast(f16x8, fa0[m]), acc[n][m], 0, 0, 0);
+            acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, fw1[n]), __builtin_bit_cast(f16x8, fa1[m]), acc[n][m], 0, 0, 0);
+          } else {
+            const i32x8 w8 = __builtin_shufflevector(fw0[n], fw1[n], 0, 1, 2, 3, 4, 5, 6, 7), a8 = __builtin_shufflevector(fa0[m], fa1[m], 0, 1, 2, 3, 4, 5, 6, 7);
+            acc[n][m] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(w8, a8, acc[n][m], 0, 0, 0, mix_scale, 0, 0x7f7f7f7f);
+          }
+        } else {
+          if (NTERMS == 3) {
+            acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[n], ah[m], acc[n][m], 0, 0, 0);
+            acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[n], al[m], acc[n][m], 0, 0, 0);
+          }
+          acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[n], ah[m], acc[n][m], 0, 0, 0);
         }
-        acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[n], ah[m], acc[n][m], 0, 0, 0);
       };
       rdW(0);
       rdA(0);
@@ -349,22 +383,33 @@ __global__ __launch_bounds__(64 * (NCONS + NLOAD), 3) void gemm_split_ps_kernel(
 #pragma unroll
         for (int m = 0; m < 4; ++m) mma(n, m);
       }
-      if (NTERMS == 3) {  // pin the interleave: DS_READ 0x100, MFMA 0x8
+      if (NTERMS >= 2) {  // pin the interleave: DS_READ 0x100, MFMA 0x8
         constexpr int R = TN ? 2 : 1;   // a transposed fragment is two reads
+        constexpr int MPB = kMixed ? (KIND == 0 ? 2 : 1) : 3;   // MFMAs per output block and stage
         __builtin_amdgcn_sched_group_barrier(0x100, 4 * R, 0);   // W0 (hi, lo), A0 (hi, lo)
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
           __builtin_amdgcn_sched_group_barrier(0x100, 2 * R, 0); // A(m+1) or W1
-          __builtin_amdgcn_sched_group_barrier(0x8, 3, 0);   // tile (0, m)
+          __builtin_amdgcn_sched_group_barrier(0x8, MPB, 0);   // tile (0, m)
         }
 #pragma unroll
         for (int n = 1; n < 6; ++n) {
           if (n < 5) __builtin_amdgcn_sched_group_barrier(0x100, 2 * R, 0);
-          __builtin_amdgcn_sched_group_barrier(0x8, 12, 0);
+          __builtin_amdgcn_sched_group_barrier(0x8, 4 * MPB, 0);
         }
       }
       STAMP(t2);
       ACC(a_bar, t1, t0); ACC(a_cmp, t2, t1);
+      ++s;
+      s3 = s3 == 2 ? 0 : s3 + 1;
+    };
+    if constexpr (kMixed) {
+      for (int kt = 0; kt < nk; kt += 2) {   // nk is even: a 64-k block is two stages
+        stage(IntTag<0>());
+        stage(IntTag<1>());
+      }
+    } else {
+      for (int kt = 0; kt < nk; ++kt) stage(IntTag<0>());
     }
 
     // epilogue.  The MFMA leaves lane l with C[row l&15 of the 16-row group][4 consecutive columns of chunk
@@ -418,18 +463,10 @@ __global__ __launch_bounds__(64 * (NCONS + NLOAD), 3) void gemm_split_ps_kernel(
               v[e] = dropout_keep(g.drop_seed, (unsigned long long)row * g.N + col + e, g.drop_thresh) ? v[e] * g.drop_scale : 0.f;
           }
           if (EPI == EPI_RESID) v += res[u & 1][j];
-          if (EPI == EPI_GELU_SPLIT) {
-            bf16x4 hi, lo;
+          if (EPI == EPI_GELU_SPLIT) {   // the operand format of the next GEMM = this one's
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              __bf16 h, l;
-              split_bf16(gelu_erf(v[e]), h, l);
-              hi[e] = h;
-              lo[e] = l;
-            }
-            __bf16* dst = g.c_split + (size_t)row * g.ldc + split_index(col);
-            *(bf16x4*)dst = hi;
-            *(bf16x4*)(dst + 32) = lo;
+            for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+            store_act4<kMixed ? FMT_MIXED : FMT_SPLIT>(g.c_split + (size_t)row * g.ldc, col, v);
           } else if (EPI == EPI_ATOMIC) {
             float* dstc = g.c + (size_t)row * g.ldc + col;
 #pragma unroll
@@ -453,6 +490,15 @@ __global__ __launch_bounds__(64 * (NCONS + NLOAD), 3) void gemm_split_ps_kernel(
 template <int NTERMS>
 hipError_t launch_ps_terms(GemmArgs g, int epi, int nblocks, hipStream_t s) {
   dim3 grid(nblocks), block(64 * (NCONS + NLOAD));
+  if constexpr (NTERMS == 2) {   // inference forms only
+    switch (epi) {
+      case EPI_F32: VETO_LAUNCH((gemm_split_ps_kernel<2, EPI_F32>), grid, block, 0, s, g); break;
+      case EPI_RESID: VETO_LAUNCH((gemm_split_ps_kernel<2, EPI_RESID>), grid, block, 0, s, g); break;
+      case EPI_GELU_SPLIT: VETO_LAUNCH((gemm_split_ps_kernel<2, EPI_GELU_SPLIT>), grid, block, 0, s, g); break;
+      default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+  } else
   switch (epi) {
     case EPI_F32: VETO_LAUNCH((gemm_split_ps_kernel<NTERMS, EPI_F32>), grid, block, 0, s, g); break;
     case EPI_RESID: VETO_LAUNCH((gemm_split_ps_kernel<NTERMS, EPI_RESID>), grid, block, 0, s, g); break;
@@ -487,7 +533,9 @@ hipError_t launch_gemm_split_ps(GemmArgs g, int epi, int precision, hipStream_t 
   const int ntiles = g.tiles_m * g.tiles_n * ksp;
   int nblocks = num_cu;  // one persistent workgroup per CU (LDS: 112 KiB each)
   if (ntiles < nblocks) nblocks = (ntiles + 7) / 8 * 8;
-  hipError_t rc = precision == 0 ? launch_ps_terms<3>(g, epi, nblocks, s) : launch_ps_terms<1>(g, epi, nblocks, s);
+  if (g.fmt == FMT_MIXED && (g.tn || !g.w_exp || (g.K / BK) % 2 != 0 || ksp != 1)) return hipErrorInvalidValue;
+  hipError_t rc = g.fmt == FMT_MIXED ? launch_ps_terms<2>(g, epi, nblocks, s)
+                  : precision == 0 ? launch_ps_terms<3>(g, epi, nblocks, s) : launch_ps_terms<1>(g, epi, nblocks, s);
 #ifdef VETO_GEMM_STAMPS
   {
     static unsigned long long host[256 * 8];

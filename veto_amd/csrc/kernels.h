@@ -31,6 +31,10 @@ struct GemmArgs {
   // split rows the backward already holds: a = dY split rows [k_valid, lda] (M = its column count), w = X split rows
   // [k_valid, ldw] (N = its column count), K = the reduction length rounded up to 32 * k_splits.  Reduction rows >= k_valid
   // are read from `zero` (>= 1 KiB of zeros).  The operands are transposed on their way out of LDS (ds_read_b64_tr_b16).
+  // fmt == FMT_MIXED (common.h): a and w are mixed rows (fp16 + e4m3), w_exp points to the weight tensor's e4m3 exponent
+  // on the device, and an EPI_GELU_SPLIT output is written as mixed rows too.  Inference forms only (no tn / split-K).
+  int fmt;
+  const int* w_exp;
   int tn;
   long ldw;
   int k_valid;
@@ -45,6 +49,10 @@ hipError_t launch_gemm_split_ps(GemmArgs g, int epi, int precision, hipStream_t 
 // ---- weight preparation (once per weight upload) ---------------------------------------------
 // src [rows, K] fp32 -> dst [rows, 2K] split rows
 hipError_t launch_split_rows(const float* src, __bf16* dst, size_t rows, int K, hipStream_t s);
+// src [rows, K] fp32 -> dst [rows, 4K bytes] mixed WEIGHT rows (common.h); *exp_out (device) receives the tensor's e4m3 exponent e:
+// the largest e in [0, 24] with 2^e max|w| <= 448
+hipError_t launch_mixed_act_rows(const float* src, __bf16* dst, size_t rows, int K, hipStream_t s);
+hipError_t launch_mixed_weight_rows(const float* src, __bf16* dst, size_t rows, int K, int* exp_out, hipStream_t s);
 // src [M, ld] fp32 (N columns used) -> dst [N, 2*Mp] split rows of the TRANSPOSE, Mp = M rounded up to 32*mult
 // (zero padded): the operand layout of a GEMM that reduces over M (weight gradients)
 hipError_t launch_transpose_split(const float* src, long ld, int M, int N, __bf16* dst, int Mp, hipStream_t s);
@@ -120,12 +128,13 @@ hipError_t launch_dropout_apply(const float* x, float* y, size_t rows, int n_col
 
 // LayerNorm(eps 1e-5) of `rows` rows (row r at x + r*ldx) -> split rows [rows, 2*576]
 hipError_t launch_layernorm(const float* x, long ldx, const float* w, const float* b, __bf16* dst, int rows,
-                            hipStream_t s);
+                            hipStream_t s, int fmt = FMT_SPLIT);
 
 struct AttnArgs {
   const float* qkv;        // [n_pair*19, 1728]
   __bf16* o;               // split rows [rows, 2*576]; rows = n_pair*19, or n_pair when cls_only
   int n_pair, heads, cls_only;
+  int o_fmt = FMT_SPLIT;   // operand format of o (MFMA head widths; the generic kernel writes split rows only)
   // layer 0, per-object form (rowops.hip): when sw != nullptr the rows of tokens 1..16 are formed on load as
   // rstd * (sw[subj*16 + t-1] + ow[obj*16 + t-1]) + c2, token 0 is the constant row vec + 2*1728, and only the rows of tokens
   // 17 / 18 are read from qkv.  MFMA head widths (72, 96) only: launch_attention returns hipErrorInvalidValue otherwise.

@@ -37,6 +37,58 @@ __global__ void split_rows_kernel(const float* __restrict__ src, __bf16* __restr
   }
 }
 
+// fp32 [rows, K] -> mixed ACTIVATION rows (common.h); test hook of the mixed GEMM
+__global__ void mixed_act_rows_kernel(const float* __restrict__ src, __bf16* __restrict__ dst, size_t n, int K) {
+  for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += (size_t)gridDim.x * blockDim.x * 4) {
+    const size_t row = i / K;
+    store_act4<FMT_MIXED>(dst + row * (2 * (size_t)K), (int)(i % K), *(const f32x4*)(src + i));
+  }
+}
+
+// Mixed weight rows (common.h).  Pass 1: max |w| as float bits (non-negative floats order like unsigned integers).
+__global__ void absmax_bits_kernel(const float* __restrict__ src, size_t n, unsigned* __restrict__ out) {
+  unsigned m = 0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const unsigned b = __float_as_uint(src[i]) & 0x7fffffffu;
+    m = b > m ? b : m;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { const unsigned t = __shfl_xor(m, o, 64); m = t > m ? t : m; }
+  if ((threadIdx.x & 63) == 0) atomicMax(out, m);
+}
+// e = the largest exponent in [0, 24] with 2^e * max|w| <= 448 (an all-zero tensor gets 24)
+__device__ __forceinline__ int weight_exp_of(unsigned maxbits) {
+  const float mx = __uint_as_float(maxbits);
+  int e = 24;
+  while (e > 0 && !(ldexpf(mx, e) <= 448.f)) --e;
+  return e;
+}
+// Pass 2: 4 consecutive k's per thread: h = fp16(w) (8 B), X = e4m3(2^e h) (4 B), Y = e4m3(2^(e+11) (w - h)) (4 B)
+__global__ void mixed_weight_rows_kernel(const float* __restrict__ src, __bf16* __restrict__ dst, size_t n, int K,
+                                         const int* __restrict__ maxbits) {
+  const int e = weight_exp_of((unsigned)*maxbits);
+  const float sx = ldexpf(1.f, e), sy = ldexpf(1.f, e + kMixWLoShift);
+  for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += (size_t)gridDim.x * blockDim.x * 4) {
+    const size_t row = i / K;
+    const int k = (int)(i % K);
+    const f32x4 w = *(const f32x4*)(src + i);
+    char* base = (char*)dst + row * (4 * (size_t)K);
+    f16x4 h;
+    float x[4], y[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      h[j] = (_Float16)w[j];
+      x[j] = (float)h[j] * sx;
+      y[j] = (w[j] - (float)h[j]) * sy;
+    }
+    *(f16x4*)(base + mixed_h_offset(k)) = h;
+    *(uint32_t*)(base + mixed_x_offset(k)) = pack_e4m3x4(x[0], x[1], x[2], x[3]);
+    *(uint32_t*)(base + mixed_x_offset(k) + 64) = pack_e4m3x4(y[0], y[1], y[2], y[3]);
+  }
+}
+// Pass 3: replace the float bits by the exponent itself (what the GEMM reads)
+__global__ void finish_weight_exp_kernel(int* e) { *e = weight_exp_of((unsigned)*e); }
+
 // fp32 [M, ld] -> split rows of the transpose [N, 2*Mp]: a 32 (m) x 64 (n) tile goes through LDS; every output
 // row n receives one whole 32-k block, [8 x 4 hi | 8 x 4 lo] bf16 = 128 contiguous bytes, as 16-byte pieces.
 __global__ __launch_bounds__(256) void transpose_split_kernel(const float* __restrict__ src, long ld, int M, int N,
@@ -297,33 +349,26 @@ __device__ __forceinline__ void rowq_stats(const RowQ& r, float& mean, float& rs
   rstd = 1.f / sqrtf(group16_sum(sq) * (1.f / kDim) + 1e-5f);
 }
 
+template <int FMT = FMT_SPLIT>
 __device__ __forceinline__ void rowq_normalized_store(const RowQ& r, int q, float mean, float rstd, const float* __restrict__ w,
                                                       const float* __restrict__ b, __bf16* __restrict__ dst) {
 #pragma unroll
   for (int j = 0; j < 9; ++j) {
-
     const int c = 4 * (q + 16 * j);
     const f32x4 wv = *(const f32x4*)(w + c), bv = *(const f32x4*)(b + c);
-    bf16x4 hi, lo;
+    f32x4 y;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      __bf16 h, l;
-      split_bf16((r.v[j][e] - mean) * rstd * wv[e] + bv[e], h, l);
-      hi[e] = h;
-      lo[e] = l;
-    }
-    __bf16* d = dst + split_index(c);  // 4 consecutive columns stay inside one 32-k block
-    *(bf16x4*)d = hi;
-    *(bf16x4*)(d + 32) = lo;
+    for (int e = 0; e < 4; ++e) y[e] = (r.v[j][e] - mean) * rstd * wv[e] + bv[e];
+    store_act4<FMT>(dst, c, y);  // 4 consecutive columns stay inside one 32-k block
   }
 }
 
-
+template <int FMT = FMT_SPLIT>
 __device__ __forceinline__ void rowq_layernorm_store(const RowQ& r, int q, const float* __restrict__ w,
                                                      const float* __restrict__ b, __bf16* __restrict__ dst) {
   float mean, rstd;
   rowq_stats(r, mean, rstd);
-  rowq_normalized_store(r, q, mean, rstd, w, b, dst);
+  rowq_normalized_store<FMT>(r, q, mean, rstd, w, b, dst);
 }
 
 // Token assembly (model_veto.py:56-63 with the per-object partial products of section 4 of DESIGN.md):
@@ -494,6 +539,7 @@ __global__ __launch_bounds__(64) void qkv0_consts_kernel(const float* __restrict
   }
 }
 
+template <int FMT>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, long ldx,
                                                         const float* __restrict__ w,
                                                         const float* __restrict__ b,
@@ -505,7 +551,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
   RowQ r;
 #pragma unroll
   for (int j = 0; j < 9; ++j) r.v[j] = *(const f32x4*)(xr + 4 * (q + 16 * j));
-  rowq_layernorm_store(r, q, w, b, dst + (size_t)row * (2 * kDim));
+  rowq_layernorm_store<FMT>(r, q, w, b, dst + (size_t)row * (2 * kDim));
 }
 
 __global__ __launch_bounds__(256) void dropout_apply_kernel(const float* __restrict__ x, float* __restrict__ y, size_t n,
@@ -637,8 +683,29 @@ hipError_t launch_qkv0_consts(const float* wq, const float* gamma, const float* 
 }
 
 hipError_t launch_layernorm(const float* x, long ldx, const float* w, const float* b, __bf16* dst, int rows,
-                            hipStream_t s) {
-  VETO_LAUNCH(layernorm_kernel, dim3((rows + 15) / 16), dim3(256), 0, s, x, ldx, w, b, dst, rows);
+                            hipStream_t s, int fmt) {
+  if (fmt == FMT_MIXED) VETO_LAUNCH(layernorm_kernel<FMT_MIXED>, dim3((rows + 15) / 16), dim3(256), 0, s, x, ldx, w, b, dst, rows);
+  else VETO_LAUNCH(layernorm_kernel<FMT_SPLIT>, dim3((rows + 15) / 16), dim3(256), 0, s, x, ldx, w, b, dst, rows);
+  return hipGetLastError();
+}
+
+hipError_t launch_mixed_act_rows(const float* src, __bf16* dst, size_t rows, int K, hipStream_t s) {
+  if (K % 64 != 0) return hipErrorInvalidValue;
+  const size_t n = rows * (size_t)K;
+  const int blocks = (int)((n / 4 + 255) / 256 < 2048 ? (n / 4 + 255) / 256 : 2048);
+  VETO_LAUNCH(mixed_act_rows_kernel, dim3(blocks), dim3(256), 0, s, src, dst, n, K);
+  return hipGetLastError();
+}
+
+hipError_t launch_mixed_weight_rows(const float* src, __bf16* dst, size_t rows, int K, int* exp_out, hipStream_t s) {
+  if (K % 64 != 0) return hipErrorInvalidValue;
+  const size_t n = rows * (size_t)K;
+  const int blocks = (int)((n / 4 + 255) / 256 < 2048 ? (n / 4 + 255) / 256 : 2048);
+  hipError_t e = hipMemsetAsync(exp_out, 0, sizeof(int), s);
+  if (e != hipSuccess) return e;
+  VETO_LAUNCH(absmax_bits_kernel, dim3(blocks), dim3(256), 0, s, src, n, (unsigned*)exp_out);
+  VETO_LAUNCH(mixed_weight_rows_kernel, dim3(blocks), dim3(256), 0, s, src, dst, n, K, exp_out);
+  VETO_LAUNCH(finish_weight_exp_kernel, dim3(1), dim3(1), 0, s, exp_out);
   return hipGetLastError();
 }
 

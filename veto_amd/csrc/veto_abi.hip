@@ -47,6 +47,9 @@ typedef __bf16* SplitW;  // [N, 2K] split rows (common.h)
 struct LayerW {
   const float *ln1_w, *ln1_b, *ln2_w, *ln2_b, *out_b, *fc1_b, *fc2_b;
   SplitW qkv = nullptr, out = nullptr, fc1 = nullptr, fc2 = nullptr;
+  // VETO_MIXED: the same four weights as mixed rows (common.h) and their e4m3 exponents (device ints: qkv, out, fc1, fc2)
+  SplitW qkv_m = nullptr, out_m = nullptr, fc1_m = nullptr, fc2_m = nullptr;
+  int* exp_m = nullptr;
 };
 
 struct ProfRec {
@@ -149,6 +152,12 @@ int finalize_weights(veto_handle_t h, hipStream_t s) {
     HIP_TRY(launch_split_rows(h->p(lname(l, "0.fn.to_out.0.weight")), w.out, kDim, kDim, s));
     HIP_TRY(launch_split_rows(h->p(lname(l, "1.fn.net.0.weight")), w.fc1, 2 * kDim, kDim, s));
     HIP_TRY(launch_split_rows(h->p(lname(l, "1.fn.net.3.weight")), w.fc2, kDim, 2 * kDim, s));
+    if (h->cfg.precision == VETO_MIXED) {
+      HIP_TRY(launch_mixed_weight_rows(h->p(lname(l, "0.fn.to_qkv.weight")), w.qkv_m, 3 * kDim, kDim, w.exp_m + 0, s));
+      HIP_TRY(launch_mixed_weight_rows(h->p(lname(l, "0.fn.to_out.0.weight")), w.out_m, kDim, kDim, w.exp_m + 1, s));
+      HIP_TRY(launch_mixed_weight_rows(h->p(lname(l, "1.fn.net.0.weight")), w.fc1_m, 2 * kDim, kDim, w.exp_m + 2, s));
+      HIP_TRY(launch_mixed_weight_rows(h->p(lname(l, "1.fn.net.3.weight")), w.fc2_m, kDim, 2 * kDim, w.exp_m + 3, s));
+    }
   }
   const std::string pe = std::string(kT) + "patch_embed.";
   HIP_TRY(launch_build_patch_weight(h->p(pe + "proj_d.weight"), h->p(pe + "proj_d.bias"), h->p(pe + "proj_v.weight"),
@@ -239,8 +248,9 @@ struct DropSite {   // one dropout site of the training path: threshold p * 2^24
 
 int run_gemm(veto_handle_t h, hipStream_t s, const char* name, const __bf16* a, SplitW w, const float* bias,
              const float* resid, long ldr, float* c, __bf16* c_split, long ldc, int M, int N, int K, int epi,
-             long lda = 0, int w_row0 = 0, DropSite drop = DropSite()) {
+             long lda = 0, int w_row0 = 0, DropSite drop = DropSite(), const int* w_exp = nullptr) {
   GemmArgs g{};
+  if (w_exp) { g.fmt = FMT_MIXED; g.w_exp = w_exp; }   // a, w (and an EPI_GELU_SPLIT output) are mixed rows
   if (drop.thresh) {
     if (epi != EPI_RESID) return fail(VETO_ERR_INVALID, "dropout is fused into the residual epilogue only");
     epi = EPI_RESID_DROP;
@@ -253,7 +263,7 @@ int run_gemm(veto_handle_t h, hipStream_t s, const char* name, const __bf16* a, 
   const double flops = 2.0 * M * (double)N * K;
   const double bytes = 4.0 * ((double)M * K + (double)N * K) + (double)M * N * (epi == EPI_RESID ? 8.0 : 4.0);
   ProfScope ps(h, s, name, flops, bytes);
-  HIP_TRY(launch_gemm_split(g, epi, h->cfg.precision, s));
+  HIP_TRY(launch_gemm_split(g, epi, h->cfg.precision == VETO_FAST ? 1 : 0, s));
   return VETO_OK;
 }
 
@@ -276,7 +286,7 @@ int veto_create(const veto_config_t* cfg, veto_handle_t* out) {
   if (cfg->num_obj_cls < 2 || cfg->num_obj_cls > 256 || cfg->embed_dim < 1 || cfg->embed_dim > 256)
     return fail(VETO_ERR_INVALID, "num_obj_cls/embed_dim out of range");
   if (cfg->num_out < 1 || cfg->num_out > 4096) return fail(VETO_ERR_INVALID, "bad num_out %d", cfg->num_out);
-  if (cfg->precision != VETO_PRECISE && cfg->precision != VETO_FAST) return fail(VETO_ERR_INVALID, "bad precision");
+  if (cfg->precision != VETO_PRECISE && cfg->precision != VETO_FAST && cfg->precision != VETO_MIXED) return fail(VETO_ERR_INVALID, "bad precision");
   HIP_TRY(hipSetDevice(cfg->device));
 
   veto_handle_t h = new veto_handle_s();
@@ -333,7 +343,14 @@ int veto_create(const veto_config_t* cfg, veto_handle_t* out) {
     lo_[l * 8 + 2] = dtake((size_t)kDim * kDim * 4);
     lo_[l * 8 + 4] = dtake((size_t)2 * kDim * kDim * 4);
     lo_[l * 8 + 6] = dtake((size_t)2 * kDim * kDim * 4);
+    if (cfg->precision == VETO_MIXED) {
+      lo_[l * 8 + 1] = dtake((size_t)3 * kDim * kDim * 4);
+      lo_[l * 8 + 3] = dtake((size_t)kDim * kDim * 4);
+      lo_[l * 8 + 5] = dtake((size_t)2 * kDim * kDim * 4);
+      lo_[l * 8 + 7] = dtake((size_t)2 * kDim * kDim * 4);
+    }
   }
+  const size_t o_exp = dtake((size_t)L * 4 * sizeof(int));
   const size_t o_pw = dtake((size_t)2 * kDim * 2048 * 4);
   const size_t o_pb = dtake((size_t)2 * kDim * 4);
   const size_t o_loc = dtake((size_t)kPosDim * 2 * kDim * 4);
@@ -352,6 +369,13 @@ int veto_create(const veto_config_t* cfg, veto_handle_t* out) {
     w.out = (__bf16*)(d + lo_[l * 8 + 2]);
     w.fc1 = (__bf16*)(d + lo_[l * 8 + 4]);
     w.fc2 = (__bf16*)(d + lo_[l * 8 + 6]);
+    if (cfg->precision == VETO_MIXED) {
+      w.qkv_m = (__bf16*)(d + lo_[l * 8 + 1]);
+      w.out_m = (__bf16*)(d + lo_[l * 8 + 3]);
+      w.fc1_m = (__bf16*)(d + lo_[l * 8 + 5]);
+      w.fc2_m = (__bf16*)(d + lo_[l * 8 + 7]);
+      w.exp_m = (int*)(d + o_exp) + 4 * l;
+    }
     w.ln1_w = h->p(lname(l, "0.norm.weight")); w.ln1_b = h->p(lname(l, "0.norm.bias"));
     w.ln2_w = h->p(lname(l, "1.norm.weight")); w.ln2_b = h->p(lname(l, "1.norm.bias"));
     w.out_b = h->p(lname(l, "0.fn.to_out.0.bias"));
@@ -475,6 +499,10 @@ int veto_forward(veto_handle_t h, void* stream, const veto_inputs_t* in, void* w
   const bool qkv0_tables = L >= 2 && !tables_off;
   static const bool fold_off = getenv("VETO_CLS_FOLD") && !strcmp(getenv("VETO_CLS_FOLD"), "0");           // A/B knob
   const bool fold_last = !fold_off && H <= cls_fold_max_heads();   // last layer in the folded CLS form (attention.hip)
+  // VETO_MIXED: the four token-row Linears of every layer but the last take fp16 + e4m3 operands (common.h); the per-object and
+  // CLS-row GEMMs (8 % of the GEMM work) stay on split-bf16 operands.  The out projection only behind the MFMA attention kernel.
+  const bool mixed = h->cfg.precision == VETO_MIXED;
+  const bool mixed_out = mixed && attention_reads_tables(H);
   if (qkv0_tables) {
     const int R = n_obj * 16;
     HIP_TRY(launch_centre_split(ws.patch_tab, ws.ptab_split, R, s));
@@ -540,7 +568,9 @@ int veto_forward(veto_handle_t h, void* stream, const veto_inputs_t* in, void* w
           if (rc) return rc;
         }
       } else if (!last) {
-        rc = run_gemm(h, s, "gemm_qkv", ws.a, w.qkv, nullptr, nullptr, 0, qkv, nullptr, 3 * kDim, M, 3 * kDim, kDim, EPI_F32);
+        const bool mq = mixed && l > 0;   // layer 0's LayerNorm'ed rows come from token assembly (split rows)
+        rc = run_gemm(h, s, "gemm_qkv", ws.a, mq ? w.qkv_m : w.qkv, nullptr, nullptr, 0, qkv, nullptr, 3 * kDim, M, 3 * kDim, kDim, EPI_F32,
+                      0, 0, DropSite(), mq ? w.exp_m + 0 : nullptr);
         if (rc) return rc;
       } else {
         // last layer: keys/values for all 19 tokens, the query for the CLS row of each pair only
@@ -555,6 +585,7 @@ int veto_forward(veto_handle_t h, void* stream, const veto_inputs_t* in, void* w
         AttnArgs a{};
         a.qkv = qkv; a.n_pair = np; a.heads = H; a.cls_only = last ? 1 : 0;
         a.o = last ? ws.ac : ws.a;
+        a.o_fmt = (!last && mixed_out) ? FMT_MIXED : FMT_SPLIT;
         if (l == 0 && qkv0_tables && attention_reads_tables(H)) {   // q / k / v of the patch tokens are formed on load
           a.sw = ws.sw; a.ow = ws.ow; a.stats = ws.stats; a.vec = h->q0_vec; a.subj = ws.subj + c0; a.obj = ws.obj + c0;
         }
@@ -564,16 +595,18 @@ int veto_forward(veto_handle_t h, void* stream, const veto_inputs_t* in, void* w
         HIP_TRY(launch_attention(a, s));
       }
       if (!last) {
-        rc = run_gemm(h, s, "gemm_out", ws.a, w.out, w.out_b, ws.x, kDim, ws.x, nullptr, kDim, M, kDim, kDim, EPI_RESID);
+        rc = run_gemm(h, s, "gemm_out", ws.a, mixed_out ? w.out_m : w.out, w.out_b, ws.x, kDim, ws.x, nullptr, kDim, M, kDim, kDim, EPI_RESID,
+                      0, 0, DropSite(), mixed_out ? w.exp_m + 1 : nullptr);
         if (rc) return rc;
         {
           ProfScope ps(h, s, "layernorm", 0, (double)M * kDim * 8);
-          HIP_TRY(launch_layernorm(ws.x, kDim, w.ln2_w, w.ln2_b, ws.a, M, s));
+          HIP_TRY(launch_layernorm(ws.x, kDim, w.ln2_w, w.ln2_b, ws.a, M, s, mixed ? FMT_MIXED : FMT_SPLIT));
         }
-        rc = run_gemm(h, s, "gemm_fc1", ws.a, w.fc1, w.fc1_b, nullptr, 0, nullptr, hid, 4 * kDim, M, 2 * kDim, kDim,
-                      EPI_GELU_SPLIT);
+        rc = run_gemm(h, s, "gemm_fc1", ws.a, mixed ? w.fc1_m : w.fc1, w.fc1_b, nullptr, 0, nullptr, hid, 4 * kDim, M, 2 * kDim, kDim,
+                      EPI_GELU_SPLIT, 0, 0, DropSite(), mixed ? w.exp_m + 2 : nullptr);
         if (rc) return rc;
-        rc = run_gemm(h, s, "gemm_fc2", hid, w.fc2, w.fc2_b, ws.x, kDim, ws.x, nullptr, kDim, M, kDim, 2 * kDim, EPI_RESID);
+        rc = run_gemm(h, s, "gemm_fc2", hid, mixed ? w.fc2_m : w.fc2, w.fc2_b, ws.x, kDim, ws.x, nullptr, kDim, M, kDim, 2 * kDim, EPI_RESID,
+                      0, 0, DropSite(), mixed ? w.exp_m + 3 : nullptr);
         if (rc) return rc;
         {
           const LayerW& nx = h->layers[l + 1];
@@ -581,7 +614,8 @@ int veto_forward(veto_handle_t h, void* stream, const veto_inputs_t* in, void* w
             // the folded last layer LayerNorms its token rows itself
           } else {
             ProfScope ps(h, s, "layernorm", 0, (double)M * kDim * 8);
-            HIP_TRY(launch_layernorm(ws.x, kDim, nx.ln1_w, nx.ln1_b, ws.a, M, s));
+            // the next layer's QKV GEMM takes mixed rows unless it is the (unfolded) last layer
+            HIP_TRY(launch_layernorm(ws.x, kDim, nx.ln1_w, nx.ln1_b, ws.a, M, s, (mixed && l + 1 < L - 1) ? FMT_MIXED : FMT_SPLIT));
           }
         }
       } else {
@@ -776,7 +810,7 @@ int check_train_inputs(veto_handle_t h, const veto_inputs_t* in, void* workspace
     return fail(VETO_ERR_INVALID, "missing input pointer");
   if (!in->obj_labels && !in->obj_logits) return fail(VETO_ERR_INVALID, "neither obj_labels nor obj_logits given");
   if (!in->bn_batch_stats) return fail(VETO_ERR_INVALID, "the training path needs bn_batch_stats (training-mode BatchNorm)");
-  if (h->cfg.precision != VETO_PRECISE) return fail(VETO_ERR_INVALID, "the training path runs in precise mode only");
+  if (h->cfg.precision == VETO_FAST) return fail(VETO_ERR_INVALID, "the training path runs on split-bf16 operands (precise / mixed handles) only");
   if (workspace_bytes < veto_train_workspace_bytes(h, in->n_obj, in->n_pair)) return fail(VETO_ERR_WORKSPACE, "training workspace too small");
   return VETO_OK;
 }
@@ -1330,7 +1364,7 @@ int veto_profile_reset(veto_handle_t h) {
 size_t veto_debug_gemm_workspace_bytes(int32_t m, int32_t n, int32_t k) {
   if (m <= 0 || n <= 0 || k <= 0) return 0;
   const size_t mp = (size_t)gemm_rows_padded(m);
-  return align_up(mp * k * 4, 256) + align_up((size_t)n * k * 4, 256);
+  return align_up(mp * k * 4, 256) + align_up((size_t)n * k * 4, 256) + 256;
 }
 
 int veto_debug_gemm(void* stream, const float* a, const float* w, const float* bias, float* c, int32_t m, int32_t n,
@@ -1342,13 +1376,21 @@ int veto_debug_gemm(void* stream, const float* a, const float* w, const float* b
   char* base = (char*)workspace;
   __bf16* a_s = (__bf16*)base;
   __bf16* w_s = (__bf16*)(base + align_up(mp * k * 4, 256));
+  int* w_exp = (int*)(base + align_up(mp * k * 4, 256) + align_up((size_t)n * k * 4, 256));
   HIP_TRY(hipMemsetAsync(base, 0, align_up(mp * k * 4, 256), s));
-  HIP_TRY(launch_split_rows(a, a_s, (size_t)m, k, s));
-  HIP_TRY(launch_split_rows(w, w_s, (size_t)n, k, s));
   GemmArgs g{};
+  if (precision == VETO_MIXED) {
+    if (k % 64 != 0) return fail(VETO_ERR_INVALID, "mixed rows need K %% 64 == 0");
+    HIP_TRY(launch_mixed_act_rows(a, a_s, (size_t)m, k, s));
+    HIP_TRY(launch_mixed_weight_rows(w, w_s, (size_t)n, k, w_exp, s));
+    g.fmt = FMT_MIXED; g.w_exp = w_exp;
+  } else {
+    HIP_TRY(launch_split_rows(a, a_s, (size_t)m, k, s));
+    HIP_TRY(launch_split_rows(w, w_s, (size_t)n, k, s));
+  }
   g.a = a_s; g.w = w_s; g.bias = bias; g.c = c;
   g.M = m; g.N = n; g.K = k; g.ldc = n;
-  hipError_t e = launch_gemm_split(g, EPI_F32, precision, s);
+  hipError_t e = launch_gemm_split(g, EPI_F32, precision == VETO_FAST ? 1 : 0, s);
   if (e != hipSuccess) return fail(e == hipErrorInvalidValue ? VETO_ERR_INVALID : VETO_ERR_HIP,
                                    "gemm launch failed (N must be a multiple of 192, K of 32): %s", hipGetErrorString(e));
   return VETO_OK;

@@ -27,7 +27,7 @@ EXPORTS = [
     "veto_roi_pool", "veto_roi_pool_backward", "veto_sgg_eval", "veto_sgg_eval_workspace_bytes",
 ]
 
-VETO_PRECISE, VETO_FAST = 0, 1
+VETO_PRECISE, VETO_FAST, VETO_MIXED = 0, 1, 2
 
 
 class VetoConfig(Structure):

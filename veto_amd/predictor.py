@@ -72,9 +72,10 @@ def _mode(config):
 def _precision(config):
     ext = getattr(config, "VETO_AMD", None)
     name = getattr(ext, "PRECISION", "precise") if ext is not None else "precise"
-    if name not in ("precise", "fast"):
-        raise ValueError("VETO_AMD.PRECISION must be 'precise' or 'fast', got %r" % (name,))
-    return native.VETO_PRECISE if name == "precise" else native.VETO_FAST
+    modes = {"precise": native.VETO_PRECISE, "fast": native.VETO_FAST, "mixed": native.VETO_MIXED}
+    if name not in modes:
+        raise ValueError("VETO_AMD.PRECISION must be one of %s, got %r" % (sorted(modes), name))
+    return modes[name]
 
 
 def _max_chunk(config):
