@@ -103,6 +103,27 @@ __device__ __forceinline__ void store_act4(__bf16* row, int col, f32x4 v) {
   }
 }
 
+// 8 consecutive columns (col % 8 == 0) of a mixed activation row: one 16-byte and two 8-byte stores
+__device__ __forceinline__ void store_act8_mixed(__bf16* row, int col, f32x4 v0, f32x4 v1) {
+  typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
+  typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+  char* base = (char*)row;
+  f16x8_t h;
+  float l[8], y[8];
+  constexpr float ys = (float)(1 << kMixActHiExp);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float x = e < 4 ? v0[e] : v1[e - 4];
+    h[e] = (_Float16)x;
+    l[e] = (x - (float)h[e]) * (float)(1 << kMixActExp);
+    y[e] = x * ys;
+  }
+  *(f16x8_t*)(base + mixed_h_offset(col)) = h;
+  char* x = base + mixed_x_offset(col);
+  *(u32x2*)x = u32x2{pack_e4m3x4(l[0], l[1], l[2], l[3]), pack_e4m3x4(l[4], l[5], l[6], l[7])};
+  *(u32x2*)(x + 64) = u32x2{pack_e4m3x4(y[0], y[1], y[2], y[3]), pack_e4m3x4(y[4], y[5], y[6], y[7])};
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -118,6 +139,23 @@ __device__ __forceinline__ float gelu_erf(float x) {
   const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
   const float erf_abs = 1.0f - poly * __expf(-z * z);
   return 0.5f * x * (1.0f + copysignf(erf_abs, x));
+}
+
+// The same function through ONE exponential: x Phi(x) = x sigmoid(g(x)) with g = logit(Phi) fitted by an odd polynomial of
+// degree 11 on [-6, 6] (minimax-reweighted least squares, tools/precision_study.py --gelu; |error| <= 1e-6 absolute in fp32,
+// beyond +-6 Phi is 0 / 1 to 1e-9).  10 VALU + 2 transcendental instructions against 17 + 2: the FeedForward epilogue of the
+// inference path is VALU-bound (96 values per lane).  The coefficients carry the factor -log2(e) of v_exp_f32.
+__device__ __forceinline__ float gelu_sigmoid(float x) {
+  const float xc = __builtin_amdgcn_fmed3f(x, -6.f, 6.f);
+  const float x2 = xc * xc;
+  float p = 1.3906235096783348e-07f;
+  p = fmaf(p, x2, -7.393736268568318e-06f);
+  p = fmaf(p, x2, 0.000129951280541718f);
+  p = fmaf(p, x2, 0.00019161769887432456f);
+  p = fmaf(p, x2, -0.10496557503938675f);
+  p = fmaf(p, x2, -2.3021585941314697f);
+  const float e = __builtin_amdgcn_exp2f(p * xc);             // exp(-g(x)), <= 2^23
+  return x * __builtin_amdgcn_rcpf(1.0f + e);
 }
 
 // Counter-based dropout mask (training path): element `idx` of dropout site `seed` is kept iff the top 24 bits of a

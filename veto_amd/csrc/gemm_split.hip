@@ -176,7 +176,7 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void gemm_split_kernel(GemmArgs g) 
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           __bf16 h, l;
-          split_bf16(gelu_erf(v[e]), h, l);
+          split_bf16(gelu_sigmoid(v[e]), h, l);
           hi[e] = h;
           lo[e] = l;
         }

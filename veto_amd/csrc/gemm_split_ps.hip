@@ -44,8 +44,9 @@ constexpr int BM = 256, BN = 192, BK = 32;
 constexpr int NCONS = 8, NLOAD = 4;
 constexpr int kABytes = BM * 128;             // one A stage: 256 rows x 128 B = 32 KiB (3 of them)
 constexpr int kWBytes = BN * 128;             // one W stage: 192 rows x 128 B = 24 KiB (2 of them)
-constexpr int kLdsBytes = 3 * kABytes + 2 * kWBytes + 1024;  // 144 KiB + a dump area for prefetches
 constexpr int kDumpOff = 3 * kABytes + 2 * kWBytes;
+constexpr int kBiasOff = kDumpOff + 1024;     // two 768-byte bias slices (tile parity), filled by loader wave 0
+constexpr int kLdsBytes = kBiasOff + 2 * BN * 4;  // 144 KiB + a dump area for prefetches + the bias slices
 constexpr int kPrefSteps = BN * 4 / 128;      // 6: 128-byte lines per residual row of a tile
 constexpr int CPA = BM / 8 / NLOAD;           // 8 A chunks (8 rows x 128 B) per loader wave and stage
 constexpr int CPWL = BN / 8 / NLOAD;          // 6 W chunks
@@ -195,6 +196,13 @@ __global__ __launch_bounds__(64 * (NCONS + NLOAD), 3) void gemm_split_ps_kernel(
     // cursors of the next A stage / W stage to issue (the stream of stages crosses tile boundaries)
     int itA = 0, ktA = 0, bufA = 0, itW = 0, ktW = 0, bufW = 0;
     auto issueA = [&]() {
+      // first stage of a tile: loader wave 0 also fetches the tile's 192 bias values into the slice of the tile's parity (the
+      // epilogue reads them from LDS: no bias registers held across it, no vector-memory wait behind its own stores).  Issued
+      // BEFORE the A chunks: older than them in vmcnt order, so the stage's counted wait covers it.
+      if (ktA == 0 && lw == 0 && g.bias && lane < BN / 4) {
+        const int tn = (tile_of(itA) % out_tiles) % g.tiles_n;
+        glds16((const char*)(g.bias + tn * BN) + lane * 16, smem + kBiasOff + (itA & 1) * (BN * 4));
+      }
       char* dst = smem + bufA * kABytes + lw * 1024;
       if constexpr (TN) {
 #pragma unroll
@@ -420,16 +428,16 @@ __global__ __launch_bounds__(64 * (NCONS + NLOAD), 3) void gemm_split_ps_kernel(
     // Stores are not waited for.  EPI_RESID: the residual reads of row group m+1 are issued BEFORE the
     // stores of group m (vmcnt counts loads and stores in issue order, so a load issued after a store would
     // have to wait for it; and c may alias resid, which stops the compiler from hoisting the loads by itself).
-    const int er = kEpiT ? lane >> 2 : lane & 15;   // row inside a 16-row group
-    const int eq = kEpiT ? lane & 3 : lane >> 4;    // 16-byte chunk inside a 16-column group
+    // (the lane id is laundered through an empty asm so that the epilogue's lane-dependent offsets are recomputed per tile
+    // instead of being hoisted out of the persistent loop, where they would stay live -- and spill -- across the k-loop)
+    int lane_e = lane;
+    asm volatile("" : "+v"(lane_e));
+    const int er = kEpiT ? lane_e >> 2 : lane_e & 15;   // row inside a 16-row group
+    const int eq = kEpiT ? lane_e & 3 : lane_e >> 4;    // 16-byte chunk inside a 16-column group
     const int perm_addr = ((eq << 4) + er) << 2;    // byte address of the source lane for ds_bpermute
-    f32x4 bias_v[6];
-#pragma unroll
-    for (int n = 0; n < 6; ++n)
-      bias_v[n] = g.bias ? *(const f32x4*)(g.bias + tile_n * BN + wn * 96 + n * 16 + eq * 4)
-                         : f32x4{0.f, 0.f, 0.f, 0.f};
     const int row0 = tile_m * BM + wm * 64 + er;
     const int col0 = tile_n * BN + wn * 96 + eq * 4;
+    const char* bias_lds = smem + kBiasOff + (it & 1) * (BN * 4) + (wn * 96 + eq * 4) * 4;
     // the epilogue walks 8 units of (16-row group m, half h of the 6 column groups); the residual of unit
     // u+1 is in flight while unit u is stored (two buffers of 3 x 4 registers next to the 96 accumulators)
     f32x4 res[2][3];
@@ -442,12 +450,12 @@ __global__ __launch_bounds__(64 * (NCONS + NLOAD), 3) void gemm_split_ps_kernel(
     if (EPI == EPI_RESID) load_res(0, res[0]);
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-      const int m = u >> 1;
+      const int m = u >> 1, h = u & 1;
       if (EPI == EPI_RESID && u < 7) load_res(u + 1, res[(u + 1) & 1]);
       const int row = row0 + m * 16;
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
-        const int n = (u & 1) * 3 + j;
+        const int n = h * 3 + j;
         f32x4 t = acc[n][m];
         if (kEpiT) {   // executed by every lane: rows past M hold values other lanes need
 #pragma unroll
@@ -456,7 +464,8 @@ __global__ __launch_bounds__(64 * (NCONS + NLOAD), 3) void gemm_split_ps_kernel(
         }
         if (row < g.M) {
           const int col = col0 + n * 16;
-          f32x4 v = t + bias_v[n];
+          f32x4 v = t;
+          if (g.bias) v += *(const f32x4*)(bias_lds + n * 64);
           if (kDrop) {   // training: Dropout behind the attention out projection
 #pragma unroll
             for (int e = 0; e < 4; ++e)
@@ -465,7 +474,7 @@ __global__ __launch_bounds__(64 * (NCONS + NLOAD), 3) void gemm_split_ps_kernel(
           if (EPI == EPI_RESID) v += res[u & 1][j];
           if (EPI == EPI_GELU_SPLIT) {   // the operand format of the next GEMM = this one's
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+            for (int e = 0; e < 4; ++e) v[e] = gelu_sigmoid(v[e]);
             store_act4<kMixed ? FMT_MIXED : FMT_SPLIT>(g.c_split + (size_t)row * g.ldc, col, v);
           } else if (EPI == EPI_ATOMIC) {
             float* dstc = g.c + (size_t)row * g.ldc + col;
