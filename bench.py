@@ -36,7 +36,7 @@ PEAK_HBM_GBS = 8000.0
 DTYPE_OF = {"precise": "bf16x3 (split-bf16 MFMA, fp32 accumulate)", "fast": "bf16",
             "mixed": "fp16 + e4m3 correction terms (fp16 MFMA main product, e4m3 K=128 MFMA cross terms, fp32 accumulate)"}
 MFMA_PASSES = {"precise": 3.0, "fast": 1.0, "mixed": 2.0}
-DEFAULT_PRECISION = "precise"
+DEFAULT_PRECISION = "mixed"
 
 
 def flops_per_pair(layers, heads):

@@ -105,6 +105,32 @@ def load_golden(name):
     return g, sd, batch
 
 
+def golden_pairs(g):
+    """The fixture's pair lists, one [P_i, 2] int64 array per image (the capped fixtures carry the reference's own
+    top-2048 selection, whose tie order a re-implementation need not reproduce: feed these to the predictor)."""
+    counts = [int(x) for x in g["pair_counts"]]
+    return np.split(g["pair_idx"], np.cumsum(counts)[:-1])
+
+
+def subset_images(g, batch, idxs):
+    """(batch, pair lists, row index into the fixture's logits) restricted to the images `idxs`: bounds the CPU time of the
+    oracle checks on the full-size fixtures (images are independent, eval-mode BatchNorm uses running statistics)."""
+    num_objs = [int(x) for x in batch["num_objs"]]
+    o0 = np.concatenate([[0], np.cumsum(num_objs)])
+    pairs = golden_pairs(g)
+    p0 = np.concatenate([[0], np.cumsum([len(p) for p in pairs])])
+    sub = {"num_objs": [num_objs[i] for i in idxs], "image_size": batch["image_size"]}
+    for k, v in batch.items():
+        if isinstance(v, np.ndarray) and v.shape[:1] == (o0[-1],):
+            sub[k] = np.concatenate([v[o0[i]:o0[i + 1]] for i in idxs])
+    rows = np.concatenate([np.arange(p0[i], p0[i + 1]) for i in idxs])
+    return sub, [pairs[i] for i in idxs], rows
+
+
+# images of the full-size fixtures the CPU oracle check walks (the GPU parity test takes all of them)
+ORACLE_IMAGE_SUBSET = {"sgcls_b12_n36_l4h8": [0, 11], "predcls_b12_n36_l6h6": [5], "ragged12_capped_l4h8": [0, 1, 2, 4, 7, 11]}
+
+
 @pytest.fixture(scope="session")
 def repo_root():
     return REPO

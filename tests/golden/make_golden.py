@@ -155,8 +155,19 @@ def load_sd(module, sd_np):
     assert all("criterion" in m or "CE_loss" in m for m in missing), missing
 
 
+def reference_test_pairs(props, num_objs):
+    """The reference's own RelationSampling.prepare_test_pairs (sampling.py:31-52) with the GT-box settings and
+    MAX_PROPOSAL_PAIR = 2048 (defaults.py): images with more candidate pairs keep the 2048 best by pred_scores product.
+    `pred_scores` comes from the portable RNG, one stream per image."""
+    from pysgg.modeling.roi_heads.relation_head.sampling import RelationSampling
+    for i, (p, n) in enumerate(zip(props, num_objs)):
+        p.add_field("pred_scores", torch.from_numpy(synth.uniform01(7, "pred_scores.%d" % i, n).astype(np.float32)))
+    samp = RelationSampling(0.5, False, 4, 1024, 0.25, 2048, True, False)   # max_proposal_pairs 2048, use_gt_box True
+    return samp.prepare_test_pairs(torch.device("cpu"), props)
+
+
 def run_case(P, cfg, BoxList, name, mode, layers, heads, num_objs, meet=False, dataset="VG",
-             train=False, experts=False):
+             train=False, experts=False, capped_pairs=False):
     n_obj, n_rel = configure(P, cfg, mode, layers, heads,
                              "VETOPredictor_MEET" if meet else "VETOPredictor", dataset)
     cfg.ENSEMBLE_LEARNING.EXPERT_GROUP = bool(experts)   # defaults.py:864 default True: 3 experts per group
@@ -172,11 +183,14 @@ def run_case(P, cfg, BoxList, name, mode, layers, heads, num_objs, meet=False, d
     model.eval()
     batch = synth.synthetic_batch(7, len(num_objs), list(num_objs), num_obj_cls=n_obj)
     props = make_proposals(BoxList, batch, mode)
-    pairs = test_pairs(batch["num_objs"])
+    pairs = reference_test_pairs(props, batch["num_objs"]) if capped_pairs else test_pairs(batch["num_objs"])
     rgb = torch.from_numpy(batch["roi_features"])
     dep = torch.from_numpy(batch["roi_depth_features"])
     out = {"layers": layers, "heads": heads, "num_objs": np.array(batch["num_objs"]),
-           "mode": mode, "dataset": dataset, "meet": int(meet), "experts": int(bool(experts))}
+           "mode": mode, "dataset": dataset, "meet": int(meet), "experts": int(bool(experts)),
+           "capped_pairs": int(bool(capped_pairs)), "pair_counts": np.array([len(p) for p in pairs]),
+           # the checkpoint contract: every key of the reference module's state dict
+           "state_dict_keys": np.array(sorted(model.state_dict().keys()))}
     with torch.no_grad():
         res = model(props, pairs, None, None, roi_features=rgb, roi_depth_features=dep)
     obj_dists, rel_dists = res[0], res[1]
@@ -486,6 +500,32 @@ def run_sgg_eval(cfg, BoxList, name):
     print(evaluator["eval_recall"].generate_print_string(mode) + evaluator["eval_pair_accuracy"].generate_print_string(mode), end="")
 
 
+# Full-size cases (round 2): the BASELINE.json workloads that round 1 only exercised at <= 14 objects per image.
+RAGGED12 = [1, 2, 64, 36, 7, 50, 13, 3, 46, 20, 36, 5]     # 64 / 50 / 46 objects exceed MAX_PROPOSAL_PAIR = 2048 candidates
+
+
+def predictor_cases(P, cfg, BoxList):
+    run_case(P, cfg, BoxList, "predcls_n10_l6h6", "predcls", 6, 6, [10], train=True)
+    run_case(P, cfg, BoxList, "predcls_n10_l4h8", "predcls", 4, 8, [10])
+    run_case(P, cfg, BoxList, "predcls_n36_l6h6", "predcls", 6, 6, [36])
+    run_case(P, cfg, BoxList, "predcls_n36_l4h8", "predcls", 4, 8, [36])
+    run_case(P, cfg, BoxList, "sgcls_n10_l6h6", "sgcls", 6, 6, [10])
+    run_case(P, cfg, BoxList, "ragged_l4h8", "predcls", 4, 8, [5, 1, 9])
+    run_case(P, cfg, BoxList, "meet_n10_l6h6", "predcls", 6, 6, [10], meet=True)
+    run_case(P, cfg, BoxList, "meet_sgcls_n10_l6h6", "sgcls", 6, 6, [10], meet=True)
+    run_case(P, cfg, BoxList, "meet_gqa_n6_l4h8", "predcls", 4, 8, [6], meet=True, dataset="GQA")
+    run_case(P, cfg, BoxList, "meetx_n10_l4h8", "predcls", 4, 8, [10], meet=True, experts=True)
+    # cfg-4 per-GPU workload: sgcls, 12 images x 36 objects
+    run_case(P, cfg, BoxList, "sgcls_b12_n36_l4h8", "sgcls", 4, 8, [36] * 12)
+    # the shipped architecture (configs/VETO_final.yaml: 6 layers x 6 heads) on the 12 x 36 batch
+    run_case(P, cfg, BoxList, "predcls_b12_n36_l6h6", "predcls", 6, 6, [36] * 12)
+    # cfg-5 heads at 36 objects: VG (5 group heads) and GQA (4 group heads)
+    run_case(P, cfg, BoxList, "meet_n36_l6h6", "predcls", 6, 6, [36], meet=True)
+    run_case(P, cfg, BoxList, "meet_gqa_n36_l4h8", "predcls", 4, 8, [36], meet=True, dataset="GQA")
+    # one ragged 12-image batch, 1 .. 64 objects, with the reference's own 2048-pair cap on three images
+    run_case(P, cfg, BoxList, "ragged12_capped_l4h8", "predcls", 4, 8, RAGGED12, capped_pairs=True)
+
+
 def main():
     torch.set_num_threads(8)
     P, cfg, BoxList = import_reference()
@@ -506,6 +546,9 @@ def main():
     if os.environ.get("GOLDEN_ONLY") == "sggeval":   # regenerate only the evaluator fixtures
         for name in SGG_EVAL_CASES:
             run_sgg_eval(cfg, BoxList, name)
+        return
+    if os.environ.get("GOLDEN_ONLY") == "predictor":   # regenerate only the predictor forward fixtures
+        predictor_cases(P, cfg, BoxList)
         return
     if os.environ.get("GOLDEN_ONLY") == "experts":   # regenerate only the EXPERT_GROUP fixtures
         run_postprocessor_vote(cfg, BoxList, "postvote_vg_c_n10", 10, "VG", "C")
@@ -528,20 +571,11 @@ def main():
     run_postprocessor_vote(cfg, BoxList, "postvote_vg_c_n10", 10, "VG", "C")
     run_postprocessor_vote(cfg, BoxList, "postvote_vg_u_n10", 10, "VG", "U")
     run_postprocessor_vote(cfg, BoxList, "postvote_gqa_c_n7", 7, "GQA", "C")
-    run_case(P, cfg, BoxList, "meetx_n10_l4h8", "predcls", 4, 8, [10], meet=True, experts=True)
     run_postprocessor_meet(cfg, BoxList, "postmeet_vg_n10", 10, "VG")
     run_postprocessor_meet(cfg, BoxList, "postmeet_gqa_n7", 7, "GQA")
     run_postprocessor(cfg, BoxList, "post_sgcls_ragged", [5, 1, 9], onehot=False)
     run_postprocessor(cfg, BoxList, "post_predcls_n36", [36], onehot=True)
-    run_case(P, cfg, BoxList, "predcls_n10_l6h6", "predcls", 6, 6, [10], train=True)
-    run_case(P, cfg, BoxList, "predcls_n10_l4h8", "predcls", 4, 8, [10])
-    run_case(P, cfg, BoxList, "predcls_n36_l6h6", "predcls", 6, 6, [36])
-    run_case(P, cfg, BoxList, "predcls_n36_l4h8", "predcls", 4, 8, [36])
-    run_case(P, cfg, BoxList, "sgcls_n10_l6h6", "sgcls", 6, 6, [10])
-    run_case(P, cfg, BoxList, "ragged_l4h8", "predcls", 4, 8, [5, 1, 9])
-    run_case(P, cfg, BoxList, "meet_n10_l6h6", "predcls", 6, 6, [10], meet=True)
-    run_case(P, cfg, BoxList, "meet_sgcls_n10_l6h6", "sgcls", 6, 6, [10], meet=True)
-    run_case(P, cfg, BoxList, "meet_gqa_n6_l4h8", "predcls", 4, 8, [6], meet=True, dataset="GQA")
+    predictor_cases(P, cfg, BoxList)
     # BETA_LOSS data (roi_relation_predictors.py:4058-4066 reads this pickle): 51 predicate counts
     import pickle
     with open(os.path.join(REF, "pred_counts.pkl"), "rb") as f:

@@ -87,11 +87,69 @@ def test_all_reduce_gradients_world2(tmp_path):
             assert r0["after_one"][k] is None and r1["after_one"][k] is None
             continue
         total = (a if a is not None else 0) + (b if b is not None else 0)
-        for r, mine in ((r0, a), (r1, b)):
-            if mine is None:
-                assert r["after_one"][k] is None        # a rank that had no gradient keeps none
-            else:
-                assert torch.allclose(r["after_one"][k], total / 2) and torch.allclose(r["after_many"][k], total)
+        for r in (r0, r1):   # DDP find_unused_parameters semantics: EVERY rank ends with the reduced gradient
+            assert torch.allclose(r["after_one"][k], total / 2) and torch.allclose(r["after_many"][k], total)
+
+
+def _train_worker(rank, world, port, out):
+    """Three optimizer steps of two replicas whose used-parameter sets differ per rank and per step
+    (tools/relation_train_net.py:372-380 wraps the model with find_unused_parameters=True for exactly this)."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(0)
+        net = torch.nn.ModuleList([torch.nn.Linear(6, 6) for _ in range(4)])   # branch b used when (rank + step + b) % 3 != 0
+        opt = torch.optim.SGD(net.parameters(), lr=0.1, momentum=0.9)
+        gen = torch.Generator().manual_seed(7 + rank)
+        for step in range(3):
+            opt.zero_grad(set_to_none=True)
+            x = torch.randn(5, 6, generator=gen)
+            y = sum(net[b](x).square().mean() for b in range(3) if (rank + step + b) % 3 != 0)   # net[3] is never used
+            y.backward()
+            vdist.all_reduce_gradients(net.parameters())
+            opt.step()
+        torch.save([p.detach().clone() for p in net.parameters()], out % rank)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_replicas_stay_identical_with_rank_dependent_unused_parameters(tmp_path):
+    out = str(tmp_path / "t%d.pt")
+    mp.spawn(_train_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    p0, p1 = torch.load(out % 0), torch.load(out % 1)
+    torch.manual_seed(0)
+    init = [p.detach().clone() for p in torch.nn.ModuleList([torch.nn.Linear(6, 6) for _ in range(4)]).parameters()]
+    for a, b in zip(p0, p1):
+        assert torch.equal(a, b)
+    assert not torch.equal(p0[0], init[0])                                   # the used branches moved ...
+    assert torch.equal(p0[6], init[6]) and torch.equal(p0[7], init[7])       # ... the never-used one did not
+
+
+def test_bench_self_launch_dry_run(tmp_path):
+    """`python bench.py --gpus 2` outside torch.distributed.run starts its own two ranks (gloo / CPU dry run of the launch,
+    rendezvous and all-gather plumbing: no model, no GPU) and relays ONE JSON line that shows both ranks took part."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, VETO_BENCH_DRYRUN="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["dry_run"] is True
+    assert d["gathered_rows"] == 2 * 12 * 36 * 35
+    # without the dry-run switch and without two GPUs the parent refuses cleanly before touching a device
+    env.pop("VETO_BENCH_DRYRUN")
+    if torch.cuda.device_count() < 2:
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], stdout=subprocess.PIPE,
+                           stderr=subprocess.PIPE, text=True, env=env, timeout=300)
+        assert r.returncode == 2 and "nothing was run" in r.stderr and r.stdout.strip() == ""
 
 
 def test_shard_images_partitions_exactly():

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import (golden_names, load_golden, load_post_golden, load_postmeet_golden, load_postvote_golden,
+from conftest import (golden_names, golden_pairs, load_golden, load_post_golden, load_postmeet_golden, load_postvote_golden,
                       post_golden_names, postmeet_golden_names, postvote_golden_names)
 
 pytestmark = pytest.mark.gpu
@@ -54,7 +54,9 @@ def test_split_gemm_against_fp64(m, n, k):
     bias = torch.randn(n, generator=g).to(dev)
     ref = (a.double() @ w.double().t() + bias.double())
     ws = torch.empty(lib.veto_debug_gemm_workspace_bytes(m, n, k), dtype=torch.uint8, device=dev)
-    for precision, tol in ((native.VETO_PRECISE, 3e-5), (native.VETO_FAST, 2e-2)):
+    for precision, tol in ((native.VETO_PRECISE, 3e-5), (native.VETO_MIXED, 1.5e-5), (native.VETO_FAST, 2e-2)):
+        if precision == native.VETO_MIXED and k % 64 != 0:
+            continue   # mixed rows come in blocks of 64 k's
         c = torch.full((m, n), float("nan"), device=dev)
         native.check(lib.veto_debug_gemm(None, a.data_ptr(), w.data_ptr(), bias.data_ptr(), c.data_ptr(), m, n, k,
                                          precision, ws.data_ptr(), ws.numel()))
@@ -88,18 +90,22 @@ def test_enumerate_pairs_bit_exact(n):
         assert torch.equal(got, ref)
 
 
+@pytest.mark.parametrize("precision", ["mixed", "precise"])
 @pytest.mark.parametrize("name", golden_names())
-def test_golden_parity(name):
-    """HIP path vs the committed outputs of the real reference."""
+def test_golden_parity(name, precision):
+    """HIP path vs the committed outputs of the real reference, in both parity-grade precision modes; the fixtures include the
+    full-size workloads: sgcls 12 x 36 (cfg-4 per GPU), L6/H6 12 x 36, MEET VG / GQA at 36 objects, a ragged 12-image batch with
+    1..64 objects and the reference's own 2048-pair cap."""
     from veto_amd import testing
     dev = _dev()
     g, sd, batch = load_golden(name)
     meet, mode = bool(int(g["meet"])), str(g["mode"])
-    cfg = testing.make_config(g["_layers"], g["_heads"], mode, meet, str(g["dataset"]))
+    cfg = testing.make_config(g["_layers"], g["_heads"], mode, meet, str(g["dataset"]), precision=precision)
     experts = bool(int(g.get("experts", 0)))
     cfg.ENSEMBLE_LEARNING.EXPERT_GROUP = experts
     model = testing.make_predictor(cfg, sd, dev)
-    out, pairs = _run(model, batch, mode, dev, debug=True)
+    given = [torch.from_numpy(p).to(dev) for p in golden_pairs(g)] if int(g["capped_pairs"]) else None
+    out, pairs = _run(model, batch, mode, dev, pairs=given, debug=True)
     assert np.array_equal(torch.cat(pairs).cpu().numpy(), g["pair_idx"])
     obj_dists, rel = out[0], out[1]
     assert np.array_equal(torch.cat([o.argmax(1) for o in obj_dists]).cpu().numpy(), g["obj_dists_argmax"])
@@ -115,10 +121,13 @@ def test_golden_parity(name):
     else:
         assert out[2] == {} and out[3] is None and out[4] is None and out[5] is None
         got = torch.cat(list(rel)).cpu().numpy()
-        assert [r.shape[0] for r in rel] == [max(n * (n - 1), 1) for n in batch["num_objs"]]
+        assert [r.shape[0] for r in rel] == [int(x) for x in g["pair_counts"]]
+        if not int(g["capped_pairs"]):
+            assert [r.shape[0] for r in rel] == [max(n * (n - 1), 1) for n in batch["num_objs"]]
         err = np.abs(got - g["rel_dists"]).max()
-        print("%s: logit max-abs-err %.3e" % (name, err))
+        print("%s [%s]: logit max-abs-err %.3e" % (name, precision, err))
         assert err <= LOGIT_TOL, (name, err)
+        assert err <= 3e-4, (name, err)     # the margin both modes are expected to keep (measured: 2-3e-5 / 4-9e-5)
         step = int(g["tokens_step"])
         tok = model.last_debug["tokens"][::step, :, ::9].cpu().numpy()
         assert np.abs(tok - g["tokens_sample"]).max() <= 2e-4
@@ -194,6 +203,71 @@ def test_full_size_properties():
     modelc = testing.make_predictor(testing.make_config(4, 8, max_chunk_pairs=4000), sd, dev)
     outc, _ = _run(modelc, batch, "predcls", dev)
     assert torch.equal(torch.cat(list(outc[1])), full)
+
+
+def _flat(rel):
+    """Predicate logits as one [P, n] tensor: list of per-image tensors (vanilla) or dict of group heads (MEET)."""
+    if isinstance(rel, dict):
+        return torch.cat([rel[k] for k in sorted(rel)], 1)
+    return torch.cat(list(rel))
+
+
+@pytest.mark.parametrize("mode,meet,dataset,layers,heads,precision", [
+    ("sgcls", False, "VG", 4, 8, "mixed"),        # cfg-4 per-GPU workload
+    ("predcls", False, "VG", 6, 6, "mixed"),      # the shipped architecture
+    ("predcls", True, "VG", 6, 6, "mixed"),       # cfg-5 heads, VG
+    ("sgcls", True, "GQA", 4, 8, "mixed"),        # GQA heads, hard-label sgcls embedding of the MEET trunk
+    ("predcls", False, "VG", 4, 8, "precise"),
+])
+def test_full_size_properties_other_modes(mode, meet, dataset, layers, heads, precision):
+    """12 images x 36 objects in the modes round 1 only ran small: every pair's logits depend on its own subject / object only,
+    so the batch result must equal -- bit for bit -- the single-image result, a permuted pair list must give permuted logits,
+    and a workspace chunk size that cuts inside images must change nothing (table layer 0, folded last layer and the chunk loop
+    all take part at this size)."""
+    from veto_amd import synth, testing
+    from veto_amd.meet_tables import NUM_CLASSES
+    dev = _dev()
+    n_objc = NUM_CLASSES[dataset][0]
+    if meet:
+        from conftest import GQA_MEET_GROUPS, VG_MEET_GROUPS
+        sd = synth.meet_state_dict(0, VG_MEET_GROUPS if dataset == "VG" else GQA_MEET_GROUPS, layers=layers, num_obj_cls=n_objc)
+    else:
+        sd = synth.predictor_state_dict(0, layers=layers, num_obj_cls=n_objc, num_rel_cls=NUM_CLASSES[dataset][1])
+    batch = synth.synthetic_batch(7, 12, 36, num_obj_cls=n_objc)
+    model = testing.make_predictor(testing.make_config(layers, heads, mode, meet, dataset, precision=precision), sd, dev)
+    out, pairs = _run(model, batch, mode, dev)
+    full = _flat(out[1])
+    assert full.shape[0] == 15120 and torch.isfinite(full).all()
+    one = synth.synthetic_batch(7, 1, 36, num_obj_cls=n_objc)
+    out1, _ = _run(model, one, mode, dev)
+    assert torch.equal(_flat(out1[1]), full[:1260])
+    perm = torch.randperm(1260, generator=torch.Generator().manual_seed(5)).to(dev)
+    outp, _ = _run(model, batch, mode, dev, pairs=[pairs[0]] + [pairs[1][perm]] + list(pairs[2:]))
+    assert torch.equal(_flat(outp[1])[1260:2520], full[1260:2520][perm])
+    modelc = testing.make_predictor(testing.make_config(layers, heads, mode, meet, dataset, precision=precision, max_chunk_pairs=3333), sd, dev)
+    outc, _ = _run(modelc, batch, mode, dev)
+    assert torch.equal(_flat(outc[1]), full)
+
+
+def test_ragged_capped_batch_properties():
+    """The ragged 12-image fixture (1 .. 64 objects, three images cut to 2048 pairs by the reference's own selection): chunking
+    invariance with a chunk size that splits the capped images, and image-by-image == batch, bit for bit."""
+    from veto_amd import testing
+    dev = _dev()
+    g, sd, batch = load_golden("ragged12_capped_l4h8")
+    given = [torch.from_numpy(p).to(dev) for p in golden_pairs(g)]
+    model = testing.make_predictor(testing.make_config(4, 8), sd, dev)
+    out, _ = _run(model, batch, "predcls", dev, pairs=given)
+    full = torch.cat(list(out[1]))
+    assert [int(r.shape[0]) for r in out[1]] == [int(x) for x in g["pair_counts"]]
+    modelc = testing.make_predictor(testing.make_config(4, 8, max_chunk_pairs=1000), sd, dev)
+    outc, _ = _run(modelc, batch, "predcls", dev, pairs=given)
+    assert torch.equal(torch.cat(list(outc[1])), full)
+    # image 2 (64 objects, capped) on its own
+    from conftest import subset_images
+    sub, sub_pairs, rows = subset_images(g, batch, [2])
+    outs, _ = _run(model, sub, "predcls", dev, pairs=[torch.from_numpy(sub_pairs[0]).to(dev)])
+    assert torch.equal(outs[1][0], full[torch.from_numpy(rows).to(dev)])
 
 
 def test_cpu_tensors_fail_loudly():
@@ -436,39 +510,6 @@ def test_repeated_runs_are_bit_identical():
         junk.normal_()                                   # perturbs cache state and timing between runs
         out, _ = _run(model, batch, "predcls", dev, pairs=pairs)
         assert torch.equal(torch.cat(list(out[1])), first), i
-
-
-def test_plain_gemm_variant_matches_persistent_variant(tmp_path):
-    """VETO_GEMM_VARIANT=plain (homogeneous waves, one workgroup per tile) is the A/B twin of the
-    persistent loader-wave kernel: same MFMA order, so bit-identical logits.  The variant is read once
-    per process, hence the subprocess."""
-    import subprocess, sys, os
-    script = tmp_path / "run_variant.py"
-    script.write_text(
-        "import sys, torch, numpy as np\n"
-        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
-        "from conftest import load_golden\n"
-        "from veto_amd import testing\n"
-        "from veto_amd.pairs import prepare_test_pairs\n"
-        "g, sd, batch = load_golden('predcls_n36_l4h8')\n"
-        "dev = torch.device('cuda:0')\n"
-        "m = testing.make_predictor(testing.make_config(4, 8), sd, dev)\n"
-        "props = testing.make_proposals(batch, 'predcls', dev)\n"
-        "pairs = prepare_test_pairs(dev, props)\n"
-        "with torch.no_grad():\n"
-        "    out = m(props, pairs, None, None, roi_features=torch.from_numpy(batch['roi_features']).to(dev),\n"
-        "            roi_depth_features=torch.from_numpy(batch['roi_depth_features']).to(dev))\n"
-        "np.save(sys.argv[1], out[1][0].cpu().numpy())\n" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
-                                                          os.path.dirname(os.path.abspath(__file__))))
-    res = {}
-    for variant in ("ps", "plain"):
-        out = str(tmp_path / (variant + ".npy"))
-        env = dict(os.environ, VETO_GEMM_VARIANT=variant)
-        subprocess.run([sys.executable, str(script), out], check=True, env=env, timeout=600)
-        res[variant] = np.load(out)
-    assert np.array_equal(res["ps"], res["plain"])
-    g, _, _ = load_golden("predcls_n36_l4h8")
-    assert np.abs(res["plain"] - g["rel_dists"]).max() <= LOGIT_TOL
 
 
 def test_large_image_with_pair_cap_against_oracle():

@@ -56,6 +56,29 @@ def test_state_dict_keys_equal_the_reference_names():
     assert [h.out_features for h in gq.model.rel_out] == [int(x) + 2 for x in g["group_sizes"]]
 
 
+@pytest.mark.parametrize("name", ["predcls_n36_l6h6", "predcls_n36_l4h8", "sgcls_n10_l6h6", "meet_n36_l6h6", "meet_gqa_n36_l4h8", "meetx_n10_l4h8"])
+def test_state_dict_keys_equal_the_reference_modules_own_key_list(name):
+    """The checkpoint contract, pinned directly: every predictor fixture stores sorted(model.state_dict()) of the REAL
+    reference module it was generated from; the mirror module must have exactly those keys."""
+    g, _, _ = load_golden(name)
+    predictor.set_embedding_provider(lambda names, d, k: torch.zeros(len(names), k))
+    meet = bool(int(g["meet"]))
+    cfg = testing.make_config(g["_layers"], g["_heads"], str(g["mode"]), meet, str(g["dataset"]))
+    cfg.ENSEMBLE_LEARNING.EXPERT_GROUP = bool(int(g["experts"]))
+    m = (predictor.VETOPredictor_MEET if meet else predictor.VETOPredictor)(cfg, 512)
+    ref_keys = [str(k) for k in g["state_dict_keys"]]
+    assert sorted(m.state_dict().keys()) == ref_keys, sorted(set(m.state_dict()) ^ set(ref_keys))
+
+
+def test_every_predictor_fixture_carries_the_round2_keys():
+    from conftest import golden_names
+    for name in golden_names():
+        g, _, _ = load_golden(name)
+        for k in ("experts", "capped_pairs", "pair_counts", "state_dict_keys"):
+            assert k in g, (name, k)
+        assert int(g["pair_counts"].sum()) == g["pair_idx"].shape[0]
+
+
 def test_modes_and_constructor_errors():
     cfg = default_config()
     cfg.MODEL.ROI_RELATION_HEAD.USE_GT_OBJECT_LABEL = False

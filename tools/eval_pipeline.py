@@ -60,6 +60,7 @@ for k, v in timers.items():
 # Throughput as an eval loop would run it: no per-batch synchronisation on the compute stream; the evaluators of
 # batch i run on a second stream (after an event recorded behind batch i's PostProcessor) while the predictor of
 # batch i+1 already executes, so their read-back only waits for their own kernels.
+evaluator.reset()
 main, side = torch.cuda.current_stream(dev), torch.cuda.Stream(dev)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
@@ -76,10 +77,12 @@ for i in range(steps + 1):
     if pending is not None:
         with torch.cuda.stream(side):
             side.wait_event(pending[1])
-            res = evaluator.evaluate_boxlists(gts, pending[0])
+            evaluator.update_boxlists(gts, pending[0])      # per-relation match ranks accumulate over the split
     pending = cur
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / steps
 print("pipelined: %.2f ms per %d-image batch -> %.0f images/s, %.0f pairs/s end to end" %
       (dt * 1e3, n_img, n_img / dt, n_img * n_obj * (n_obj - 1) / dt))
+res = evaluator.finalize()                                   # ONE fold over every image seen, as the reference's evaluators do
+print("dataset-level metrics over %d images:" % res["images_evaluated"])
 print(evaluator.generate_print_string(res), end="")

@@ -71,7 +71,9 @@ def default_config():
     c.GLOVE_DIR = ""
     # veto_amd extensions (absent from the reference config; read with getattr defaults)
     c.VETO_AMD = CfgNode()
-    c.VETO_AMD.PRECISION = "precise"              # "precise" (3-term split bf16) | "fast" (bf16)
+    # what the token-row Linears compute in: "mixed" (fp16 main product + e4m3 correction terms, default: 2/3 of the matrix-pipe
+    # time of "precise" at 5-9e-5 logit error) | "precise" (3-term split bf16, 2-3e-5) | "fast" (single bf16 pass, ~1e-2: reported only)
+    c.VETO_AMD.PRECISION = "mixed"
     c.VETO_AMD.MAX_CHUNK_PAIRS = 0
     c.VETO_AMD.TRAIN_FORWARD_ONLY = False         # True: .train() runs the forward + losses (no backward exists yet)
     return c

@@ -1,7 +1,20 @@
-// Split-bf16 MFMA GEMM, persistent + wave-specialised variant.
+// MFMA GEMM for the token-wise Linear layers of the VETO relation transformer (to_qkv / to_out / FeedForward of
+// model_veto.py:78-96,137-143 and the per-object patch projection derived from model_veto.py:103-113):
 //
-// Same tile (256x192x32), split-row operands, LDS image, swizzle, MFMA order and epilogue as
-// gemm_split.hip (results are bit-identical); two structural differences:
+//   C[M,N] = A[M,K] . W[N,K]^T        (nn.Linear layout: both operands K-contiguous)
+//
+// Operands are split rows or mixed rows (common.h).
+//   NTERMS == 3 (VETO_PRECISE): split rows, A_hi.W_hi + A_lo.W_hi + A_hi.W_lo on v_mfma_f32_16x16x32_bf16, fp32 accumulate
+//                -> ~2^-16 relative (plain bf16 misses the 1e-3 logit bar by 14x).
+//   NTERMS == 1 (VETO_FAST): A_hi.W_hi only (reported, never trusted).
+//   NTERMS == 2 (VETO_MIXED): mixed rows, fp16 main product + e4m3 correction terms (below).
+//
+// Tile 256(M) x 192(N) x 32(K), 8 consumer waves (4 along M x 2 along N) + 4 loader waves.  The MFMA is issued "swapped"
+// (weights as the A operand, activations as the B operand) so that each lane ends up with 4 CONSECUTIVE output columns of one
+// row -> 16-byte epilogue accesses.  LDS stages are filled by global_load_lds_dwordx4 (no VGPR staging): one wave-instruction
+// moves 8 rows x 128 B (8 full cache lines).  Inside a row the eight 16-byte slots are XOR-swizzled with (row>>1)&7 -- on the
+// per-lane SOURCE address of the DMA (its LDS destination is lane-linear) and again on the ds_read_b128 address -- which makes
+// every fragment read bank-conflict free.
 //
 //  * Loader waves.  4 of the 12 waves of a workgroup only issue the LDS-DMA (global_load_lds) of
 //    the next stage; the 8 consumer waves run nothing but ds_read_b128 + MFMA between barriers.
@@ -425,9 +438,8 @@ __global__ __launch_bounds__(64 * (NCONS + NLOAD), 3) void gemm_split_ps_kernel(
     // 64 separate 16-byte pieces.  kEpiT: a ds_bpermute per value (lane 4r+q takes the value of lane 16q+r)
     // turns that into lane = (row r = l>>2, chunk q = l&3): every quad of lanes writes 64 contiguous bytes of
     // one row, and the residual is read the same way.  Values and the order of the additions are unchanged.
-    // Stores are not waited for.  EPI_RESID: the residual reads of row group m+1 are issued BEFORE the
-    // stores of group m (vmcnt counts loads and stores in issue order, so a load issued after a store would
-    // have to wait for it; and c may alias resid, which stops the compiler from hoisting the loads by itself).
+    // Stores are not waited for.  EPI_RESID: every residual read of the tile is issued before its first store (two
+    // phases, below; c may alias resid, which stops the compiler from moving loads across stores by itself).
     // (the lane id is laundered through an empty asm so that the epilogue's lane-dependent offsets are recomputed per tile
     // instead of being hoisted out of the persistent loop, where they would stay live -- and spill -- across the k-loop)
     int lane_e = lane;
@@ -462,7 +474,13 @@ __global__ __launch_bounds__(64 * (NCONS + NLOAD), 3) void gemm_split_ps_kernel(
           for (int e = 0; e < 4; ++e)
             t[e] = __int_as_float(__builtin_amdgcn_ds_bpermute(perm_addr, __float_as_int(acc[n][m][e])));
         }
-        if (row < g.M) {
+        if (EPI == EPI_RESID && !kDrop) {
+          // every lane consumes its residual load (rows past M read a clamped row): a load left pending on a skipped
+          // path would have to be waited for -- behind this tile's stores -- when the k-loop reuses its register
+          f32x4 v = t + res[u & 1][j];
+          if (g.bias) v += *(const f32x4*)(bias_lds + n * 64);
+          acc[n][m] = v;    // stored below, after the last residual load
+        } else if (row < g.M) {
           const int col = col0 + n * 16;
           f32x4 v = t;
           if (g.bias) v += *(const f32x4*)(bias_lds + n * 64);
@@ -480,8 +498,29 @@ __global__ __launch_bounds__(64 * (NCONS + NLOAD), 3) void gemm_split_ps_kernel(
             float* dstc = g.c + (size_t)row * g.ldc + col;
 #pragma unroll
             for (int e = 0; e < 4; ++e) unsafeAtomicAdd(dstc + e, v[e]);
+          } else if (EPI == EPI_RESID) {
+            acc[n][m] = v;    // (training, dropout form) stored below, after the last residual load
           } else {
             *(f32x4*)(g.c + (size_t)row * g.ldc + col) = v;
+          }
+        }
+      }
+    }
+    if (EPI == EPI_RESID) {
+      // Two phases: loads, stores and LDS-DMA share ONE in-order counter per wave, so a residual load issued behind a store
+      // cannot return before that store has drained -- and with every CU in its epilogue at once the stores drain slowly (the
+      // store-only epilogue of a 256 x 192 tile takes ~10 k cycles).  Interleaved (load group m+1, store group m) the eight units
+      // of a tile paid that round trip one after the other (~24 k cycles per tile); with every store behind the last load the
+      // loads see an empty queue and the stores of this tile drain under the next tile's k-loop.
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int m = u >> 1, h = u & 1;
+        const int row = row0 + m * 16;
+        if (row < g.M) {
+#pragma unroll
+          for (int j = 0; j < 3; ++j) {
+            const int n = h * 3 + j;
+            *(f32x4*)(g.c + (size_t)row * g.ldc + col0 + n * 16) = acc[n][m];
           }
         }
       }
@@ -523,6 +562,17 @@ hipError_t launch_ps_terms(GemmArgs g, int epi, int nblocks, hipStream_t s) {
 }
 
 }  // namespace
+
+// Row padding every contiguous A-operand buffer must have.
+int gemm_rows_padded(int m) { return (m + BM - 1) / BM * BM; }
+
+hipError_t launch_gemm_split(GemmArgs g, int epi, int precision, hipStream_t s) {
+  if (g.N % BN != 0 || g.K % BK != 0 || g.M <= 0) return hipErrorInvalidValue;
+  if (g.lda == 0) g.lda = 2 * (long)g.K;
+  g.tiles_m = (g.M + BM - 1) / BM;
+  g.tiles_n = g.N / BN;
+  return launch_gemm_split_ps(g, epi, precision, s);
+}
 
 // g.tiles_m / g.tiles_n / g.lda are already filled by launch_gemm_split.
 hipError_t launch_gemm_split_ps(GemmArgs g, int epi, int precision, hipStream_t s) {

@@ -42,7 +42,7 @@ struct GemmArgs {
 };
 
 int gemm_rows_padded(int m);
-// VETO_GEMM_VARIANT: "ps" (persistent + loader waves) or "plain" (homogeneous waves); same results.
+// precision: 0 = three split-bf16 terms, 1 = one; g.fmt == FMT_MIXED selects the fp16 + e4m3 kernel regardless
 hipError_t launch_gemm_split(GemmArgs g, int epi, int precision, hipStream_t s);
 hipError_t launch_gemm_split_ps(GemmArgs g, int epi, int precision, hipStream_t s);
 

@@ -29,11 +29,14 @@ __global__ __launch_bounds__(256) void ce_rows_kernel(CeLossArgs a) {
   for (int c = lane; c < a.C; c += 64) sum += expf(z[c] - mx);
   sum = wave_sum(sum);
   if (lane == 0) {
-    const int y = (int)a.labels[i];
+    // a label outside [0, C) -- nn.CrossEntropyLoss's ignore_index (-100) in particular -- is an ignored row: weight 0
+    const long yl = a.labels[i];
+    const bool valid = yl >= 0 && yl < a.C;
+    const int y = valid ? (int)yl : 0;
     const float lse = mx + logf(sum);
-    const float w = a.weight ? a.weight[y] : 1.f;
+    const float w = valid ? (a.weight ? a.weight[y] : 1.f) : 0.f;
     a.lse[i] = lse;
-    a.nll_w[i] = w * (lse - z[y]);
+    a.nll_w[i] = valid ? w * (lse - z[y]) : 0.f;
     a.w_row[i] = w;
   }
 }
@@ -61,7 +64,8 @@ __global__ __launch_bounds__(256) void ce_grad_kernel(CeLossArgs a) {
   if (i >= a.n) return;
   const long r = a.rows ? a.rows[i] : i;
   const float* z = a.logits + r * a.ld;
-  const int y = (int)a.labels[i];
+  const long yl = a.labels[i];
+  const int y = (yl >= 0 && yl < a.C) ? (int)yl : -1;      // ignored rows have w_row = 0: zero gradient
   const float scale = a.w_row[i] * a.inv_wsum[0], lse = a.lse[i];
   float* g = a.grad + (size_t)i * a.C;
   for (int c = lane; c < a.C; c += 64) g[c] = (expf(z[c] - lse) - (c == y ? 1.f : 0.f)) * scale;

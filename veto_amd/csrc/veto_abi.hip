@@ -843,6 +843,7 @@ int veto_forward_train(veto_handle_t h, void* stream, const veto_inputs_t* in, c
   if ((rc = check_train_opts(opts))) return rc;
   if (!out_logits) return fail(VETO_ERR_INVALID, "null out_logits");
   hipStream_t s = (hipStream_t)stream;
+  HIP_TRY(hipSetDevice(h->cfg.device));
   if (h->dirty) { rc = finalize_weights(h, s); if (rc) return rc; }
   const int n_obj = in->n_obj, n_pair = in->n_pair, L = h->cfg.layers, H = h->cfg.heads, n_out = h->cfg.num_out;
   const int M = n_pair * kTokens;
@@ -938,6 +939,10 @@ int veto_backward(veto_handle_t h, void* stream, const veto_inputs_t* in, const 
   if ((rc = check_train_opts(opts))) return rc;
   if (!dlogits || !grads) return fail(VETO_ERR_INVALID, "null gradient pointer");
   hipStream_t s = (hipStream_t)stream;
+  HIP_TRY(hipSetDevice(h->cfg.device));
+  // the backward reads the derived operands the matching forward used: a weight upload in between would pair this
+  // workspace's activations with different weights
+  if (h->dirty) return fail(VETO_ERR_WEIGHTS, "weights were reloaded between veto_forward_train and veto_backward");
   const int n_obj = in->n_obj, n_pair = in->n_pair, L = h->cfg.layers, H = h->cfg.heads, n_out = h->cfg.num_out, E = h->cfg.embed_dim;
   const int M = n_pair * kTokens;
   TrainWs ws = carve_train((char*)workspace, h, n_obj, n_pair);

@@ -55,9 +55,14 @@ def all_reduce_gradients(params, group=None, average=True, bucket_bytes=256 << 2
     find_unused_parameters=True); for the predictor alone that is one all-reduce of ~70 MB fp32 per step.  On the
     point-to-point xGMI mesh a ring all-reduce is bound by one link (~153 GB/s), so the gradients are packed into
     as few, as large messages as possible: one flat bucket for the whole predictor by default (bucket_bytes only
-    bounds the staging copy), ~1 ms against a ~100 ms step -- nothing to overlap.  Parameters without a gradient
-    (the reference's unused `obj_embed2` / `bbox_embed`) contribute zeros, so that every rank sends the same layout,
-    and stay without a gradient afterwards.  Returns the number of collectives issued."""
+    bounds the staging copy), ~1 ms against a ~100 ms step -- nothing to overlap.
+
+    Same contract as DDP with find_unused_parameters=True: a parameter that received a gradient on ANY rank ends up
+    with the same (summed / averaged, absent ranks counting as zero) gradient on EVERY rank -- a rank that had none
+    gets one allocated -- so replicas that start equal stay equal under any optimizer.  A parameter without a gradient
+    on every rank (the reference's unused `obj_embed2` / `bbox_embed`) stays without one.  One "has a gradient" flag per
+    parameter travels at the tail of the same bucket, so this costs no extra collective.
+    Returns the number of collectives issued."""
     if not dist.is_available() or not dist.is_initialized():
         return 0
     world = dist.get_world_size(group)
@@ -73,19 +78,26 @@ def all_reduce_gradients(params, group=None, average=True, bucket_bytes=256 << 2
             nbytes += params[j].numel() * 4
             j += 1
         bucket = params[i:j]
-        flat = torch.zeros(sum(p.numel() for p in bucket), dtype=torch.float32, device=bucket[0].device)
+        n = sum(p.numel() for p in bucket)
+        flat = torch.zeros(n + len(bucket), dtype=torch.float32, device=bucket[0].device)
         off = 0
-        for p in bucket:
+        for k, p in enumerate(bucket):
             if p.grad is not None:
                 flat[off:off + p.numel()] = p.grad.reshape(-1)
+                flat[n + k] = 1.0
             off += p.numel()
         dist.all_reduce(flat, group=group)
         if average:
-            flat /= world
+            flat[:n] /= world
+        used = flat[n:].tolist()          # one small read-back per bucket; the step is ~100 ms
         off = 0
-        for p in bucket:
-            if p.grad is not None:
-                p.grad.copy_(flat[off:off + p.numel()].view_as(p.grad))
+        for k, p in enumerate(bucket):
+            if used[k] > 0:
+                g = flat[off:off + p.numel()].view_as(p)
+                if p.grad is None:
+                    p.grad = g.clone()
+                else:
+                    p.grad.copy_(g)
             off += p.numel()
         calls += 1
         i = j

@@ -39,6 +39,69 @@ class SGGEvaluator:
             raise RuntimeError("veto_amd.SGGEvaluator runs only on a HIP device (got %s)" % self.device)
         self.zeroshot = _t(zeroshot_triplet, torch.int64, self.device).reshape(-1, 3).contiguous()
         self._workspace = None
+        self.reset()
+
+    # ---- dataset-level accumulation (the reference's evaluators keep per-image lists over the WHOLE split and fold them once,
+    # sgg_eval.py:133-136,209,331-336,420-466; per-batch results cannot be averaged into mR@K / A@K afterwards) --------------
+    def reset(self):
+        """Forgets everything accumulated by update()."""
+        self._acc = []        # per evaluated image: (gc_rank, ng_rank, acc_rank, zeroshot flags, GT predicate of every GT relation)
+
+    def update(self, images):
+        """Scores one batch on the device (same launch as evaluate()) and keeps its per-relation match ranks for finalize().
+        Returns the batch's own result dict."""
+        res = self.evaluate(images)
+        for im, r in zip(images, res["per_image"]):
+            if r is None:
+                continue
+            gt_pred = _t(im["gt_rels"], torch.int64, "cpu").reshape(-1, 3)[:, 2].numpy()
+            self._acc.append((r["gc_rank"], r["ng_rank"], r["acc_rank"], r["zeroshot"], gt_pred))
+        return res
+
+    def update_boxlists(self, groundtruths, predictions):
+        res = self.evaluate_boxlists(groundtruths, predictions)
+        for gt, r in zip(groundtruths, res["per_image"]):
+            if r is None:
+                continue
+            gt_pred = _t(gt.get_field("relation_tuple"), torch.int64, "cpu").reshape(-1, 3)[:, 2].numpy()
+            self._acc.append((r["gc_rank"], r["ng_rank"], r["acc_rank"], r["zeroshot"], gt_pred))
+        return res
+
+    def finalize(self):
+        """Folds every image seen by update() the way the reference does at the end of the split: np.mean of the per-image
+        recalls, A@K = mean(hits) / mean(counts), mean recall from the per-image per-class hit ratios."""
+        C = self.num_rel
+        res = {"images_evaluated": len(self._acc)}
+        lists = {n: {k: [] for k in KS} for n in ("recall", "recall_nogc", "zeroshot_recall", "acc_hit", "acc_cnt")}
+        coll = {n: {k: [[] for _ in range(C)] for k in KS} for n in ("mean_recall", "ng_mean_recall")}
+        n_zs = 0
+        for gc, ng, ac, zs, gt_pred in self._acc:
+            G = len(gc)
+            n_zs += bool(zs.any())
+            for k in KS:
+                hit, nghit = gc < k, ng < k
+                lists["recall"][k].append(float(hit.sum()) / float(G))
+                lists["recall_nogc"][k].append(float(nghit.sum()) / float(G))
+                if zs.any():
+                    lists["zeroshot_recall"][k].append(float((hit & zs).sum()) / float(zs.sum()))
+                lists["acc_hit"][k].append(float((ac < k).sum()))
+                lists["acc_cnt"][k].append(float(G))
+                for name, h in (("mean_recall", hit), ("ng_mean_recall", nghit)):
+                    cnt = np.bincount(gt_pred, minlength=C)
+                    hc = np.bincount(gt_pred[h], minlength=C)
+                    for n in np.nonzero(cnt[1:])[0] + 1:
+                        coll[name][k][n].append(float(hc[n]) / float(cnt[n]))
+        res["images_with_zeroshot"] = n_zs
+        for name in ("recall", "recall_nogc", "zeroshot_recall"):
+            res[name] = {k: (float(np.mean(v)) if len(v) else float("nan")) for k, v in lists[name].items()}
+            res[name + "_list"] = lists[name]
+        res["accuracy"] = {k: (float(np.mean(lists["acc_hit"][k]) / np.mean(lists["acc_cnt"][k])) if lists["acc_cnt"][k] else float("nan"))
+                           for k in KS}
+        for name in ("mean_recall", "ng_mean_recall"):
+            res[name + "_list"] = {k: [float(np.mean(coll[name][k][n + 1])) if coll[name][k][n + 1] else 0.0 for n in range(C - 1)]
+                                   for k in KS}
+            res[name] = {k: sum(res[name + "_list"][k]) / float(C - 1) for k in KS}
+        return res
 
     def evaluate_boxlists(self, groundtruths, predictions):
         """vg_eval.py:470-498: unpack the fields of the GT / prediction BoxLists."""

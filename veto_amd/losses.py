@@ -35,6 +35,11 @@ def relation_ce_loss(logits, labels, weight=None, rows=None, want_grad=False):
         raise ValueError("labels must have one entry per logit row")
     if weight is not None:
         weight = weight.to(device=dev, dtype=torch.float32).contiguous()
+    if n == 0:
+        # no sampled relation for this head (a MEET tail group on a small batch): the reference's CE_loss over zero rows is
+        # the mean of nothing, NaN (roi_relation_predictors.py:3842-3846); same value here, an empty gradient, no launch
+        return (torch.full((1,), float("nan"), dtype=torch.float32, device=dev),
+                torch.zeros((0, C), dtype=torch.float32, device=dev) if want_grad else None)
     loss = torch.empty(1, dtype=torch.float32, device=dev)
     grad = torch.empty((n, C), dtype=torch.float32, device=dev) if want_grad else None
     ws = torch.empty(lib.veto_ce_loss_workspace_bytes(n), dtype=torch.uint8, device=dev)

@@ -12,6 +12,7 @@ There is no PyTorch or CPU fallback; if the library is missing, or the inputs ar
 device, forward raises.
 """
 import ctypes
+import weakref
 import warnings
 
 import torch
@@ -71,7 +72,7 @@ def _mode(config):
 
 def _precision(config):
     ext = getattr(config, "VETO_AMD", None)
-    name = getattr(ext, "PRECISION", "precise") if ext is not None else "precise"
+    name = getattr(ext, "PRECISION", "mixed") if ext is not None else "mixed"
     modes = {"precise": native.VETO_PRECISE, "fast": native.VETO_FAST, "mixed": native.VETO_MIXED}
     if name not in modes:
         raise ValueError("VETO_AMD.PRECISION must be one of %s, got %r" % (sorted(modes), name))
@@ -192,11 +193,14 @@ class _NativeForward:
         self._num_out = sum(h.out_features for h in head_modules)
         self._precision = _precision(config)
         self._max_chunk = _max_chunk(config)
+        ext = getattr(config, "VETO_AMD", None)
+        self._allow_detached_roi = bool(getattr(ext, "ALLOW_DETACHED_ROI_GRAD", False)) if ext is not None else False
         object.__setattr__(self, "_trunk", trunk)  # not a sub-module registration
         self._engine = None
         self._engine_device = None
         self._uploaded = None
         self._workspace = None
+        self.register_load_state_dict_post_hook(lambda module, incompatible_keys: module.refresh_weights())
 
     def _weight_tensors(self):
         t = self._trunk
@@ -212,6 +216,15 @@ class _NativeForward:
     def _weights_version(self):
         return tuple((p.data_ptr(), p._version) for p in list(self._trunk.parameters()) + list(self._trunk.buffers()))
 
+    def refresh_weights(self):
+        """Forces the next call to re-upload every weight (and rebuild the engine's derived operands: split / mixed rows,
+        Wqkv diag(gamma), Mcat, Ncat).  Weight changes are detected through (data_ptr, Tensor._version), which writes
+        through `.data` (`p.data.copy_()`, EMA updates, hand-written optimisers, some checkpoint loaders) do NOT bump:
+        call this after such a write in eval mode.  In training mode and after load_state_dict it happens by itself."""
+        self._uploaded = None
+
+    invalidate = refresh_weights
+
     def _ensure_engine(self, device):
         if device.type != "cuda":
             raise RuntimeError("veto_amd: the predictor runs only on a HIP device (got %s); there is no CPU path" % device)
@@ -224,6 +237,8 @@ class _NativeForward:
             self._engine_device = idx
             self._uploaded = None
         ver = self._weights_version()
+        if self._trunk.training:
+            self._uploaded = None      # a training step changes the weights: never trust the version stamp there
         if self._uploaded != ver:
             tensors = self._weight_tensors()
             stream = torch.cuda.current_stream(device).cuda_stream
@@ -360,8 +375,22 @@ class _NativeForward:
 
     def _run_native_train_grad(self, proposals, rel_pair_idxs, roi_features, roi_depth_features, labels, logits=None):
         """Training-mode forward whose result carries an autograd graph: logits [sum P, num_out]."""
+        if torch.is_grad_enabled() and (roi_features.requires_grad or roi_depth_features.requires_grad) and not self._allow_detached_roi:
+            raise NotImplementedError(
+                "veto_amd: the training path has no input gradient for roi_features / roi_depth_features yet (veto_backward stops at "
+                "the per-object patch table), so a module that produced them -- the reference trains its depth backbone through "
+                "roi_depth_features, tools/relation_train_net.py:166-170 -- would silently get no gradient.  Detach the tensors, or "
+                "set VETO_AMD.ALLOW_DETACHED_ROI_GRAD = True to train the predictor alone.")
         spec = self._train_param_spec()
         return _TrainFn.apply(self, (proposals, rel_pair_idxs, roi_features, roi_depth_features, labels, logits), *[s[0] for s in spec])
+
+
+class _WsToken:
+    """Ownership of the cached training workspace by one (forward, backward) pair; see _TrainFn.forward."""
+    __slots__ = ("done", "__weakref__")
+
+    def __init__(self):
+        self.done = False
 
 
 class _TrainFn(torch.autograd.Function):
@@ -380,14 +409,21 @@ class _TrainFn(torch.autograd.Function):
         need = lib.veto_train_workspace_bytes(eng.handle, inp.n_obj, inp.n_pair)
         # tens of GB: keep one workspace on the module and hand it to the next step once its backward has run (an
         # allocation of this size goes to the driver every time, and releasing it synchronises the device)
+        # The cached workspace belongs to at most one forward whose backward has not run yet.  Ownership is a token held by
+        # that forward's autograd context and seen here through a weak reference: a forward that never gets a backward
+        # (torch.no_grad(), a loss-only validation pass, an exception in between) drops its context, the token dies with it
+        # and the workspace is free again -- no sticky flag.
         ws = owner.__dict__.get("_train_ws")
-        if ws is None or ws.numel() < need or ws.device != device or owner.__dict__.get("_train_ws_busy", False):
+        holder = owner.__dict__.get("_train_ws_owner")
+        busy = holder is not None and holder() is not None and not holder().done
+        if ws is None or ws.numel() < need or ws.device != device or busy:
             ws = torch.empty(need, dtype=torch.uint8, device=device)
-            if not owner.__dict__.get("_train_ws_busy", False):
+            if not busy:
                 owner.__dict__["_train_ws"] = ws
-        ctx.owns_cached_ws = ws is owner.__dict__.get("_train_ws")
-        if ctx.owns_cached_ws:
-            owner.__dict__["_train_ws_busy"] = True
+        ctx.ws_token = None
+        if ws is owner.__dict__.get("_train_ws"):
+            ctx.ws_token = _WsToken()
+            owner.__dict__["_train_ws_owner"] = weakref.ref(ctx.ws_token)
         out = torch.empty((inp.n_pair, owner._num_out), dtype=torch.float32, device=device)
         stream = torch.cuda.current_stream(device)
         native.check(lib.veto_forward_train(eng.handle, ctypes.c_void_p(stream.cuda_stream), ctypes.byref(inp), ctypes.byref(opts),
@@ -414,8 +450,8 @@ class _TrainFn(torch.autograd.Function):
         native.check(lib.veto_backward(eng.handle, ctypes.c_void_p(stream.cuda_stream), ctypes.byref(ctx.inp), ctypes.byref(ctx.opts),
                                        ctypes.c_void_p(ctx.ws.data_ptr()), ctx.ws.numel(), ctypes.c_void_p(dlogits.data_ptr()),
                                        ctypes.c_void_p(flat.data_ptr())))
-        if ctx.owns_cached_ws:
-            owner.__dict__["_train_ws_busy"] = False
+        if ctx.ws_token is not None:
+            ctx.ws_token.done = True
         offsets = eng.weight_offsets()
         grads = []
         for prm, name, row0, rows in ctx.spec:

@@ -8,7 +8,7 @@ from .config import default_config
 from .structures import BoxList
 
 
-def make_config(layers, heads, mode="predcls", meet=False, dataset="VG", precision="precise", max_chunk_pairs=0):
+def make_config(layers, heads, mode="predcls", meet=False, dataset="VG", precision="mixed", max_chunk_pairs=0):
     cfg = default_config()
     rh = cfg.MODEL.ROI_RELATION_HEAD
     rh.PREDICTOR = "VETOPredictor_MEET" if meet else "VETOPredictor"
