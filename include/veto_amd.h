@@ -326,6 +326,10 @@ typedef struct veto_train_opts {
   int32_t struct_size;
   float p_pos, p_emb, p_attn;
   uint64_t seed;
+  /* veto_backward only, optional (NULL = not wanted): gradients of the loss w.r.t. the ROI maps, device [n_obj, 256, 8, 8]
+   * fp32 each.  The reference trains its depth backbone through roi_depth_features (tools/relation_train_net.py:166-170). */
+  float* d_roi_rgb;
+  float* d_roi_depth;
 } veto_train_opts_t;
 
 size_t veto_train_workspace_bytes(veto_handle_t h, int32_t n_obj, int32_t n_pair);

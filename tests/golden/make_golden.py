@@ -388,8 +388,12 @@ def run_train_losses(P, cfg, BoxList, name, meet, beta_loss=False, dataset="VG",
         w *= float(n_rel) / np.sum(w)
         model.criterion_loss_rel = torch.nn.CrossEntropyLoss(weight=torch.FloatTensor(w))
     random.seed(1)
+    # the ROI maps are leaves of the autograd graph too: the reference trains its depth backbone through roi_depth_features
+    # (tools/relation_train_net.py:166-170), so their gradients are part of the training contract
+    roi_in = {"roi_features": torch.from_numpy(batch["roi_features"]).requires_grad_(True),
+              "roi_depth_features": torch.from_numpy(batch["roi_depth_features"]).requires_grad_(True)}
     res = model(props, pairs, list(rel_labels.split([len(p) for p in pairs])), None,
-                roi_features=torch.from_numpy(batch["roi_features"]), roi_depth_features=torch.from_numpy(batch["roi_depth_features"]))
+                roi_features=roi_in["roi_features"], roi_depth_features=roi_in["roi_depth_features"])
     for h in hooks:
         h.remove()
     out = {"labels": labels, "meet": int(meet), "dataset": dataset, "beta_loss": int(beta_loss), "num_objs": np.array(num_objs),
@@ -405,6 +409,12 @@ def run_train_losses(P, cfg, BoxList, name, meet, beta_loss=False, dataset="VG",
         out["gradnorm_" + pname] = np.array(float(np.linalg.norm(gflat.astype(np.float64))))
         out["gradsample_" + pname] = gflat[::step].copy()
         out["gradstep_" + pname] = np.array(step)
+    for iname, t in roi_in.items():
+        gflat = t.grad.detach().reshape(-1).numpy()
+        step = max(1, gflat.size // 2048)
+        out["inputgradnorm_" + iname] = np.array(float(np.linalg.norm(gflat.astype(np.float64))))
+        out["inputgradsample_" + iname] = gflat[::step].copy()
+        out["inputgradstep_" + iname] = np.array(step)
     for k, v in captured.items():
         out["logits_%d" % k] = v.numpy()
     for k, v in res[2].items():

@@ -264,13 +264,24 @@ def test_training_backward_matches_reference_gradients(name):
     pairs = prepare_test_pairs(dev, props)
     rel_labels = list(torch.from_numpy(g["labels"]).to(dev).split([int(p.shape[0]) for p in pairs]))
     random.seed(1)
-    out = model(props, pairs, rel_labels, None, roi_features=torch.from_numpy(batch["roi_features"]).to(dev),
-                roi_depth_features=torch.from_numpy(batch["roi_depth_features"]).to(dev))
+    roi_in = {"roi_features": torch.from_numpy(batch["roi_features"]).to(dev).requires_grad_(True),
+              "roi_depth_features": torch.from_numpy(batch["roi_depth_features"]).to(dev).requires_grad_(True)}
+    out = model(props, pairs, rel_labels, None, roi_features=roi_in["roi_features"], roi_depth_features=roi_in["roi_depth_features"])
     for key, val in out[2].items():
         ref = float(g["loss_" + key])
         assert abs(float(val.detach()) - ref) < 2e-4 * max(1.0, abs(ref)), (key, float(val.detach()), ref)
     sum(out[2].values()).backward()
     torch.cuda.synchronize()
+    # input gradients: the ROI maps are leaves of the reference's graph (its depth backbone trains through them)
+    for iname, t in roi_in.items():
+        assert t.grad is not None and t.grad.shape == t.shape, iname
+        got = t.grad.detach().reshape(-1).cpu().numpy().astype(np.float64)
+        ref_norm, step = float(g["inputgradnorm_" + iname]), int(g["inputgradstep_" + iname])
+        ref_s = g["inputgradsample_" + iname].astype(np.float64)
+        scale = max(np.abs(ref_s).max(), ref_norm / np.sqrt(got.size), 1e-12)
+        err = np.abs(got[::step] - ref_s).max() / scale
+        nerr = abs(np.linalg.norm(got) - ref_norm) / max(ref_norm, 1e-12)
+        assert err < 2e-3 and nerr < 2e-3, (iname, err, nerr, ref_norm)
     params = dict(model.named_parameters(remove_duplicate=False))     # EXPERT_GROUP: rel_out aliases the last expert's heads
     names = [k[9:] for k in g if k.startswith("gradnorm_")]
     assert names

@@ -75,6 +75,7 @@ def make_mm(scheme):
     return mm
 
 
+QKV_PARTS = "qkv"
 QKV_DT = None   # storage type of q, k, v between the projection and the attention (None = fp32)
 
 
@@ -93,7 +94,12 @@ def run(name, scheme):
         y = vo.layer_norm(x, T("0.norm.weight"), T("0.norm.bias"))
         qkv = mm(y.reshape(-1, D), T("0.fn.to_qkv.weight")).reshape(b, n, 3 * D)
         if QKV_DT is not None and 0 < l < cfg_.layers - 1:     # the middle layers materialise q, k, v
-            qkv = qkv.to(QKV_DT).float()
+            r = qkv.to(QKV_DT).float()
+            if QKV_PARTS == "qk":
+                r[..., 2 * D:] = qkv[..., 2 * D:]
+            elif QKV_PARTS == "v":
+                r[..., :2 * D] = qkv[..., :2 * D]
+            qkv = r
         q, k, v = [z.reshape(b, n, H, dh).permute(0, 2, 1, 3) for z in qkv.chunk(3, dim=-1)]
         attn = torch.softmax((q @ k.transpose(-1, -2)) * (dh ** -0.5), dim=-1)
         out = (attn @ v).permute(0, 2, 1, 3).reshape(b * n, D)
@@ -114,9 +120,9 @@ def run(name, scheme):
 if __name__ == "__main__":
     names = [a for a in sys.argv[1:] if not a.startswith("--")] or ["predcls_n10_l4h8", "predcls_n36_l4h8", "predcls_n36_l6h6"]
     if "--qkv16" in sys.argv:
-        for dt in (None, torch.float16, torch.bfloat16):
-            QKV_DT = dt
-            print("q/k/v stored as %s, Linears f16+e4m3:" % dt, "  ".join("%s %.2e" % (n, run(n, "f16+e4m3")) for n in names), flush=True)
+        for dt, parts in ((None, "qkv"), (torch.float16, "qkv"), (torch.float16, "qk"), (torch.float16, "v"), (torch.bfloat16, "qkv")):
+            QKV_DT, QKV_PARTS = dt, parts
+            print("%s stored as %s, Linears f16+e4m3:" % (parts, dt), "  ".join("%s %.2e" % (n, run(n, "f16+e4m3")) for n in names), flush=True)
         sys.exit(0)
     for scheme in ["fp32", "bf16x3", "f16x3", "f16+e4m3", "f16+e2m3", "f16+e4m3/1", "f16", "bf16"]:
         print("%-12s" % scheme, "  ".join("%s %.2e" % (n, run(n, scheme)) for n in names), flush=True)

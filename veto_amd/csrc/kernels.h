@@ -331,5 +331,11 @@ hipError_t launch_gather_rows(const float* table, const int64_t* labels, int dim
 hipError_t launch_scatter_rows(const float* demb, const int64_t* labels, int dim, float* dtable, int n, hipStream_t s);
 hipError_t launch_untranspose_pair_proj(const float* dwt, float* dw, int kin, hipStream_t s);
 hipError_t launch_patch_weight_grad(const float* dwcat_t, float* dwd, float* dwv, hipStream_t s);
+// Input gradient of the patch projection (training): the TRANSPOSE of the combined patch weight as a GEMM weight operand,
+// dst [kPatchTRows = 2112, 2*1152] split rows (rows 2048.. are zero: 2112 = 11 x 192 output columns), and the scatter of
+// dPA [n_obj*16, ld] fp32 (patch rows x patch features, depth features first) back onto the ROI maps [n_obj, 256, 8, 8]
+constexpr int kPatchTRows = 2112;
+hipError_t launch_build_patch_weight_t(const float* wd, const float* wv, __bf16* dst, hipStream_t s);
+hipError_t launch_unpatchify(const float* dpa, long ld, float* d_depth, float* d_rgb, int n_obj, hipStream_t s);
 
 }  // namespace veto

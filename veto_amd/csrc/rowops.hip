@@ -142,6 +142,25 @@ __global__ void build_patch_weight_kernel(const float* __restrict__ wd, const fl
   if (threadIdx.x == 0) bias_cat[j] = half == 0 ? (jj < 512 ? bd[jj] : bv[jj - 512]) : 0.f;
 }
 
+// Wcat^T as a GEMM weight operand: row kk (patch feature), column j (table column) = Wcat[j][kk] of the kernel above
+__global__ void build_patch_weight_t_kernel(const float* __restrict__ wd, const float* __restrict__ wv, __bf16* __restrict__ dst) {
+  const int kk = blockIdx.x;  // 0..2111
+  const int mod = kk >> 10, f = kk & 1023, pp = f >> 8, c = f & 255;
+  for (int j = threadIdx.x; j < 2 * kDim; j += blockDim.x) {
+    const int half = j / kDim, jj = j % kDim;
+    float v = 0.f;
+    if (kk < 2048) {
+      if (jj < 512 && mod == 0) v = wd[(size_t)jj * 2048 + pp * 512 + half * 256 + c];
+      if (jj >= 512 && mod == 1) v = wv[(size_t)(jj - 512) * 2048 + pp * 512 + half * 256 + c];
+    }
+    __bf16 h, l;
+    split_bf16(v, h, l);
+    __bf16* d = dst + (size_t)kk * (2 * 2 * kDim) + split_index(j);
+    d[0] = h;
+    d[32] = l;
+  }
+}
+
 __global__ void transpose_pair_proj_kernel(const float* __restrict__ src, float* __restrict__ dst,
                                            int kin) {
   const int k = blockIdx.x;  // 0..kin-1
@@ -288,6 +307,29 @@ __global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__
       d[0] = h;
       d[32] = l;
     }
+}
+
+// the inverse index map of patchify_kernel, on fp32 gradients: thread c of block (n, modality) gathers the 64 pixels of
+// channel c from the 16 patch rows of object n (every pixel receives exactly one contribution: patches do not overlap)
+__global__ __launch_bounds__(256) void unpatchify_kernel(const float* __restrict__ dpa, long ld, float* __restrict__ d_depth,
+                                                         float* __restrict__ d_rgb) {
+  const int n = blockIdx.x, mod = blockIdx.y, c = threadIdx.x;
+  float* out = (mod == 0 ? d_depth : d_rgb);
+  if (!out) return;
+  out += ((size_t)n * 256 + c) * 64;
+#pragma unroll
+  for (int y = 0; y < 8; ++y) {
+    f32x4 lo, hi;
+#pragma unroll
+    for (int x = 0; x < 8; ++x) {
+      const int row = n * 16 + (y >> 1) * 4 + (x >> 1);
+      const int col = mod * 1024 + ((y & 1) * 2 + (x & 1)) * 256 + c;
+      const float v = dpa[(size_t)row * ld + col];
+      if (x < 4) lo[x] = v; else hi[x - 4] = v;
+    }
+    *(f32x4*)(out + y * 8) = lo;
+    *(f32x4*)(out + y * 8 + 4) = hi;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -594,6 +636,16 @@ hipError_t launch_split_rows(const float* src, __bf16* dst, size_t rows, int K, 
   const size_t n = rows * (size_t)K;
   const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
   VETO_LAUNCH(split_rows_kernel, dim3(blocks), dim3(256), 0, s, src, dst, n, K);
+  return hipGetLastError();
+}
+
+hipError_t launch_build_patch_weight_t(const float* wd, const float* wv, __bf16* dst, hipStream_t s) {
+  VETO_LAUNCH(build_patch_weight_t_kernel, dim3(kPatchTRows), dim3(256), 0, s, wd, wv, dst);
+  return hipGetLastError();
+}
+
+hipError_t launch_unpatchify(const float* dpa, long ld, float* d_depth, float* d_rgb, int n_obj, hipStream_t s) {
+  VETO_LAUNCH(unpatchify_kernel, dim3(n_obj, 2), dim3(256), 0, s, dpa, ld, d_depth, d_rgb);
   return hipGetLastError();
 }
 

@@ -680,6 +680,8 @@ struct TrainWs {
   __bf16 *dsplit, *wdg, *zero;
   float *ln_partial, *col_partial, *colp, *dgb, *head_partial;
   float *dpatch, *dlc, *dpos, *dpre, *xhat, *bn_out, *dbn_out, *emb, *demb, *prob, *dloc_wt, *dcls_wt, *dwcat_t;
+  __bf16* wcat_t;   // Wcat^T [2112, 2*1152] split rows: weight operand of the patch projection's input gradient
+  float* dpa;       // dPA [prow, 2112] fp32: gradient w.r.t. the patch rows
   size_t mp2;    // padded reduction length of the weight-gradient GEMMs
   size_t total;
 };
@@ -740,6 +742,8 @@ TrainWs carve_train(char* base, veto_handle_t h, int n_obj, int n_pair) {
   w.dloc_wt = (float*)take((size_t)kPosDim * 2 * kDim * 4);
   w.dcls_wt = (float*)take((size_t)E * 2 * kDim * 4);
   w.dwcat_t = (float*)take((size_t)2048 * 2 * kDim * 4);
+  w.wcat_t = (__bf16*)take((size_t)kPatchTRows * 2 * 2 * kDim * 2);
+  w.dpa = (float*)take((size_t)gemm_rows_padded(n_obj * 16) * kPatchTRows * 4);
   w.total = off;
   return w;
 }
@@ -1046,6 +1050,17 @@ int veto_backward(veto_handle_t h, void* stream, const veto_inputs_t* in, const 
     HIP_TRY(launch_column_sums(ws.dpatch, 2 * kDim, R, kDim, ws.dgb, ws.col_partial, column_sums_chunks(), s));
     HIP_TRY(hipMemcpyAsync(G(pe + "proj_d.bias"), ws.dgb, 512 * 4, hipMemcpyDeviceToDevice, s));
     HIP_TRY(hipMemcpyAsync(G(pe + "proj_v.bias"), ws.dgb + 512, 64 * 4, hipMemcpyDeviceToDevice, s));
+    // input gradient (optional): dPA = dpatch . Wcat, i.e. the forward GEMM kernel on split(dpatch) (still in ws.dsplit) and
+    // Wcat^T as the weight operand; then the inverse of patchify onto the ROI maps.  The reference's depth backbone is
+    // trained through roi_depth_features (tools/relation_train_net.py:166-170).
+    if (opts && (opts->d_roi_rgb || opts->d_roi_depth)) {
+      HIP_TRY(launch_build_patch_weight_t(h->p(pe + "proj_d.weight"), h->p(pe + "proj_v.weight"), ws.wcat_t, s));
+      GemmArgs g{};
+      g.a = ws.dsplit; g.w = ws.wcat_t; g.c = ws.dpa;
+      g.M = R; g.N = kPatchTRows; g.K = 2 * kDim; g.ldc = kPatchTRows;
+      HIP_TRY(launch_gemm_split(g, EPI_F32, 0, s));
+      HIP_TRY(launch_unpatchify(ws.dpa, kPatchTRows, opts->d_roi_depth, opts->d_roi_rgb, n_obj, s));
+    }
   }
 
   // ---- location / class projections and what feeds them -----------------------------------------------------------

@@ -96,7 +96,7 @@ class VetoSggEvalArgs(Structure):
 
 class VetoTrainOpts(Structure):
     _fields_ = [("struct_size", c_int32), ("p_pos", ctypes.c_float), ("p_emb", ctypes.c_float), ("p_attn", ctypes.c_float),
-                ("seed", ctypes.c_uint64)]
+                ("seed", ctypes.c_uint64), ("d_roi_rgb", c_void_p), ("d_roi_depth", c_void_p)]
 
 
 class VetoError(RuntimeError):

@@ -193,8 +193,6 @@ class _NativeForward:
         self._num_out = sum(h.out_features for h in head_modules)
         self._precision = _precision(config)
         self._max_chunk = _max_chunk(config)
-        ext = getattr(config, "VETO_AMD", None)
-        self._allow_detached_roi = bool(getattr(ext, "ALLOW_DETACHED_ROI_GRAD", False)) if ext is not None else False
         object.__setattr__(self, "_trunk", trunk)  # not a sub-module registration
         self._engine = None
         self._engine_device = None
@@ -375,14 +373,10 @@ class _NativeForward:
 
     def _run_native_train_grad(self, proposals, rel_pair_idxs, roi_features, roi_depth_features, labels, logits=None):
         """Training-mode forward whose result carries an autograd graph: logits [sum P, num_out]."""
-        if torch.is_grad_enabled() and (roi_features.requires_grad or roi_depth_features.requires_grad) and not self._allow_detached_roi:
-            raise NotImplementedError(
-                "veto_amd: the training path has no input gradient for roi_features / roi_depth_features yet (veto_backward stops at "
-                "the per-object patch table), so a module that produced them -- the reference trains its depth backbone through "
-                "roi_depth_features, tools/relation_train_net.py:166-170 -- would silently get no gradient.  Detach the tensors, or "
-                "set VETO_AMD.ALLOW_DETACHED_ROI_GRAD = True to train the predictor alone.")
         spec = self._train_param_spec()
-        return _TrainFn.apply(self, (proposals, rel_pair_idxs, roi_features, roi_depth_features, labels, logits), *[s[0] for s in spec])
+        # roi_features / roi_depth_features are differentiable inputs: veto_backward returns their gradients (the reference trains
+        # its depth backbone through roi_depth_features, tools/relation_train_net.py:166-170)
+        return _TrainFn.apply(self, (proposals, rel_pair_idxs, labels, logits), roi_features, roi_depth_features, *[s[0] for s in spec])
 
 
 class _WsToken:
@@ -398,8 +392,8 @@ class _TrainFn(torch.autograd.Function):
     veto_backward.  The parameters are inputs only so that autograd routes their gradients."""
 
     @staticmethod
-    def forward(ctx, owner, call, *params):
-        proposals, rel_pair_idxs, roi_features, roi_depth_features, labels, obj_logits = call
+    def forward(ctx, owner, call, roi_features, roi_depth_features, *params):
+        proposals, rel_pair_idxs, labels, obj_logits = call
         device = roi_features.device
         stats = torch.empty(12, dtype=torch.float32, device=device)
         inp, keep, n_objs, n_pairs, device, eng = owner._prepare_inputs(proposals, rel_pair_idxs, roi_features, roi_depth_features,
@@ -447,6 +441,14 @@ class _TrainFn(torch.autograd.Function):
         n_floats = lib.veto_grad_floats(eng.handle)
         flat = torch.empty(n_floats, dtype=torch.float32, device=device)
         stream = torch.cuda.current_stream(device)
+        d_rgb = d_dep = None
+        n_obj = ctx.inp.n_obj
+        if ctx.needs_input_grad[2]:
+            d_rgb = torch.empty((n_obj, 256, 8, 8), dtype=torch.float32, device=device)
+        if ctx.needs_input_grad[3]:
+            d_dep = torch.empty((n_obj, 256, 8, 8), dtype=torch.float32, device=device)
+        ctx.opts.d_roi_rgb = d_rgb.data_ptr() if d_rgb is not None else None
+        ctx.opts.d_roi_depth = d_dep.data_ptr() if d_dep is not None else None
         native.check(lib.veto_backward(eng.handle, ctypes.c_void_p(stream.cuda_stream), ctypes.byref(ctx.inp), ctypes.byref(ctx.opts),
                                        ctypes.c_void_p(ctx.ws.data_ptr()), ctx.ws.numel(), ctypes.c_void_p(dlogits.data_ptr()),
                                        ctypes.c_void_p(flat.data_ptr())))
@@ -462,7 +464,7 @@ class _TrainFn(torch.autograd.Function):
                 per_row = prm.numel() // rows
                 g = flat[off + row0 * per_row: off + (row0 + rows) * per_row]
             grads.append(g.view_as(prm).to(prm.device))
-        return (None, None) + tuple(grads)
+        return (None, None, d_rgb, d_dep) + tuple(grads)
 
 
 def _offset_tensors(n_objs, n_pairs, device):
