@@ -127,8 +127,9 @@ hipError_t launch_dropout_apply(const float* x, float* y, size_t rows, int n_col
                                 float scale, hipStream_t s);
 
 // LayerNorm(eps 1e-5) of `rows` rows (row r at x + r*ldx) -> split rows [rows, 2*576]
+// dst row r at dst + r*ldd (bf16 elements; 0 = contiguous rows of 2*576)
 hipError_t launch_layernorm(const float* x, long ldx, const float* w, const float* b, __bf16* dst, int rows,
-                            hipStream_t s, int fmt = FMT_SPLIT);
+                            hipStream_t s, int fmt = FMT_SPLIT, long ldd = 0);
 
 struct AttnArgs {
   const float* qkv;        // [n_pair*19, 1728]

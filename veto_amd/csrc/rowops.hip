@@ -416,6 +416,11 @@ __device__ __forceinline__ void rowq_layernorm_store(const RowQ& r, int q, const
 // Token assembly (model_veto.py:56-63 with the per-object partial products of section 4 of DESIGN.md):
 // one quarter wave per token row.  Reads of the per-object tables hit L2 / Infinity Cache (each object
 // row is re-used by 2(N-1) pairs); the writes (x fp32 + LN(x) split) are the HBM stream.
+// STATS_ONLY (layer 0 in the per-object form): the kernel writes the token rows and their LayerNorm statistics only; the
+// LayerNorm'ed split rows of tokens 17 / 18 come from a strided layernorm_kernel launch behind it.  Keeping that store path
+// (gamma / beta of nine chunks, the split conversion) out of this instantiation takes it from 138 to ~70 registers, i.e.
+// from 3 to 7 waves per SIMD: the kernel is a latency-bound gather (measured 2.3 TB/s of writes at 3 waves per SIMD).
+template <bool STATS_ONLY>
 __global__ __launch_bounds__(256) void assemble_kernel(AssembleArgs a) {
   // Workgroups are dealt round-robin to the 8 XCDs; XCD x takes the x-th contiguous eighth of the token rows, i.e. the pairs of
   // one or two images, whose per-object rows (2.65 MB per 36-object image) then stay in THAT XCD's 4 MB L2.
@@ -436,38 +441,54 @@ __global__ __launch_bounds__(256) void assemble_kernel(AssembleArgs a) {
   }
   RowQ r;
   float* xr = a.x + (size_t)row * kDim;
+  // Three groups of three 16-byte chunks: with all nine chunks of the three sources in flight at once the kernel needed 138
+  // registers (3 waves per SIMD) and was bound by the latency of its gathers (0.32 ms for 0.73 GB written = 2.3 TB/s, against
+  // 5.5 TB/s for plain store streams, profiles/r02_store_bw.txt); a group keeps 9 loads in flight per lane and leaves the
+  // overlap to the other waves of the SIMD.
 #pragma unroll
-  for (int j = 0; j < 9; ++j) {
-    const int c = 4 * (q + 16 * j);
-    f32x4 v;
-    if (t == 0) {
-      v = *(const f32x4*)(a.cls_token + c);
-    } else {
-      v = *(const f32x4*)(ps + c) + *(const f32x4*)(po + c);
+  for (int g3 = 0; g3 < 3; ++g3) {
+    f32x4 vs[3], vo[3], vp[3];
+#pragma unroll
+    for (int jj = 0; jj < 3; ++jj) {
+      const int c = 4 * (q + 16 * (g3 * 3 + jj));
+      vp[jj] = *(const f32x4*)(a.pos_embedding + c);
+      if (t == 0) {
+        vs[jj] = *(const f32x4*)(a.cls_token + c);
+        vo[jj] = f32x4{0.f, 0.f, 0.f, 0.f};
+      } else {
+        vs[jj] = *(const f32x4*)(ps + c);
+        vo[jj] = *(const f32x4*)(po + c);
+      }
+    }
+#pragma unroll
+    for (int jj = 0; jj < 3; ++jj) {
+      const int j = g3 * 3 + jj, c = 4 * (q + 16 * j);
+      f32x4 v = t == 0 ? vs[jj] : vs[jj] + vo[jj];
       if (t > kPatchTokens) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);  // ReLU of location / class projection
       }
-    }
-    v += *(const f32x4*)(a.pos_embedding + c);
-    if (a.drop_thresh) {   // training: pos_drop (model_veto.py:63)
+      v += vp[jj];
+      if (a.drop_thresh) {   // training: pos_drop (model_veto.py:63)
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
-        v[e] = dropout_keep(a.drop_seed, (unsigned long long)row * kDim + c + e, a.drop_thresh) ? v[e] * a.drop_scale : 0.f;
+        for (int e = 0; e < 4; ++e)
+          v[e] = dropout_keep(a.drop_seed, (unsigned long long)row * kDim + c + e, a.drop_thresh) ? v[e] * a.drop_scale : 0.f;
+      }
+      r.v[j] = v;
+      *(f32x4*)(xr + c) = v;
     }
-    r.v[j] = v;
-    *(f32x4*)(xr + c) = v;
+    asm volatile("" ::: "memory");   // keeps the next group's loads behind this group's stores (bounds the registers)
   }
-  if (a.stats) {
+  if constexpr (STATS_ONLY) {
     // layer 0 in the per-object form (qkv0_combine_kernel): the patch-token rows and the CLS row only need their LayerNorm
     // statistics; the two ReLU'd rows (location, class) are not linear in the per-object tables and keep the split-row path
+    // (written by the layernorm launch behind this kernel)
     float mean, rstd;
     rowq_stats(r, mean, rstd);
     if (q == 0) *(float2*)(a.stats + (size_t)row * 2) = float2{mean, rstd};
-    if (t > kPatchTokens) rowq_normalized_store(r, q, mean, rstd, a.ln_w, a.ln_b, a.a + (size_t)row * (2 * kDim));
-    return;
+  } else {
+    rowq_layernorm_store(r, q, a.ln_w, a.ln_b, a.a + (size_t)row * (2 * kDim));
   }
-  rowq_layernorm_store(r, q, a.ln_w, a.ln_b, a.a + (size_t)row * (2 * kDim));
 }
 
 // ---- layer 0, per-object form of LayerNorm + QKV ---------------------------------------------
@@ -585,7 +606,7 @@ template <int FMT>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, long ldx,
                                                         const float* __restrict__ w,
                                                         const float* __restrict__ b,
-                                                        __bf16* __restrict__ dst, int rows) {
+                                                        __bf16* __restrict__ dst, int rows, long ldd) {
   const int row = blockIdx.x * 16 + (threadIdx.x >> 4);
   if (row >= rows) return;
   const int q = threadIdx.x & 15;
@@ -593,7 +614,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
   RowQ r;
 #pragma unroll
   for (int j = 0; j < 9; ++j) r.v[j] = *(const f32x4*)(xr + 4 * (q + 16 * j));
-  rowq_layernorm_store<FMT>(r, q, w, b, dst + (size_t)row * (2 * kDim));
+  rowq_layernorm_store<FMT>(r, q, w, b, dst + (size_t)row * ldd);
 }
 
 __global__ __launch_bounds__(256) void dropout_apply_kernel(const float* __restrict__ x, float* __restrict__ y, size_t n,
@@ -711,7 +732,17 @@ hipError_t launch_enumerate_pairs(int n, int64_t* out, hipStream_t s) {
 
 hipError_t launch_assemble(const AssembleArgs& a, hipStream_t s) {
   const long blocks = ((long)a.n_pair * kTokens + 15) / 16;
-  VETO_LAUNCH(assemble_kernel, dim3((unsigned)((blocks + 7) / 8 * 8)), dim3(256), 0, s, a);
+  if (a.stats) {
+    VETO_LAUNCH(assemble_kernel<true>, dim3((unsigned)((blocks + 7) / 8 * 8)), dim3(256), 0, s, a);
+    // LayerNorm'ed split rows of the location / class tokens (rows 19 p + 17, 19 p + 18): 2 of 19 rows, read back from x
+    for (int t = kPatchTokens + 1; t < kTokens; ++t) {
+      hipError_t e = launch_layernorm(a.x + (size_t)t * kDim, (long)kTokens * kDim, a.ln_w, a.ln_b, a.a + (size_t)t * 2 * kDim, a.n_pair, s,
+                                      FMT_SPLIT, (long)kTokens * 2 * kDim);
+      if (e != hipSuccess) return e;
+    }
+  } else {
+    VETO_LAUNCH(assemble_kernel<false>, dim3((unsigned)((blocks + 7) / 8 * 8)), dim3(256), 0, s, a);
+  }
   return hipGetLastError();
 }
 
@@ -735,9 +766,10 @@ hipError_t launch_qkv0_consts(const float* wq, const float* gamma, const float* 
 }
 
 hipError_t launch_layernorm(const float* x, long ldx, const float* w, const float* b, __bf16* dst, int rows,
-                            hipStream_t s, int fmt) {
-  if (fmt == FMT_MIXED) VETO_LAUNCH(layernorm_kernel<FMT_MIXED>, dim3((rows + 15) / 16), dim3(256), 0, s, x, ldx, w, b, dst, rows);
-  else VETO_LAUNCH(layernorm_kernel<FMT_SPLIT>, dim3((rows + 15) / 16), dim3(256), 0, s, x, ldx, w, b, dst, rows);
+                            hipStream_t s, int fmt, long ldd) {
+  if (ldd == 0) ldd = 2 * kDim;
+  if (fmt == FMT_MIXED) VETO_LAUNCH(layernorm_kernel<FMT_MIXED>, dim3((rows + 15) / 16), dim3(256), 0, s, x, ldx, w, b, dst, rows, ldd);
+  else VETO_LAUNCH(layernorm_kernel<FMT_SPLIT>, dim3((rows + 15) / 16), dim3(256), 0, s, x, ldx, w, b, dst, rows, ldd);
   return hipGetLastError();
 }
 
