@@ -33,8 +33,9 @@ def _worker(rank, world, port, out):
         local = torch.cat(rows)
         full = vdist.all_gather_logits(local)
         same = vdist.all_gather_logits(local[:6], equal_counts=True)
+        padded, counts = vdist.all_gather_logits(local, max_rows=40)      # no read-back of the counts
         if rank == 0:
-            torch.save({"mine": mine, "full": full, "same": same}, out)
+            torch.save({"mine": mine, "full": full, "same": same, "padded": padded, "counts": counts}, out)
     finally:
         dist.destroy_process_group()
 
@@ -47,6 +48,8 @@ def test_shard_and_all_gather_world2(tmp_path):
     exp = torch.cat([torch.arange(n * (n - 1), dtype=torch.float32) + 1000.0 * i for i, n in enumerate([5, 3, 4])])
     assert r["full"].shape == (20 + 6 + 12, 51) and torch.equal(r["full"][:, 0], exp)
     assert r["same"].shape == (12, 51)
+    assert r["padded"].shape == (2, 40, 51) and r["counts"].tolist() == [26, 12]
+    assert torch.equal(torch.cat([r["padded"][k, :n] for k, n in enumerate(r["counts"].tolist())]), r["full"])
 
 
 def _grad_worker(rank, world, port, out):

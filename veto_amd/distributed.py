@@ -18,12 +18,18 @@ def shard_images(num_images, rank=None, world=None):
     return list(range(start, start + base + (1 if rank < rem else 0)))
 
 
-def all_gather_logits(logits, equal_counts=False, group=None, force=False):
+def all_gather_logits(logits, equal_counts=False, group=None, force=False, max_rows=None):
     """logits: [P_r, C] on this rank -> [sum_r P_r, C], rank-major, on every rank.
 
     P_r may differ between ranks (images have different object counts): the row counts are gathered
     first and the payload is padded to the maximum, so the data exchange is a single
-    all_gather_into_tensor (direct, one hop per peer on the fully connected xGMI mesh)."""
+    all_gather_into_tensor (direct, one hop per peer on the fully connected xGMI mesh).
+
+    Host synchronisation: none with `equal_counts`; with ragged counts the default form reads the gathered counts back (one
+    small copy) to size and trim the result.  `max_rows` (an upper bound of P_r known to every rank, e.g. images per rank x
+    MAX_PROPOSAL_PAIR) removes that read-back: the call then returns `(padded [world, max_rows, C], counts [world] on the
+    device)` and never touches the host -- the form for an eval loop that keeps everything on the GPU (the evaluators take
+    device tensors)."""
     if not dist.is_available() or not dist.is_initialized():
         return logits
     world = dist.get_world_size(group)
@@ -37,6 +43,14 @@ def all_gather_logits(logits, equal_counts=False, group=None, force=False):
         return out
     counts = torch.empty(world, dtype=torch.int64, device=logits.device)
     dist.all_gather_into_tensor(counts, torch.tensor([p], dtype=torch.int64, device=logits.device), group=group)
+    if max_rows is not None:
+        if p > max_rows:
+            raise ValueError("all_gather_logits: %d rows on this rank exceed max_rows=%d" % (p, max_rows))
+        padded = torch.zeros((max_rows, c), dtype=logits.dtype, device=logits.device)
+        padded[:p] = logits
+        out = torch.empty((world * max_rows, c), dtype=logits.dtype, device=logits.device)
+        dist.all_gather_into_tensor(out, padded, group=group)
+        return out.view(world, max_rows, c), counts
     counts = counts.tolist()
     pmax = max(counts)
     padded = logits
