@@ -67,6 +67,36 @@ def test_split_gemm_against_fp64(m, n, k):
         assert rel < tol, (m, n, k, precision, rel)
 
 
+def test_mixed_gemm_saturates_gracefully_on_outliers():
+    """The e4m3 correction planes of the mixed format clamp instead of overflowing (v_cvt_pk_fp8_f32 itself would produce NaN
+    above 448): activations far outside the fixed scaling range (|a| > 28) and a weight tensor whose exponent is set by one
+    huge entry must give finite results whose error is that of the fp16 main product at worst (2^-11 relative), and the
+    well-scaled rows of the same call keep the full 2^-16 class."""
+    from veto_amd import native
+    lib = native.load_library()
+    dev = _dev()
+    m, n, k = 512, 384, 576
+    g = torch.Generator(device="cpu").manual_seed(5)
+    a = torch.randn(m, k, generator=g)
+    a[7] *= 300.0                      # one row of large activations
+    a[100, 13] = 6.0e4                 # near the fp16 maximum
+    w = torch.randn(n, k, generator=g) * 0.04
+    w[3, 5] = 3.0                      # sets the tensor's e4m3 exponent: every other weight then uses few e4m3 bits
+    a, w = a.to(dev), w.to(dev)
+    ref = a.double() @ w.double().t()
+    scale = (a.abs().double() @ w.abs().double().t()).clamp_min(1e-6)
+    ws = torch.empty(lib.veto_debug_gemm_workspace_bytes(m, n, k), dtype=torch.uint8, device=dev)
+    c = torch.full((m, n), float("nan"), device=dev)
+    native.check(lib.veto_debug_gemm(None, a.data_ptr(), w.data_ptr(), None, c.data_ptr(), m, n, k, native.VETO_MIXED, ws.data_ptr(), ws.numel()))
+    torch.cuda.synchronize()
+    assert torch.isfinite(c).all()
+    rel = (c.double() - ref).abs() / scale
+    assert rel.max().item() < 2.0 ** -10, rel.max().item()
+    ok = torch.ones(m, dtype=torch.bool, device=dev)
+    ok[7] = ok[100] = False
+    assert rel[ok].max().item() < 2e-4, rel[ok].max().item()       # (the coarse weight exponent costs correction bits, not the main term)
+
+
 @pytest.mark.parametrize("n", [1, 2, 3, 10, 36, 50])
 def test_enumerate_pairs_bit_exact(n):
     from veto_amd.pairs import prepare_test_pairs
