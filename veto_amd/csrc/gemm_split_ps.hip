@@ -133,7 +133,9 @@ __global__ __launch_bounds__(64 * (NCONS + NLOAD), 3) void gemm_split_ps_kernel(
   const int nk = K / BK / ksp;               // k-steps per tile
   // tile of round `it` for this workgroup; gridDim.x is a multiple of 8 (launcher)
   const int per_xcd = gridDim.x >> 3;
-  auto tile_of = [&](int it) { return (it * 8 + (b & 7)) * per_xcd + (b >> 3); };
+  // g.panel_major (A/B, speed only): a workgroup walks the tiles_n tiles of ONE row panel back to back (panels dealt like tiles)
+  const int pm = g.panel_major ? g.tiles_n : 1;
+  auto tile_of = [&](int it) { return ((it / pm * 8 + (b & 7)) * per_xcd + (b >> 3)) * pm + it % pm; };
   int my_tiles = 0;
   while (tile_of(my_tiles) < ntiles) ++my_tiles;  // tile_of is increasing in `it`
   if (my_tiles == 0) return;
@@ -578,6 +580,8 @@ hipError_t launch_gemm_split(GemmArgs g, int epi, int precision, hipStream_t s) 
 hipError_t launch_gemm_split_ps(GemmArgs g, int epi, int precision, hipStream_t s) {
   static const int stagger = getenv("VETO_GEMM_STAGGER") ? atoi(getenv("VETO_GEMM_STAGGER")) : 0;
   g.stagger = stagger;
+  static const int panel_major = getenv("VETO_GEMM_PANEL") ? atoi(getenv("VETO_GEMM_PANEL")) : 0;   // A/B knob (speed only)
+  g.panel_major = panel_major && g.tiles_n == 3 && (epi == EPI_RESID);
   static int num_cu = 0;
   if (num_cu == 0) {
     int dev = 0;

@@ -27,6 +27,7 @@ struct GemmArgs {
   float drop_scale;
   int tiles_m, tiles_n;  // filled by the launcher
   int stagger;           // persistent kernel: start-phase stagger in units of s_sleep(127) (speed only)
+  int panel_major;       // persistent kernel: tiles of one row panel back to back on one workgroup (speed only)
   // tn (EPI_ATOMIC only, weight gradients): C[M, N] += A^T B with BOTH operands row-major in the reduction index, i.e. the
   // split rows the backward already holds: a = dY split rows [k_valid, lda] (M = its column count), w = X split rows
   // [k_valid, ldw] (N = its column count), K = the reduction length rounded up to 32 * k_splits.  Reduction rows >= k_valid
