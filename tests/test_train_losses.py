@@ -341,3 +341,70 @@ def test_relation_head_training_branch_end_to_end():
     grads = [p.grad for p in head.predictor.parameters() if p.grad is not None]
     assert len(grads) >= 30 and all(torch.isfinite(g).all() for g in grads)
     assert float(head.predictor.rel_out.weight.grad.abs().max()) > 0
+
+
+@pytest.mark.gpu
+def test_ce_loss_edge_cases_follow_torch():
+    """No rows (a MEET tail group that received no sampled relation): NaN like the reference's CE over nothing, empty gradient,
+    no launch.  Labels outside [0, C) -- nn.CrossEntropyLoss's ignore_index -100 in particular -- are ignored rows: same loss and
+    gradients as torch's own criterion."""
+    from veto_amd.losses import ce_loss, relation_ce_loss
+    dev = torch.device("cuda:0")
+    loss, grad = relation_ce_loss(torch.zeros((0, 7), device=dev), torch.zeros(0, dtype=torch.int64, device=dev), want_grad=True)
+    assert torch.isnan(loss).all() and grad.shape == (0, 7)
+    rows = torch.zeros(0, dtype=torch.int64, device=dev)
+    loss, grad = relation_ce_loss(torch.randn(5, 7, device=dev), torch.zeros(0, dtype=torch.int64, device=dev), rows=rows, want_grad=True)
+    assert torch.isnan(loss).all() and grad.shape == (0, 7)
+    g = torch.Generator().manual_seed(3)
+    logits = torch.randn(40, 11, generator=g)
+    labels = torch.randint(0, 11, (40,), generator=g)
+    labels[[3, 17, 18]] = -100
+    w = torch.rand(11, generator=g) + 0.1
+    ref_in = logits.clone().requires_grad_(True)
+    ref = torch.nn.CrossEntropyLoss(weight=w)(ref_in, labels)
+    ref.backward()
+    got_in = logits.to(dev).requires_grad_(True)
+    got = ce_loss(got_in, labels.to(dev), weight=w.to(dev))
+    got.backward()
+    assert abs(float(got.detach()) - float(ref.detach())) < 1e-6
+    assert (got_in.grad.cpu() - ref_in.grad).abs().max() < 1e-7
+    assert float(got_in.grad[[3, 17, 18]].abs().max()) == 0.0
+
+
+@pytest.mark.gpu
+def test_training_workspace_is_released_without_a_backward_and_weights_refresh():
+    """(1) A training-mode forward that never gets a backward (torch.no_grad(), a validation pass) must not pin the cached
+    36 GB-class workspace: the next step reuses it.  (2) A write through `.data` is invisible to the version stamp in eval mode:
+    refresh_weights() makes it take effect; load_state_dict and training mode refresh by themselves."""
+    from veto_amd import testing
+    from veto_amd.pairs import prepare_test_pairs
+    dev = torch.device("cuda:0")
+    g, model, batch, num_objs = _train_setup("train_vanilla", False, dev, forward_only=False)
+    props = testing.make_proposals(batch, "predcls", dev)
+    pairs = prepare_test_pairs(dev, props)
+    rel_labels = list(torch.from_numpy(g["labels"]).to(dev).split([int(p.shape[0]) for p in pairs]))
+    rgb, dep = torch.from_numpy(batch["roi_features"]).to(dev), torch.from_numpy(batch["roi_depth_features"]).to(dev)
+    with torch.no_grad():
+        model(props, pairs, rel_labels, None, roi_features=rgb, roi_depth_features=dep)
+    ws0 = model.__dict__["_train_ws"]
+    out = model(props, pairs, rel_labels, None, roi_features=rgb, roi_depth_features=dep)     # would allocate a second one if pinned
+    assert model.__dict__["_train_ws"] is ws0
+    holder = model.__dict__["_train_ws_owner"]()
+    assert holder is not None and not holder.done
+    sum(out[2].values()).backward()
+    assert holder.done
+    # (2)
+    model.eval()
+    with torch.no_grad():
+        a = torch.cat(list(model(props, pairs, None, None, roi_features=rgb, roi_depth_features=dep)[1]))
+        model.rel_out.bias.data.add_(1.0)                      # does not bump Tensor._version
+        b = torch.cat(list(model(props, pairs, None, None, roi_features=rgb, roi_depth_features=dep)[1]))
+        assert torch.equal(a, b)                               # the documented blind spot ...
+        model.refresh_weights()
+        c = torch.cat(list(model(props, pairs, None, None, roi_features=rgb, roi_depth_features=dep)[1]))
+        assert (c - a - 1.0).abs().max() < 1e-5                # ... and its remedy
+        sd = {k: v.clone() for k, v in model.state_dict().items()}
+        sd["rel_out.bias"] -= 1.0
+        model.load_state_dict(sd)
+        d = torch.cat(list(model(props, pairs, None, None, roi_features=rgb, roi_depth_features=dep)[1]))
+        assert (d - a).abs().max() < 1e-5
