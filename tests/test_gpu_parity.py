@@ -635,3 +635,22 @@ def test_oracle_parity_large_feature_scale():
     err = (torch.cat(list(out[1])).cpu() - ref).abs().max().item()
     print("scaled features: logit max-abs-err %.2e (|logit| max %.2f)" % (err, ref.abs().max().item()))
     assert err <= LOGIT_TOL, err
+
+
+def test_gemm_bias_slices_with_single_kstep_tiles():
+    """K = 32 makes a tile ONE stage, so the loader waves run two TILES ahead of the epilogue that reads the bias slice in LDS:
+    many such tiles per workgroup (M = 256 * 600, N = 192 * 2) must still pick up the right 192 bias values each."""
+    from veto_amd import native
+    lib = native.load_library()
+    dev = _dev()
+    m, n, k = 256 * 600, 384, 32
+    g = torch.Generator(device="cpu").manual_seed(9)
+    a = torch.randn(m, k, generator=g).to(dev)
+    w = torch.randn(n, k, generator=g).to(dev)
+    bias = (torch.arange(n, dtype=torch.float32) * 10.0).to(dev)      # distinct per column and per N-tile
+    ws = torch.empty(lib.veto_debug_gemm_workspace_bytes(m, n, k), dtype=torch.uint8, device=dev)
+    c = torch.full((m, n), float("nan"), device=dev)
+    native.check(lib.veto_debug_gemm(None, a.data_ptr(), w.data_ptr(), bias.data_ptr(), c.data_ptr(), m, n, k, native.VETO_PRECISE, ws.data_ptr(), ws.numel()))
+    torch.cuda.synchronize()
+    ref = a.double() @ w.double().t() + bias.double()
+    assert ((c.double() - ref).abs().max().item()) < 1e-2

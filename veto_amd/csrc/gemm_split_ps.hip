@@ -58,8 +58,9 @@ constexpr int NCONS = 8, NLOAD = 4;
 constexpr int kABytes = BM * 128;             // one A stage: 256 rows x 128 B = 32 KiB (3 of them)
 constexpr int kWBytes = BN * 128;             // one W stage: 192 rows x 128 B = 24 KiB (2 of them)
 constexpr int kDumpOff = 3 * kABytes + 2 * kWBytes;
-constexpr int kBiasOff = kDumpOff + 1024;     // two 768-byte bias slices (tile parity), filled by loader wave 0
-constexpr int kLdsBytes = kBiasOff + 2 * BN * 4;  // 144 KiB + a dump area for prefetches + the bias slices
+constexpr int kBiasOff = kDumpOff + 1024;     // three 768-byte bias slices (tile index mod 3), filled by loader wave 0
+constexpr int kBiasSlices = 3;                // the loaders run at most two STAGES ahead: two tiles when a tile is one k-step
+constexpr int kLdsBytes = kBiasOff + kBiasSlices * BN * 4;  // 144 KiB + a dump area for prefetches + the bias slices
 constexpr int kPrefSteps = BN * 4 / 128;      // 6: 128-byte lines per residual row of a tile
 constexpr int CPA = BM / 8 / NLOAD;           // 8 A chunks (8 rows x 128 B) per loader wave and stage
 constexpr int CPWL = BN / 8 / NLOAD;          // 6 W chunks
@@ -211,12 +212,12 @@ __global__ __launch_bounds__(64 * (NCONS + NLOAD), 3) void gemm_split_ps_kernel(
     // cursors of the next A stage / W stage to issue (the stream of stages crosses tile boundaries)
     int itA = 0, ktA = 0, bufA = 0, itW = 0, ktW = 0, bufW = 0;
     auto issueA = [&]() {
-      // first stage of a tile: loader wave 0 also fetches the tile's 192 bias values into the slice of the tile's parity (the
+      // first stage of a tile: loader wave 0 also fetches the tile's 192 bias values into slice (tile index mod 3) (the
       // epilogue reads them from LDS: no bias registers held across it, no vector-memory wait behind its own stores).  Issued
       // BEFORE the A chunks: older than them in vmcnt order, so the stage's counted wait covers it.
       if (ktA == 0 && lw == 0 && g.bias && lane < BN / 4) {
         const int tn = (tile_of(itA) % out_tiles) % g.tiles_n;
-        glds16((const char*)(g.bias + tn * BN) + lane * 16, smem + kBiasOff + (itA & 1) * (BN * 4));
+        glds16((const char*)(g.bias + tn * BN) + lane * 16, smem + kBiasOff + (itA % kBiasSlices) * (BN * 4));
       }
       char* dst = smem + bufA * kABytes + lw * 1024;
       if constexpr (TN) {
@@ -451,7 +452,7 @@ __global__ __launch_bounds__(64 * (NCONS + NLOAD), 3) void gemm_split_ps_kernel(
     const int perm_addr = ((eq << 4) + er) << 2;    // byte address of the source lane for ds_bpermute
     const int row0 = tile_m * BM + wm * 64 + er;
     const int col0 = tile_n * BN + wn * 96 + eq * 4;
-    const char* bias_lds = smem + kBiasOff + (it & 1) * (BN * 4) + (wn * 96 + eq * 4) * 4;
+    const char* bias_lds = smem + kBiasOff + (it % kBiasSlices) * (BN * 4) + (wn * 96 + eq * 4) * 4;
     // the epilogue walks 8 units of (16-row group m, half h of the 6 column groups); the residual of unit
     // u+1 is in flight while unit u is stored (two buffers of 3 x 4 registers next to the 96 accumulators)
     f32x4 res[2][3];
