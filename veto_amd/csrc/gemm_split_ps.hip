@@ -453,8 +453,8 @@ __global__ __launch_bounds__(64 * (NCONS + NLOAD), 3) void gemm_split_ps_kernel(
     const int row0 = tile_m * BM + wm * 64 + er;
     const int col0 = tile_n * BN + wn * 96 + eq * 4;
     const char* bias_lds = smem + kBiasOff + (it % kBiasSlices) * (BN * 4) + (wn * 96 + eq * 4) * 4;
-    // the epilogue walks 8 units of (16-row group m, half h of the 6 column groups); the residual of unit
-    // u+1 is in flight while unit u is stored (two buffers of 3 x 4 registers next to the 96 accumulators)
+    // the epilogue walks 8 units of (16-row group m, half h of the 6 column groups); EPI_RESID: the residual of unit
+    // u+1 is in flight while unit u is combined (two buffers of 3 x 4 registers next to the 96 accumulators)
     f32x4 res[2][3];
     auto load_res = [&](int u, f32x4 (&r)[3]) {
       int row = row0 + (u >> 1) * 16;
