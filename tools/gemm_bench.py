@@ -1,6 +1,5 @@
-"""Times the production split-bf16 GEMM (through veto_debug_gemm) on the QKV shape of cfg-2.
-Env knobs: VETO_GEMM_BM (128|256), VETO_GEMM_ABLATE (bit0 no global loads in the k-loop, bit1 no LDS
-fragment reads after step 0, bit2 no epilogue stores) -- ablated runs give wrong results, timing only."""
+"""Times the production GEMM (through veto_debug_gemm) on the four transformer shapes of cfg-2.
+usage: python tools/gemm_bench.py [n_shapes] [precision: 0 precise | 1 fast | 2 mixed]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -10,6 +9,7 @@ dev = torch.device("cuda:0")
 shapes = [(287280, 1728, 576), (287280, 576, 576), (287280, 1152, 576), (287280, 576, 1152)]
 if len(sys.argv) > 1:
     shapes = shapes[:int(sys.argv[1])]
+prec = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 for (m, n, k) in shapes:
     a = torch.randn(m, k, device=dev); w = torch.randn(n, k, device=dev) * 0.05
     c = torch.empty(m, n, device=dev)
@@ -17,7 +17,7 @@ for (m, n, k) in shapes:
     # veto_debug_gemm = split kernels + gemm; time the gemm alone via the difference to a split-only call is
     # fiddly, so time whole calls and subtract the measured split time (M=1 rows of N... negligible gemm)
     def run():
-        native.check(lib.veto_debug_gemm(None, a.data_ptr(), w.data_ptr(), None, c.data_ptr(), m, n, k, 0,
+        native.check(lib.veto_debug_gemm(None, a.data_ptr(), w.data_ptr(), None, c.data_ptr(), m, n, k, prec,
                                          ws.data_ptr(), ws.numel()))
     for _ in range(2): run()
     torch.cuda.synchronize()
