@@ -39,10 +39,11 @@ enum veto_status {
 };
 
 enum veto_precision {
-  VETO_PRECISE = 0,  /* 3-term split-bf16 MFMA, meets the 1e-3 logit tolerance (default) */
+  VETO_PRECISE = 0,  /* 3-term split-bf16 MFMA, meets the 1e-3 logit tolerance (2-3e-5 measured) */
   VETO_FAST = 1,     /* single bf16 MFMA pass, ~1e-2 logit error; reported separately */
   VETO_MIXED = 2     /* fp16 MFMA main product + e4m3 K=128 MFMA correction terms on the token-row Linears: 2/3 of the
-                        matrix-pipe time of VETO_PRECISE, logit error 5-7e-5 (1e-3 tolerance met with the same margin class) */
+                        matrix-pipe time of VETO_PRECISE, logit error 4-9e-5 measured (1e-3 tolerance); what the Python
+                        plugin selects by default (VETO_AMD.PRECISION = "mixed") */
 };
 
 /* MODEL.ROI_RELATION_HEAD.VETOTRANSFORMER.* (config/defaults.py:331-338) + class counts. */
