@@ -308,7 +308,8 @@ def test_training_backward_matches_reference_gradients(name):
 def test_relation_head_training_branch_end_to_end():
     """ROIRelationHead.forward in training mode on the device: GT-box relation sampling (budget 1024 / 25 % foreground),
     ROI pooling from FPN + depth maps, the predictor's loss with an autograd graph whose backward fills the predictor's
-    parameter gradients (the ROI features are plain inputs of the predictor: the relation stage trains the head only)."""
+    parameter gradients AND, through the ROI maps and the differentiable ROI pooling, reaches the feature maps: the reference
+    trains its depth backbone this way (tools/relation_train_net.py:166-170)."""
     from veto_amd import synth, testing
     from veto_amd.relation_head import VETORelationHead
     from veto_amd.structures import BoxList
@@ -316,7 +317,8 @@ def test_relation_head_training_branch_end_to_end():
     rng = np.random.RandomState(21)
     W, H = 512, 384
     feats = [torch.from_numpy((0.5 * rng.randn(2, 256, H >> (2 + l), W >> (2 + l))).astype(np.float32)).to(dev) for l in range(4)]
-    depth = torch.from_numpy((0.5 * rng.randn(2, 256, H >> 4, W >> 4)).astype(np.float32)).to(dev)
+    depth = torch.from_numpy((0.5 * rng.randn(2, 256, H >> 4, W >> 4)).astype(np.float32)).to(dev).requires_grad_(True)
+    feats[1].requires_grad_(True)
     cfg = testing.make_config(2, 8)
     head = VETORelationHead(cfg)
     head.predictor = testing.make_predictor(cfg, synth.predictor_state_dict(3, layers=2), dev)
@@ -341,6 +343,9 @@ def test_relation_head_training_branch_end_to_end():
     grads = [p.grad for p in head.predictor.parameters() if p.grad is not None]
     assert len(grads) >= 30 and all(torch.isfinite(g).all() for g in grads)
     assert float(head.predictor.rel_out.weight.grad.abs().max()) > 0
+    # the chain veto_backward -> d roi maps -> veto_roi_pool_backward -> feature maps is connected
+    assert depth.grad is not None and torch.isfinite(depth.grad).all() and float(depth.grad.abs().max()) > 0
+    assert feats[1].grad is not None and torch.isfinite(feats[1].grad).all()
 
 
 @pytest.mark.gpu
