@@ -49,10 +49,13 @@ __device__ __forceinline__ void split_bf16(float x, __bf16& hi, __bf16& lo) {
 // (profiles/r02_mfma_mix_probe.txt); measured logit error 5-7e-5 against 2-3e-5 (tools/precision_study.py).
 //
 // A logical row of K fp32 values (K % 64 == 0) is 4K bytes, in blocks of 64 k's = 256 B:
-//   [ h: 64 x fp16 (128 B) | X: 64 x e4m3 (64 B) | Y: 64 x e4m3 (64 B) ]
+//   [ h: 64 x fp16 (128 B) | 16 groups of 8 B, group j = { X(4 j .. 4 j + 3), Y(4 j .. 4 j + 3) }: 64 + 64 x e4m3 (128 B) ]
 //   activation rows: X = e4m3(2^15 (a - h)),  Y = e4m3(2^4 a)
 //   weight rows:     X = e4m3(2^e h),         Y = e4m3(2^(e+11) (w - h)),   e per tensor (kept on the device)
 // so that sum X_a X_w + Y_a Y_w = 2^(15+e) (al wh + ah wl); the MFMA's E8M0 scale operand undoes the 2^(15+e).
+// (The K = 128 MFMA sums the products of corresponding bytes of the two operands' 128-byte stage rows, so ANY byte order that
+// activation and weight rows share is right; this one lets a producer that owns 4 consecutive columns write its X and Y
+// bytes as ONE 8-byte store and one that owns 8 columns as one 16-byte store.)
 // e4m3 conversions do NOT saturate on gfx950 (480 -> NaN, profiles/r02_mfma_mix_probe.txt): values are clamped to +-448.
 // One GEMM stage (128 B of a row) is either the h part or the X|Y part of a block: same addressing as the split rows.
 enum OperandFmt { FMT_SPLIT = 0, FMT_MIXED = 1 };
@@ -67,9 +70,11 @@ __device__ __forceinline__ uint32_t pack_e4m3x4(float a, float b, float c, float
   r = __builtin_amdgcn_cvt_pk_fp8_f32(clamp448(c), clamp448(d), r, true);
   return (uint32_t)r;
 }
-// byte offset of column k's fp16 inside a mixed row; its X byte is at mixed_x_offset(k), its Y byte 64 further
+// byte offset of column k's fp16 inside a mixed row; its X byte is at mixed_x_offset(k), its Y byte 4 further
 __host__ __device__ __forceinline__ int mixed_h_offset(int k) { return ((k >> 6) << 8) + ((k & 63) << 1); }
-__host__ __device__ __forceinline__ int mixed_x_offset(int k) { return ((k >> 6) << 8) + 128 + (k & 63); }
+__host__ __device__ __forceinline__ int mixed_x_offset(int k) { return ((k >> 6) << 8) + 128 + (((k & 63) >> 2) << 3) + (k & 3); }
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 
 // 4 consecutive columns (col % 4 == 0) of an ACTIVATION row in either operand format; `row` = first byte of the row
 template <int FMT>
@@ -96,17 +101,14 @@ __device__ __forceinline__ void store_act4(__bf16* row, int col, f32x4 v) {
       l[e] = (v[e] - (float)h[e]) * (float)(1 << kMixActExp);
     }
     *(f16x4*)(base + mixed_h_offset(col)) = h;
-    char* x = base + mixed_x_offset(col);
-    *(uint32_t*)x = pack_e4m3x4(l[0], l[1], l[2], l[3]);
     constexpr float ys = (float)(1 << kMixActHiExp);
-    *(uint32_t*)(x + 64) = pack_e4m3x4(v[0] * ys, v[1] * ys, v[2] * ys, v[3] * ys);
+    *(u32x2*)(base + mixed_x_offset(col)) = u32x2{pack_e4m3x4(l[0], l[1], l[2], l[3]), pack_e4m3x4(v[0] * ys, v[1] * ys, v[2] * ys, v[3] * ys)};
   }
 }
 
-// 8 consecutive columns (col % 8 == 0) of a mixed activation row: one 16-byte and two 8-byte stores
+// 8 consecutive columns (col % 8 == 0) of a mixed activation row: two 16-byte stores
 __device__ __forceinline__ void store_act8_mixed(__bf16* row, int col, f32x4 v0, f32x4 v1) {
   typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
-  typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
   char* base = (char*)row;
   f16x8_t h;
   float l[8], y[8];
@@ -119,9 +121,8 @@ __device__ __forceinline__ void store_act8_mixed(__bf16* row, int col, f32x4 v0,
     y[e] = x * ys;
   }
   *(f16x8_t*)(base + mixed_h_offset(col)) = h;
-  char* x = base + mixed_x_offset(col);
-  *(u32x2*)x = u32x2{pack_e4m3x4(l[0], l[1], l[2], l[3]), pack_e4m3x4(l[4], l[5], l[6], l[7])};
-  *(u32x2*)(x + 64) = u32x2{pack_e4m3x4(y[0], y[1], y[2], y[3]), pack_e4m3x4(y[4], y[5], y[6], y[7])};
+  *(u32x4*)(base + mixed_x_offset(col)) = u32x4{pack_e4m3x4(l[0], l[1], l[2], l[3]), pack_e4m3x4(y[0], y[1], y[2], y[3]),
+                                                pack_e4m3x4(l[4], l[5], l[6], l[7]), pack_e4m3x4(y[4], y[5], y[6], y[7])};
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

@@ -63,7 +63,7 @@ __device__ __forceinline__ int weight_exp_of(unsigned maxbits) {
   while (e > 0 && !(ldexpf(mx, e) <= 448.f)) --e;
   return e;
 }
-// Pass 2: 4 consecutive k's per thread: h = fp16(w) (8 B), X = e4m3(2^e h) (4 B), Y = e4m3(2^(e+11) (w - h)) (4 B)
+// Pass 2: 4 consecutive k's per thread: h = fp16(w) (8 B), { X = e4m3(2^e h), Y = e4m3(2^(e+11) (w - h)) } (8 B)
 __global__ void mixed_weight_rows_kernel(const float* __restrict__ src, __bf16* __restrict__ dst, size_t n, int K,
                                          const int* __restrict__ maxbits) {
   const int e = weight_exp_of((unsigned)*maxbits);
@@ -82,8 +82,7 @@ __global__ void mixed_weight_rows_kernel(const float* __restrict__ src, __bf16* 
       y[j] = (w[j] - (float)h[j]) * sy;
     }
     *(f16x4*)(base + mixed_h_offset(k)) = h;
-    *(uint32_t*)(base + mixed_x_offset(k)) = pack_e4m3x4(x[0], x[1], x[2], x[3]);
-    *(uint32_t*)(base + mixed_x_offset(k) + 64) = pack_e4m3x4(y[0], y[1], y[2], y[3]);
+    *(u32x2*)(base + mixed_x_offset(k)) = u32x2{pack_e4m3x4(x[0], x[1], x[2], x[3]), pack_e4m3x4(y[0], y[1], y[2], y[3])};
   }
 }
 // Pass 3: replace the float bits by the exponent itself (what the GEMM reads)
