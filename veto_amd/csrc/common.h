@@ -70,6 +70,17 @@ __device__ __forceinline__ uint32_t pack_e4m3x4(float a, float b, float c, float
   r = __builtin_amdgcn_cvt_pk_fp8_f32(clamp448(c), clamp448(d), r, true);
   return (uint32_t)r;
 }
+// e4m3(x * 2^EXP) for four values with the power-of-two scale folded into the conversion (v_cvt_scalef32_pk_fp8_f32 converts
+// x / scale; tools/micro/cvt_probe.hip); the clamp moves in front of the scale: |x| <= 448 * 2^-EXP
+template <int EXP>
+__device__ __forceinline__ uint32_t pack_e4m3x4_scaled(float a, float b, float c, float d) {
+  typedef short v2s __attribute__((ext_vector_type(2)));
+  constexpr float lim = 448.f / (float)(1 << EXP), inv = 1.f / (float)(1 << EXP);
+  v2s r = {0, 0};
+  r = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(r, __builtin_amdgcn_fmed3f(a, -lim, lim), __builtin_amdgcn_fmed3f(b, -lim, lim), inv, false);
+  r = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(r, __builtin_amdgcn_fmed3f(c, -lim, lim), __builtin_amdgcn_fmed3f(d, -lim, lim), inv, true);
+  return __builtin_bit_cast(uint32_t, r);
+}
 // byte offset of column k's fp16 inside a mixed row; its X byte is at mixed_x_offset(k), its Y byte 4 further
 __host__ __device__ __forceinline__ int mixed_h_offset(int k) { return ((k >> 6) << 8) + ((k & 63) << 1); }
 __host__ __device__ __forceinline__ int mixed_x_offset(int k) { return ((k >> 6) << 8) + 128 + (((k & 63) >> 2) << 3) + (k & 3); }
@@ -98,11 +109,11 @@ __device__ __forceinline__ void store_act4(__bf16* row, int col, f32x4 v) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       h[e] = (_Float16)v[e];
-      l[e] = (v[e] - (float)h[e]) * (float)(1 << kMixActExp);
+      l[e] = v[e] - (float)h[e];
     }
     *(f16x4*)(base + mixed_h_offset(col)) = h;
-    constexpr float ys = (float)(1 << kMixActHiExp);
-    *(u32x2*)(base + mixed_x_offset(col)) = u32x2{pack_e4m3x4(l[0], l[1], l[2], l[3]), pack_e4m3x4(v[0] * ys, v[1] * ys, v[2] * ys, v[3] * ys)};
+    *(u32x2*)(base + mixed_x_offset(col)) = u32x2{pack_e4m3x4_scaled<kMixActExp>(l[0], l[1], l[2], l[3]),
+                                                  pack_e4m3x4_scaled<kMixActHiExp>(v[0], v[1], v[2], v[3])};
   }
 }
 
@@ -112,17 +123,16 @@ __device__ __forceinline__ void store_act8_mixed(__bf16* row, int col, f32x4 v0,
   char* base = (char*)row;
   f16x8_t h;
   float l[8], y[8];
-  constexpr float ys = (float)(1 << kMixActHiExp);
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     const float x = e < 4 ? v0[e] : v1[e - 4];
     h[e] = (_Float16)x;
-    l[e] = (x - (float)h[e]) * (float)(1 << kMixActExp);
-    y[e] = x * ys;
+    l[e] = x - (float)h[e];
+    y[e] = x;
   }
   *(f16x8_t*)(base + mixed_h_offset(col)) = h;
-  *(u32x4*)(base + mixed_x_offset(col)) = u32x4{pack_e4m3x4(l[0], l[1], l[2], l[3]), pack_e4m3x4(y[0], y[1], y[2], y[3]),
-                                                pack_e4m3x4(l[4], l[5], l[6], l[7]), pack_e4m3x4(y[4], y[5], y[6], y[7])};
+  *(u32x4*)(base + mixed_x_offset(col)) = u32x4{pack_e4m3x4_scaled<kMixActExp>(l[0], l[1], l[2], l[3]), pack_e4m3x4_scaled<kMixActHiExp>(y[0], y[1], y[2], y[3]),
+                                                pack_e4m3x4_scaled<kMixActExp>(l[4], l[5], l[6], l[7]), pack_e4m3x4_scaled<kMixActHiExp>(y[4], y[5], y[6], y[7])};
 }
 
 __device__ __forceinline__ float wave_sum(float v) {
