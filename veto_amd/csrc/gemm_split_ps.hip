@@ -135,8 +135,17 @@ __global__ __launch_bounds__(64 * (NCONS + NLOAD), 3) void gemm_split_ps_kernel(
   // tile of round `it` for this workgroup; gridDim.x is a multiple of 8 (launcher)
   const int per_xcd = gridDim.x >> 3;
   // g.panel_major (A/B, speed only): a workgroup walks the tiles_n tiles of ONE row panel back to back (panels dealt like tiles)
-  const int pm = g.panel_major ? g.tiles_n : 1;
-  auto tile_of = [&](int it) { return ((it / pm * 8 + (b & 7)) * per_xcd + (b >> 3)) * pm + it % pm; };
+  const int pm = g.panel_major == 1 ? g.tiles_n : 1;
+  // g.panel_major == 2 (A/B, speed only; tiles_n even): the XCDs work in pairs, each XCD of a pair on one HALF of the column
+  // tiles of the same row panels, so that its half of the weight matrix stays in its 4 MB L2
+  const int hn = g.tiles_n >> 1;
+  auto tile_of = [&](int it) {
+    if (g.panel_major == 2) {
+      const int lin = (it * 4 + ((b & 7) >> 1)) * per_xcd + (b >> 3);
+      return (lin / hn) * g.tiles_n + (b & 1) * hn + lin % hn;
+    }
+    return ((it / pm * 8 + (b & 7)) * per_xcd + (b >> 3)) * pm + it % pm;
+  };
   int my_tiles = 0;
   while (tile_of(my_tiles) < ntiles) ++my_tiles;  // tile_of is increasing in `it`
   if (my_tiles == 0) return;
@@ -582,7 +591,6 @@ hipError_t launch_gemm_split_ps(GemmArgs g, int epi, int precision, hipStream_t 
   static const int stagger = getenv("VETO_GEMM_STAGGER") ? atoi(getenv("VETO_GEMM_STAGGER")) : 0;
   g.stagger = stagger;
   static const int panel_major = getenv("VETO_GEMM_PANEL") ? atoi(getenv("VETO_GEMM_PANEL")) : 0;   // A/B knob (speed only)
-  g.panel_major = panel_major && g.tiles_n == 3 && (epi == EPI_RESID);
   static int num_cu = 0;
   if (num_cu == 0) {
     int dev = 0;
@@ -592,6 +600,8 @@ hipError_t launch_gemm_split_ps(GemmArgs g, int epi, int precision, hipStream_t 
     if (num_cu < 8) num_cu = 8;
   }
   const int ksp = epi == EPI_ATOMIC && g.k_splits > 1 ? g.k_splits : 1;
+  g.panel_major = (panel_major == 1 && g.tiles_n == 3 && epi == EPI_RESID) ? 1
+                  : (panel_major == 2 && g.tiles_n % 2 == 0 && g.tiles_n >= 4 && ksp == 1 && !g.tn) ? 2 : 0;
   if ((g.K / BK) % ksp != 0) return hipErrorInvalidValue;
   if (g.tn && (epi != EPI_ATOMIC || !g.zero || g.lda <= 0 || g.ldw <= 0 || g.k_valid <= 0 || g.k_valid > g.K)) return hipErrorInvalidValue;
   const int ntiles = g.tiles_m * g.tiles_n * ksp;
