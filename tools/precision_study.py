@@ -79,9 +79,21 @@ QKV_PARTS = "qkv"
 QKV_DT = None   # storage type of q, k, v between the projection and the attention (None = fp32)
 
 
+QK_SCALE = 1.0   # --sharp: q / k rows of every to_qkv weight scaled by this (sharper attention); the yardstick is then the fp64 oracle
+
+
 def run(name, scheme):
     g, sd, batch = load_golden(name)
     cfg = vo.OracleConfig(layers=g["_layers"], heads=g["_heads"])
+    if QK_SCALE != 1.0:
+        sd = dict(sd)
+        for l in range(cfg.layers):
+            k = "fusion_transformer.transformer.layers.%d.0.fn.to_qkv.weight" % l
+            w = np.array(sd[k]).copy()
+            w[:2 * cfg.dim] *= QK_SCALE
+            sd[k] = w
+        ref64, _, _ = vo.forward(sd, cfg, batch, dtype=torch.float64)
+        g = dict(g, rel_dists=ref64.numpy())
     mm = make_mm(scheme)
     orig = vo.encoder_layer
 
@@ -95,7 +107,11 @@ def run(name, scheme):
         qkv = mm(y.reshape(-1, D), T("0.fn.to_qkv.weight")).reshape(b, n, 3 * D)
         if QKV_DT is not None and 0 < l < cfg_.layers - 1:     # the middle layers materialise q, k, v
             r = qkv.to(QKV_DT).float()
-            if QKV_PARTS == "qk":
+            if QKV_PARTS == "qk+v3":     # q, k as fp16; v as fp16 + e4m3 residual (3 bytes)
+                v = qkv[..., 2 * D:]
+                vh = v.to(torch.float16).float()
+                r[..., 2 * D:] = vh + q_e4m3(v - vh, 2.0 ** 15)
+            elif QKV_PARTS == "qk":
                 r[..., 2 * D:] = qkv[..., 2 * D:]
             elif QKV_PARTS == "v":
                 r[..., :2 * D] = qkv[..., :2 * D]
@@ -119,8 +135,18 @@ def run(name, scheme):
 
 if __name__ == "__main__":
     names = [a for a in sys.argv[1:] if not a.startswith("--")] or ["predcls_n10_l4h8", "predcls_n36_l4h8", "predcls_n36_l6h6"]
+    if "--sharp" in sys.argv:
+        # storage type of q / k / v under sharper attention than the random-init fixtures have (mean max-probability of a softmax
+        # row: 0.07 at scale 1, 0.33 at 3, 0.70 at 5): fp16 q / k is free at scale 1 and breaks the 1e-3 bar at scale 5
+        for sc in (1.0, 3.0, 5.0):
+            QK_SCALE = sc
+            for dt, parts in ((None, "qkv"), (torch.float16, "qk+v3")):
+                QKV_DT, QKV_PARTS = dt, parts
+                print("q/k weight scale %g, q/k/v stored as %s:" % (sc, "fp32" if dt is None else "fp16 q, k + 3-byte v"),
+                      "  ".join("%s %.2e" % (n, run(n, "f16+e4m3")) for n in names), flush=True)
+        sys.exit(0)
     if "--qkv16" in sys.argv:
-        for dt, parts in ((None, "qkv"), (torch.float16, "qkv"), (torch.float16, "qk"), (torch.float16, "v"), (torch.bfloat16, "qkv")):
+        for dt, parts in ((None, "qkv"), (torch.float16, "qkv"), (torch.float16, "qk"), (torch.float16, "qk+v3"), (torch.float16, "v"), (torch.bfloat16, "qkv")):
             QKV_DT, QKV_PARTS = dt, parts
             print("%s stored as %s, Linears f16+e4m3:" % (parts, dt), "  ".join("%s %.2e" % (n, run(n, "f16+e4m3")) for n in names), flush=True)
         sys.exit(0)
