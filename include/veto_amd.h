@@ -290,6 +290,16 @@ int veto_debug_gemm(void* stream, const float* a, const float* w, const float* b
                     int32_t n, int32_t k, int32_t precision, void* workspace, size_t workspace_bytes);
 size_t veto_debug_gemm_workspace_bytes(int32_t m, int32_t n, int32_t k);
 
+/* ---- test / measurement hook: the FeedForward block of one layer, x <- x + W2 . gelu(W1 . a + b1) + b2 (model_veto.py:137-143
+ * with the residual of :21) on VETO_MIXED operands; mode 0 = two GEMM launches with the hidden activation in HBM, mode 1 = the
+ * fused kernel (hidden activation stays on the CU).  a [m, 576] (the LayerNorm'ed rows), w1 [1152, 576], w2 [576, 1152],
+ * x [m, 576] in / out.  flags & 1: rebuild the mixed operands in the workspace first.  Runs `reps` times; *ms_per_rep (host,
+ * optional) = mean device time of one run. */
+int veto_debug_ffn(void* stream, const float* a, const float* w1, const float* b1, const float* w2, const float* b2,
+                   float* x, int32_t m, int32_t mode, int32_t flags, int32_t reps, float* ms_per_rep, void* workspace,
+                   size_t workspace_bytes);
+size_t veto_debug_ffn_workspace_bytes(int32_t m);
+
 /* ---- training losses and MEET expert sampling (partial) -------------------------
  * veto_ce_loss: nn.CrossEntropyLoss(weight)(logits[rows], labels), mean reduction -- the relation loss of
  * VETOPredictor.forward (roi_relation_predictors.py:4133, BETA_LOSS weights :4057-4068) and, on a row subset with

@@ -5,7 +5,7 @@ import subprocess
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libveto_amd.so")
-SOURCES = ["gemm_split_ps.hip", "rowops.hip", "attention.hip", "postprocess.hip", "roialign.hip", "sgg_eval.hip", "losses.hip", "backward.hip", "train.hip", "veto_abi.hip"]
+SOURCES = ["gemm_split_ps.hip", "ffn_fused.hip", "rowops.hip", "attention.hip", "postprocess.hip", "roialign.hip", "sgg_eval.hip", "losses.hip", "backward.hip", "train.hip", "veto_abi.hip"]
 HEADERS = ["common.h", "kernels.h", os.path.join("..", "..", "include", "veto_amd.h")]
 
 

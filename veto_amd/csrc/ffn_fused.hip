@@ -1,0 +1,458 @@
+// Fused FeedForward of the VETO relation transformer (model_veto.py:137-143 with the residual of :21):
+//
+//   x <- x + W2 . gelu(W1 . a + b1) + b2        a = LayerNorm2(x) as mixed rows (common.h), W1 [1152, 576], W2 [576, 1152]
+//
+// in ONE launch: the 1152-wide hidden activation never leaves the CU (the two-launch form writes it to HBM as a 1.3 GB
+// mixed-row matrix and reads it back).  VETO_MIXED operands only (fp16 main product + e4m3 correction terms).
+//
+// One persistent workgroup per CU, 8 waves at two waves per SIMD (<= 256 registers), walks 128-row panels.  Per panel the
+// [128 x 576] fp32 result stays in registers (144 per lane) while the hidden dimension is walked in 6 chunks of 192 columns:
+//
+//   fc1 phase   18 stages (9 blocks of 64 k's x {fp16 part, e4m3 part}): [128 x 192] += a[128, stage] . W1[chunk, stage]^T,
+//               48 accumulator registers per lane
+//   fc2 phase   per 64 hidden columns (3 per chunk): bias + GELU + conversion of those columns to the mixed-row format into an
+//               LDS image (same layout as a DMA'd activation stage), then 6 sub-stages {fp16, e4m3} x 3 column thirds of
+//               W2[third, block]: [128 x 192 of 576] += hidden[128, 64] . W2^T
+//
+// Wave (wm, wn) = (w >> 2, w & 3) owns rows 64 wm .. 64 wm + 63 and, of every 64-column group of a stage's weight rows, the 16
+// columns 16 wn ..: its 16-column block j of a chunk is the hidden units 64 j + 16 wn .., so that the hidden block j the fc2
+// phase consumes is complete as soon as every wave has converted ITS block j, and lies in natural k order (no weight
+// re-layout: the kernel reads the same fc1 / fc2 mixed weight rows as the two-launch form).
+//
+// Every stage is 128 bytes of every row, exactly as in gemm_split_ps.hip: LDS-DMA (global_load_lds_dwordx4) with the
+// source-side XOR swizzle, conflict-free ds_read_b128 fragments, MFMA issued with the weights as the A operand.  There are
+// no loader waves (twelve waves would cap the kernel at 168 registers): every wave issues its share of the DMA of stage T + 2
+// at the start of interval T (5 instructions for an fc1 stage: 16 KiB of activations + 24 KiB of W1; 3 for an fc2 sub-stage:
+// 24 KiB of W2) into a ring of three 40 KiB slots; one s_barrier per interval.
+//
+// Results depend on the row alone (fixed k order, no split-K): bit-identical under batch / chunk / permutation changes.
+//
+// -DVETO_FFN_STAMPS builds a diagnostic copy that accumulates s_memtime deltas per phase.
+#include "common.h"
+#include "kernels.h"
+
+#include <cstdio>
+#include <cstdlib>
+
+#ifndef FFN_AGPR
+#define FFN_AGPR 0
+#endif
+
+
+namespace veto {
+
+namespace {
+
+constexpr int FR = 128;                     // rows per panel
+constexpr int FC = 192;                     // hidden columns per chunk
+constexpr int FH = 2 * kDim;                // hidden width 1152
+constexpr int kChunks = FH / FC;            // 6
+constexpr int kRow1 = kDim * 4;             // bytes of a mixed row with K = 576 (activation rows, W1 rows)
+constexpr int kRow2 = FH * 4;               // ... with K = 1152 (W2 rows)
+constexpr int kS1 = kDim / 64 * 2;          // 18 fc1 stages per chunk
+constexpr int kS2 = FC / 64 * 2 * 3;        // 18 fc2 sub-stages per chunk
+constexpr int kPer = kS1 + kS2;             // stages per chunk
+constexpr int kAB = FR * 128;               // activation part of a ring slot: 16 KiB
+constexpr int kWB = FC * 128;               // weight part: 24 KiB
+constexpr int kSlot = kAB + kWB;
+constexpr int kRing = 3;
+constexpr int kHidOff = kRing * kSlot;      // hidden block: fp16 image [128 x 128 B], e4m3 image behind it
+constexpr int kB1Off = kHidOff + 2 * kAB;
+constexpr int kB2Off = kB1Off + FH * 4;
+constexpr int kLds = kB2Off + kDim * 4;     // 162 560 B of the 163 840
+static_assert(kLds <= 163840, "LDS budget");
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+template <int V> struct Tag { static constexpr int value = V; };
+
+// One LDS-DMA instruction: 64 lanes x 16 bytes from (uniform base + 32-bit lane offset) to LDS address m0 + 16 * lane.
+// Inline asm: the saddr form costs no address arithmetic on the vector side, and the compiler's wait-count pass does not see
+// the transfer (it would otherwise put s_waitcnt vmcnt(0) in front of every later ds_read of this wave; the kernel counts
+// its own vmcnt).  The s_nop covers the SALU-writes-M0 -> LDS-DMA wait state and the five states between a scalar write of
+// the base (the compiler computes it right in front of the statement) and its use by a vector-memory instruction.
+__device__ __forceinline__ void glds16(const char* base, unsigned voff, unsigned lds_addr) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_addr), "v"(voff), "s"(base) : "memory");
+}
+__device__ __forceinline__ void wg_barrier() {
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
+#ifdef VETO_FFN_STAMPS
+__device__ unsigned long long g_ffn_stamps[256 * 8];
+__device__ __forceinline__ unsigned long long stamp() {
+  __builtin_amdgcn_sched_barrier(0);
+  unsigned long long t;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  __builtin_amdgcn_sched_barrier(0);
+  return t;
+}
+#define STAMP(x) x = stamp()
+#define ACC(a, t1, t0) a += (t1) - (t0)
+#else
+#define STAMP(x)
+#define ACC(a, t1, t0)
+#endif
+
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(Tag<I>());
+    static_for<I + 1, N>(f);
+  }
+}
+
+__global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs g) {
+  __shared__ __attribute__((aligned(16))) char smem[kLds];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = w >> 1, wn = w & 1;          // 4 x 2 waves: rows 32 wm .., of every 64 weight rows of a stage the 32 at 32 wn
+  const int G = gridDim.x, b = blockIdx.x;
+#if FFN_AGPR
+  {   // an inline asm that names an accumulator register makes the compiler select the AGPR form of the MFMAs: the 192
+      // accumulators then live in their own register class and the vector registers hold fragments and addresses only
+    int agpr_probe = 0;
+    asm volatile("" : "+a"(agpr_probe));
+  }
+#endif
+  const int my_panels = g.n_panels > b ? (g.n_panels - b + G - 1) / G : 0;   // panels b, b + G, ...
+  if (my_panels == 0) return;
+
+  for (int i = tid; i < FH; i += 512) ((float*)(smem + kB1Off))[i] = g.b1[i];
+  for (int i = tid; i < kDim; i += 512) ((float*)(smem + kB2Off))[i] = g.b2[i];
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  wg_barrier();
+
+  // ---- DMA side: this wave's pieces (8 rows x 128 B each) are w, w + 8 (, w + 16) of a stage image ----------------------
+  // Addresses are (uniform base) + (32-bit lane offset): two registers of lane state in all.
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+  const int rr = lane >> 3;
+  const int r16 = ((w & 1) << 3) + rr;                                   // row inside its 16-row group (w + 8 k keeps the parity)
+  const int slot16 = ((lane & 7) ^ ((r16 >> 1) & 7)) << 4;               // source-side swizzle (the LDS side is lane-linear)
+  const unsigned voff1 = (unsigned)((w * 8 + rr) * kRow1 + slot16);
+  const unsigned voff2 = (unsigned)((w * 8 + rr) * kRow2 + slot16);
+  auto panel_base = [&](int it) { return g.a + (size_t)(b + (size_t)it * G) * ((size_t)FR * kRow1); };
+  // instruction k (of 5) of fc1 stage ks of hidden chunk c: 16 KiB of activation rows (k = 0, 1) + 24 KiB of W1 rows (2..4)
+  auto issue_fc1 = [&](const char* a_panel, int c, int ks, int slot, int k) {
+    const unsigned dst = lds0 + slot * kSlot + w * 1024;
+    if (k < 2) glds16(a_panel + ks * 128 + k * 64 * kRow1, voff1, dst + k * 8 * 1024);
+    else glds16(g.w1 + (size_t)c * ((size_t)FC * kRow1) + ks * 128 + (k - 2) * 64 * kRow1, voff1, dst + kAB + (k - 2) * 8 * 1024);
+  };
+  // instruction k (of 3) of an fc2 sub-stage: 24 KiB of W2 rows (column third t, 128-byte slice `slice` of the row)
+  auto issue_fc2 = [&](int slice, int t, int slot, int k) {
+    const unsigned dst = lds0 + slot * kSlot + w * 1024 + kAB;
+    glds16(g.w2 + (size_t)t * ((size_t)FC * kRow2) + slice * 128 + (size_t)k * 64 * kRow2, voff2, dst + k * 8 * 1024);
+  };
+
+  // ---- MFMA side ---------------------------------------------------------------------------------------------------------
+  // block i = 0..5 of a wave = weight rows (i >> 1) * 64 + wn * 32 + (i & 1) * 16 of the stage; row group m = 0, 1
+  const int fr = lane & 15, fq = lane >> 4;
+  const int frag_off = fr * 128 + ((fq ^ ((fr >> 1) & 7)) << 4);
+  const int a_off = (wm * 32) * 128 + frag_off;            // + m * 2048
+  const int w_off = kAB + (wn * 32) * 128 + frag_off;      // + (i >> 1) * 8192 + (i & 1) * 2048
+  const int sc1 = (127 - kMixActExp - __builtin_amdgcn_readfirstlane(*g.exp1)) * 0x01010101;
+  const int sc2 = (127 - kMixActExp - __builtin_amdgcn_readfirstlane(*g.exp2)) * 0x01010101;
+
+
+  // The MFMAs are inline asm with the accumulator tied ("+v"): with 192 of 256 registers in accumulators the compiler's
+  // untied forms rename them from stage to stage and spill on the way back (measured: 266 spilled registers; scratch
+  // traffic also shares vmcnt with the DMA).  Hazards the compiler no longer pads (it does not know the statement is an MFMA):
+  //  * a VALU write of an operand right in front of the MFMA -- the register allocator does insert such copies, e.g. it moved
+  //    one accumulator block into its final registers two instructions ahead of its first MFMA, and the last two registers of
+  //    the block were read stale (measured) -- : s_nop 1 opens the first MFMA of every accumulator step;
+  //  * the first VALU / LDS read of an accumulator behind its last MFMA: mfma_drain*() below, tied to those accumulators;
+  //  * an accumulator chain needs none; operands come from ds_read (waited for through the register dependency).
+  // tools/audit_ffn_asm.py checks the generated code for compiler instructions that touch accumulator registers near an MFMA.
+  auto mma = [&](auto kind_tag, f32x4& acc, const i32x4& fw0, const i32x4& fw1, const i32x4& fa0, const i32x4& fa1, int scale) {
+    constexpr int KIND = decltype(kind_tag)::value;
+    if constexpr (KIND == 0) {
+      asm("s_nop 1\n\tv_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(fw0), "v"(fa0));
+      asm("s_nop 1\n\tv_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(fw1), "v"(fa1));
+    } else {
+      const i32x8 w8 = __builtin_shufflevector(fw0, fw1, 0, 1, 2, 3, 4, 5, 6, 7), a8 = __builtin_shufflevector(fa0, fa1, 0, 1, 2, 3, 4, 5, 6, 7);
+      asm("s_nop 1\n\tv_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0]" : "+v"(acc) : "v"(w8), "v"(a8), "v"(scale), "v"(0x7f7f7f7f));
+    }
+  };
+  // MFMA result -> VALU / LDS reader: more than 18 wait states, tied to the accumulators it fences (the MFMA statements are
+  // register-only: nothing else orders them against a later statement)
+  auto mfma_drain3 = [&](f32x4& a, f32x4& b, f32x4& c) { asm volatile("s_nop 15\n\ts_nop 15" : "+v"(a), "+v"(b), "+v"(c)); };
+  auto mfma_drain4 = [&](f32x4& a, f32x4& b, f32x4& c, f32x4& d) {
+    asm volatile("s_nop 15\n\ts_nop 15" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+  };
+  // One stage: the activation image at LDS offset AB (a ring slot's A part, or a hidden image) x the weight part of the ring
+  // slot at SB (compile-time constants).  Register budget: 192 accumulators leave ~50 registers: the two activation fragments
+  // of the wave are held (16), the six weight fragments stream through two buffers (16), and the four LDS addresses are
+  // re-derived per stage from one lane register (laundered through an empty asm: the compiler would otherwise keep a dozen
+  // loop-invariant address registers live, and spill).  Group i = the reads of weight fragment i + 1, the MFMAs of fragment
+  // i, then one of this wave's DMA instructions for the stage two positions on (`dma(k)`, k < 5): an LDS-DMA issue waits
+  // 100-200 cycles in back-pressure, during which the matrix pipe runs this group's MFMAs, then the SIMD partner's.
+  // sched_barrier(0) after every group keeps that order.
+  typedef __attribute__((address_space(3))) i32x4 lds_i32x4_t;
+  typedef const lds_i32x4_t* lds_frag_t;
+  auto stage = [&](auto kind_tag, auto ab_tag, auto sb_tag, f32x4 (&acc)[6][2], int scale, auto&& dma) {
+    constexpr int AB = decltype(ab_tag)::value, SB = decltype(sb_tag)::value;
+    int fo = frag_off;
+    asm volatile("" : "+v"(fo));
+    const unsigned a0 = lds0 + AB + wm * 4096 + fo, a1 = lds0 + AB + wm * 4096 + (fo ^ 64);
+    const unsigned w0 = lds0 + SB + kAB + wn * 4096 + fo, w1 = lds0 + SB + kAB + wn * 4096 + (fo ^ 64);
+    i32x4 fa0[2], fa1[2], fw0[2], fw1[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      fa0[m] = *(lds_frag_t)(size_t)(a0 + m * 2048);
+      fa1[m] = *(lds_frag_t)(size_t)(a1 + m * 2048);
+    }
+    fw0[0] = *(lds_frag_t)(size_t)(w0);
+    fw1[0] = *(lds_frag_t)(size_t)(w1);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      if (i < 5) {
+        fw0[(i + 1) & 1] = *(lds_frag_t)(size_t)(w0 + ((i + 1) >> 1) * 8192 + ((i + 1) & 1) * 2048);
+        fw1[(i + 1) & 1] = *(lds_frag_t)(size_t)(w1 + ((i + 1) >> 1) * 8192 + ((i + 1) & 1) * 2048);
+      }
+#pragma unroll
+      for (int m = 0; m < 2; ++m) mma(kind_tag, acc[i][m], fw0[i & 1], fw1[i & 1], fa0[m], fa1[m], scale);
+      dma(i);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  // bias + GELU + mixed-row conversion of hidden block J of chunk c (this wave's 32 columns x 32 rows) into the hidden images
+  auto hidden_write = [&](auto j_tag, int c, f32x4 (&acc1)[6][2]) {
+    constexpr int J = decltype(j_tag)::value;
+    int lane_h = lane;
+    asm volatile("" : "+v"(lane_h));                                    // recompute the lane offsets here: nothing to keep live
+    const int hr = lane_h & 15, hq = lane_h >> 4;
+    // every value is converted first, the eight LDS stores follow in one run behind a scheduling fence: the compiler merges the
+    // two row groups of a block into one ds_write2st64_b64 and, left alone, overwrites its last data register in the very next
+    // instruction (measured: exactly those two fp16 values of row group 1 reached the LDS corrupted)
+    f16x4 hh[2][2];
+    u32x2 xy[2][2];
+#pragma unroll
+    for (int ib = 0; ib < 2; ++ib) {
+      const f32x4 bias = *(const f32x4*)(smem + kB1Off + (c * FC + J * 64 + wn * 32 + ib * 16 + hq * 4) * 4);
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        f32x4 v = acc1[2 * J + ib][m] + bias;
+        float l[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[e] = gelu_sigmoid(v[e]);
+          hh[ib][m][e] = (_Float16)v[e];
+          l[e] = v[e] - (float)hh[ib][m][e];
+        }
+        xy[ib][m] = u32x2{pack_e4m3x4_scaled<kMixActExp>(l[0], l[1], l[2], l[3]), pack_e4m3x4_scaled<kMixActHiExp>(v[0], v[1], v[2], v[3])};
+      }
+    }
+#pragma unroll
+    for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+      for (int m = 0; m < 2; ++m) asm volatile("" : "+v"(hh[ib][m]), "+v"(xy[ib][m]));
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ib = 0; ib < 2; ++ib) {
+      const int ls = wn * 4 + ib * 2 + (hq >> 1);                       // 16-byte slot of this lane's 4 columns in the 128-byte row
+      char* hp = smem + kHidOff + (wm * 32 + hr) * 128 + ((ls ^ ((hr >> 1) & 7)) << 4) + (hq & 1) * 8;
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        *(f16x4*)(hp + m * 2048) = hh[ib][m];
+        *(u32x2*)(hp + kAB + m * 2048) = xy[ib][m];
+      }
+    }
+  };
+
+  unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t_begin = 0, s_wait = 0, s_bar = 0, s_iss = 0, s_cmp = 0, s_hid = 0, s_epi = 0;
+  (void)t0; (void)t1; (void)t2; (void)t3; (void)t_begin; (void)s_wait; (void)s_bar; (void)s_iss; (void)s_cmp; (void)s_hid; (void)s_epi;
+  STAMP(t_begin);
+
+  // The stream of stages: per chunk 36 positions -- 18 fc1 stages (0..17), then 18 fc2 sub-stages (hidden block j = 0..2 x
+  // {fp16, e4m3} x column third 0..2).  Position P lives in ring slot P % 3 (36 is a multiple of 3: every LDS address is a
+  // compile-time constant).  The stage two positions on is issued during interval P, into the slot position P - 1 used.
+#pragma unroll
+  for (int k = 0; k < 5; ++k) issue_fc1(panel_base(0), 0, 0, 0, k);
+#pragma unroll
+  for (int k = 0; k < 5; ++k) issue_fc1(panel_base(0), 0, 1, 1, k);
+  int skip = 0;                       // intervals whose stage is known to have landed (behind a full drain)
+
+  for (int it = 0; it < my_panels; ++it) {
+    const int panel = b + it * G;
+    const char* a_panel = panel_base(it);
+    f32x4 acc2[3][6][2];     // [column third t][block i][row group m]
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+      for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int m = 0; m < 2; ++m) acc2[t][i][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int c = 0; c < kChunks; ++c) {
+      const bool stream_ends = it == my_panels - 1 && c == kChunks - 1;   // no stage behind this chunk
+      const int c_next = c == kChunks - 1 ? 0 : c + 1;
+      const char* a_next = c == kChunks - 1 ? panel_base(it + 1) : a_panel;    // (not dereferenced when the stream ends)
+      f32x4 acc1[6][2];        // [block i][row group m]
+#pragma unroll
+      for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int m = 0; m < 2; ++m) acc1[i][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+      static_for<0, kPer>([&](auto p_tag) {
+        constexpr int P = decltype(p_tag)::value;
+        constexpr int Q = P - kS1;                                        // fc2 sub-stage index (P >= 18)
+        if constexpr (Q >= 0 && Q % 6 == 0) {                             // a new hidden block
+          STAMP(t0);
+          if (Q > 0) wg_barrier();                                        // every wave has finished reading the previous one
+          {
+            constexpr int JJ = Q >= 0 ? Q / 6 : 0;
+            mfma_drain4(acc1[2 * JJ][0], acc1[2 * JJ][1], acc1[2 * JJ + 1][0], acc1[2 * JJ + 1][1]);
+          }
+          hidden_write(Tag<(Q >= 0 ? Q / 6 : 0)>(), c, acc1);
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // published by the barrier of the interval below
+          STAMP(t1); ACC(s_hid, t1, t0);
+        }
+        // top of the interval: this wave's part of stage P has landed (all but the instructions of stage P + 1 are done),
+        // everybody's after the barrier, and the slot of stage P - 1 is free
+        STAMP(t0);
+        if (skip > 0) --skip;
+        else if (P == kPer - 1) {
+          if (stream_ends) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        } else if (P + 1 < kS1) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        STAMP(t1);
+        wg_barrier();
+        STAMP(t2);
+        ACC(s_wait, t1, t0); ACC(s_bar, t2, t1);
+        auto dma = [&](int k) {       // instruction k of this wave's share of the stage two positions on
+          constexpr int P2 = P + 2, S2 = P2 % kRing;
+          if constexpr (P2 < kS1) {
+            if (k < 5) issue_fc1(a_panel, c, P2, S2, k);
+          } else if constexpr (P2 < kPer) {
+            constexpr int Q2 = P2 - kS1;
+            if (k < 3) issue_fc2((c * 3 + Q2 / 6) * 2 + (Q2 % 6) / 3, Q2 % 3, S2, k);
+          } else {
+            if (k < 5 && !stream_ends) issue_fc1(a_next, c_next, P2 - kPer, S2, k);
+          }
+        };
+        constexpr int SB = (P % kRing) * kSlot;
+        if constexpr (P < kS1) stage(Tag<P % 2>(), Tag<SB>(), Tag<SB>(), acc1, sc1, dma);
+        else stage(Tag<((Q >= 0 ? Q : 0) % 6) / 3>(), Tag<kHidOff + (((Q >= 0 ? Q : 0) % 6) / 3) * kAB>(), Tag<SB>(), acc2[(Q >= 0 ? Q : 0) % 3], sc2, dma);
+        STAMP(t0);
+        ACC(s_cmp, t0, t2);
+      });
+    }
+
+    // ---- panel epilogue: out = acc + b2 + residual.  The MFMA leaves lane l with row l & 15, 4 consecutive columns of chunk
+    // l >> 4; one ds_bpermute per value (lane 4 r + q takes lane 16 q + r) makes every quad of lanes cover 64 contiguous bytes
+    // of one row (gemm_split_ps.hip).  Every residual read is issued before the first store (one in-order counter per wave).
+    STAMP(t0);
+    {
+      int lane_e = lane;
+      asm volatile("" : "+v"(lane_e));
+      const int er = lane_e >> 2, eq = lane_e & 3;
+      const int perm_addr = ((eq << 4) + er) << 2;
+      const int row0 = panel * FR + wm * 32 + er;
+      const int col0 = wn * 32 + eq * 4;                     // + t * 192 + (i >> 1) * 64 + (i & 1) * 16
+      const float* b2l = (const float*)(smem + kB2Off) + col0;
+      // phase A: the lane transposition, in place, three blocks at a time
+#pragma unroll
+      for (int u = 0; u < 12; ++u) {
+        const int m = u / 6, t = (u % 6) >> 1, i0 = (u & 1) * 3;
+        mfma_drain3(acc2[t][i0][m], acc2[t][i0 + 1][m], acc2[t][i0 + 2][m]);
+#pragma unroll
+        for (int i = i0; i < i0 + 3; ++i) {
+          f32x4 tv;
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            tv[e] = __int_as_float(__builtin_amdgcn_ds_bpermute(perm_addr, __float_as_int(acc2[t][i][m][e])));
+          acc2[t][i][m] = tv;
+          asm volatile("" : "+v"(acc2[t][i][m]));    // pins the group here: register-only instructions are not ordered by
+        }                                            // sched_barrier before instruction selection (they carry no chain)
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // phase B: six groups (row group m, column third t) of six blocks; the residual of group u + 1 is in flight while group
+      // u is combined (two buffers of 24 registers: the fc1 accumulators are dead here); sched_barrier keeps the groups apart
+      f32x4 res[2][6];
+      auto load_res = [&](int u, f32x4 (&r)[6]) {
+        int row = row0 + (u / 3) * 16;
+        if (row >= g.M) row = g.M - 1;          // clamp: the value is never stored
+        const float* rp = g.resid + (size_t)row * g.ldr + col0 + (u % 3) * FC;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) r[i] = *(const f32x4*)(rp + (i >> 1) * 64 + (i & 1) * 16);
+      };
+      load_res(0, res[0]);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < 6; ++u) {
+        const int m = u / 3, t = u % 3;
+        if (u < 5) load_res(u + 1, res[(u + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+          acc2[t][i][m] = acc2[t][i][m] + res[u & 1][i] + *(const f32x4*)(b2l + t * FC + (i >> 1) * 64 + (i & 1) * 16);
+          asm volatile("" : "+v"(acc2[t][i][m]));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the reads are consumed; the two prefetched stages have landed too)
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        const int row = row0 + m * 16;
+        if (row < g.M) {
+          float* op = g.out + (size_t)row * g.ldo + col0;
+#pragma unroll
+          for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int i = 0; i < 6; ++i) *(f32x4*)(op + t * FC + (i >> 1) * 64 + (i & 1) * 16) = acc2[t][i][m];
+        }
+      }
+      skip = 2;   // stages 0 and 1 of the next panel landed before the drain above
+    }
+    STAMP(t1); ACC(s_epi, t1, t0);
+  }
+#ifdef VETO_FFN_STAMPS
+  if (w == 0 && lane == 0) {
+    unsigned long long* o = g_ffn_stamps + (size_t)(b & 255) * 8;
+    o[0] = s_wait; o[1] = s_bar; o[2] = s_iss; o[3] = s_cmp; o[4] = s_hid; o[5] = s_epi; o[6] = t1 - t_begin; o[7] = my_panels;
+  }
+#endif
+}
+
+}  // namespace
+
+int ffn_panel_rows() { return FR; }
+
+hipError_t launch_ffn_fused(FfnArgs g, hipStream_t s) {
+  if (g.M <= 0 || !g.a || !g.w1 || !g.w2 || !g.b1 || !g.b2 || !g.resid || !g.out || !g.exp1 || !g.exp2) return hipErrorInvalidValue;
+  static int num_cu = 0;
+  if (num_cu == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorInvalidDevice;
+    num_cu = prop.multiProcessorCount;
+    if (num_cu < 1) num_cu = 1;
+  }
+  g.n_panels = (g.M + FR - 1) / FR;
+  const int nblocks = g.n_panels < num_cu ? g.n_panels : num_cu;   // one persistent workgroup per CU (LDS: 159 KiB each)
+  VETO_LAUNCH(ffn_fused_kernel, dim3(nblocks), dim3(512), 0, s, g);
+  hipError_t rc = hipGetLastError();
+#ifdef VETO_FFN_STAMPS
+  {
+    static unsigned long long host[256 * 8];
+    hipDeviceSynchronize();
+    hipMemcpyFromSymbol(host, HIP_SYMBOL(g_ffn_stamps), sizeof(host));
+    double sum[8] = {0};
+    const int nb = nblocks < 256 ? nblocks : 256;
+    for (int bb = 0; bb < nb; ++bb)
+      for (int k = 0; k < 8; ++k) sum[k] += (double)host[bb * 8 + k];
+    fprintf(stderr, "[ffn stamps M%d] wave 0 of each workgroup, mean cycles: load wait %.0f barrier %.0f dma issue %.0f mfma %.0f hidden %.0f "
+            "epilogue %.0f total %.0f (%.2f panels x %d chunks x %d stages)\n", g.M, sum[0] / nb, sum[1] / nb, sum[2] / nb, sum[3] / nb,
+            sum[4] / nb, sum[5] / nb, sum[6] / nb, sum[7] / nb, kChunks, kPer);
+  }
+#endif
+  return rc;
+}
+
+}  // namespace veto

@@ -47,6 +47,26 @@ int gemm_rows_padded(int m);
 hipError_t launch_gemm_split(GemmArgs g, int epi, int precision, hipStream_t s);
 hipError_t launch_gemm_split_ps(GemmArgs g, int epi, int precision, hipStream_t s);
 
+// Fused FeedForward (ffn_fused.hip), VETO_MIXED operands: out = resid + W2 . gelu(W1 . a + b1) + b2 on `M` token rows.
+// a: mixed activation rows [rows padded to ffn_panel_rows(), 4*576 B]; w1 [1152, 4*576 B], w2 [576, 4*1152 B]: mixed weight
+// rows with their e4m3 exponents exp1 / exp2 (device ints); resid / out fp32 rows (may alias).
+struct FfnArgs {
+  const char* a;
+  const char* w1;
+  const char* w2;
+  const float* b1;
+  const float* b2;
+  const float* resid;
+  float* out;
+  long ldr, ldo;         // row strides of resid / out in floats
+  int M;
+  const int* exp1;
+  const int* exp2;
+  int n_panels;          // filled by the launcher
+};
+int ffn_panel_rows();
+hipError_t launch_ffn_fused(FfnArgs g, hipStream_t s);
+
 // ---- weight preparation (once per weight upload) ---------------------------------------------
 // src [rows, K] fp32 -> dst [rows, 2K] split rows
 hipError_t launch_split_rows(const float* src, __bf16* dst, size_t rows, int K, hipStream_t s);

@@ -1416,6 +1416,71 @@ int veto_debug_gemm(void* stream, const float* a, const float* w, const float* b
   return VETO_OK;
 }
 
+// Test / measurement hook of the FeedForward block (model_veto.py:137-143 + the residual of :21) on VETO_MIXED operands:
+// x <- x + W2 . gelu(W1 . a + b1) + b2 for m token rows.  mode 0 = the two GEMM launches (fc1 with the GELU epilogue writing
+// the hidden activation as mixed rows, fc2 with the residual epilogue), mode 1 = the fused kernel (ffn_fused.hip).
+// flags & 1: (re)build the mixed operands from a / w1 / w2 first.  The block runs `reps` times (x accumulates: timing only when
+// reps > 1); *ms_per_rep (host, optional) receives the mean device time of one run from hipEvents on `stream`.
+size_t veto_debug_ffn_workspace_bytes(int32_t m) {
+  if (m <= 0) return 0;
+  const size_t mp = (size_t)gemm_rows_padded(m);
+  return align_up(mp * kDim * 4, 256) + align_up(mp * 2 * kDim * 4, 256) + 2 * align_up((size_t)2 * kDim * kDim * 4, 256) + 256;
+}
+
+int veto_debug_ffn(void* stream, const float* a, const float* w1, const float* b1, const float* w2, const float* b2, float* x,
+                   int32_t m, int32_t mode, int32_t flags, int32_t reps, float* ms_per_rep, void* workspace, size_t workspace_bytes) {
+  if (!a || !w1 || !b1 || !w2 || !b2 || !x || !workspace) return fail(VETO_ERR_INVALID, "null argument");
+  if (m <= 0 || reps <= 0 || (mode != 0 && mode != 1)) return fail(VETO_ERR_INVALID, "bad m / reps / mode");
+  if (workspace_bytes < veto_debug_ffn_workspace_bytes(m)) return fail(VETO_ERR_WORKSPACE, "workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  const size_t mp = (size_t)gemm_rows_padded(m);
+  char* base = (char*)workspace;
+  __bf16* a_m = (__bf16*)base;
+  __bf16* hid = (__bf16*)(base + align_up(mp * kDim * 4, 256));
+  __bf16* w1_m = (__bf16*)((char*)hid + align_up(mp * 2 * kDim * 4, 256));
+  __bf16* w2_m = (__bf16*)((char*)w1_m + align_up((size_t)2 * kDim * kDim * 4, 256));
+  int* exps = (int*)((char*)w2_m + align_up((size_t)2 * kDim * kDim * 4, 256));
+  if (flags & 1) {
+    HIP_TRY(hipMemsetAsync(a_m, 0, mp * kDim * 4, s));
+    HIP_TRY(launch_mixed_act_rows(a, a_m, (size_t)m, kDim, s));
+    HIP_TRY(launch_mixed_weight_rows(w1, w1_m, (size_t)2 * kDim, kDim, exps + 0, s));
+    HIP_TRY(launch_mixed_weight_rows(w2, w2_m, (size_t)kDim, 2 * kDim, exps + 1, s));
+  }
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (ms_per_rep) {
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    HIP_TRY(hipEventRecord(e0, s));
+  }
+  for (int r = 0; r < reps; ++r) {
+    if (mode == 1) {
+      FfnArgs f{};
+      f.a = (const char*)a_m; f.w1 = (const char*)w1_m; f.w2 = (const char*)w2_m; f.b1 = b1; f.b2 = b2;
+      f.resid = x; f.out = x; f.ldr = kDim; f.ldo = kDim; f.M = m; f.exp1 = exps + 0; f.exp2 = exps + 1;
+      HIP_TRY(launch_ffn_fused(f, s));
+    } else {
+      GemmArgs g1{};
+      g1.fmt = FMT_MIXED; g1.w_exp = exps + 0; g1.a = a_m; g1.w = w1_m; g1.bias = b1; g1.c_split = hid;
+      g1.M = m; g1.N = 2 * kDim; g1.K = kDim; g1.ldc = 4 * kDim;
+      HIP_TRY(launch_gemm_split(g1, EPI_GELU_SPLIT, 0, s));
+      GemmArgs g2{};
+      g2.fmt = FMT_MIXED; g2.w_exp = exps + 1; g2.a = hid; g2.w = w2_m; g2.bias = b2; g2.resid = x; g2.c = x;
+      g2.M = m; g2.N = kDim; g2.K = 2 * kDim; g2.ldr = kDim; g2.ldc = kDim;
+      HIP_TRY(launch_gemm_split(g2, EPI_RESID, 0, s));
+    }
+  }
+  if (ms_per_rep) {
+    HIP_TRY(hipEventRecord(e1, s));
+    HIP_TRY(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    *ms_per_rep = ms / reps;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+  }
+  return VETO_OK;
+}
+
 size_t veto_ce_loss_workspace_bytes(int32_t n) { return n > 0 ? 3 * align_up((size_t)n * 4, 256) + 256 : 0; }
 
 int veto_ce_loss(void* stream, const float* logits, int64_t ld, const int64_t* labels, const float* weight,
