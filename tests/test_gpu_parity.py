@@ -97,6 +97,39 @@ def test_mixed_gemm_saturates_gracefully_on_outliers():
     assert rel[ok].max().item() < 2e-4, rel[ok].max().item()       # (the coarse weight exponent costs correction bits, not the main term)
 
 
+@pytest.mark.parametrize("m", [1, 127, 128, 129, 1000, 33000])
+def test_fused_feedforward_matches_two_launch_form_and_fp64(m):
+    """The fused FeedForward kernel (ffn_fused.hip: fc1 -> GELU -> fc2 + residual, hidden activation kept on the CU;
+    model_veto.py:137-143 + the residual of :21) against an fp64 reference, and BIT-IDENTICAL to the two-launch form (same
+    operands, same summation order): panel edges (127 / 128 / 129 rows), a single row, and more panels than CUs."""
+    import ctypes
+    from veto_amd import native
+    lib = native.load_library()
+    dev = _dev()
+    g = torch.Generator(device="cpu").manual_seed(m)
+    a = torch.randn(m, 576, generator=g).to(dev)
+    x0 = torch.randn(m, 576, generator=g).to(dev)
+    w1 = (torch.randn(1152, 576, generator=g) * 0.04).to(dev)
+    b1 = (torch.randn(1152, generator=g) * 0.1).to(dev)
+    w2 = (torch.randn(576, 1152, generator=g) * 0.03).to(dev)
+    b2 = (torch.randn(576, generator=g) * 0.1).to(dev)
+    hid = torch.nn.functional.gelu(a.double() @ w1.double().t() + b1.double())
+    ref = x0.double() + hid @ w2.double().t() + b2.double()
+    scale = (hid.abs() @ w2.double().abs().t()).clamp_min(1e-6)
+    ws = torch.empty(lib.veto_debug_ffn_workspace_bytes(m), dtype=torch.uint8, device=dev)
+    out = []
+    for mode in (0, 1):
+        x = x0.clone()
+        native.check(lib.veto_debug_ffn(None, a.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), x.data_ptr(),
+                                        m, mode, 1, 1, None, ws.data_ptr(), ws.numel()))
+        torch.cuda.synchronize()
+        assert torch.isfinite(x).all()
+        rel = ((x.double() - ref).abs() / scale).max().item()
+        assert rel < 1e-4, (m, mode, rel)     # the hidden activation is rounded to 2^-16 on its way into fc2
+        out.append(x)
+    assert torch.equal(out[0], out[1]), (out[0] - out[1]).abs().max().item()
+
+
 @pytest.mark.parametrize("n", [1, 2, 3, 10, 36, 50])
 def test_enumerate_pairs_bit_exact(n):
     from veto_amd.pairs import prepare_test_pairs

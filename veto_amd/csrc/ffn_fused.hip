@@ -37,6 +37,11 @@
 #ifndef FFN_AGPR
 #define FFN_AGPR 0
 #endif
+// timing ablations (tools/ffn_variants.sh; results are WRONG with any of them set): 1 = no DMA, 2 = no MFMA, 4 = no fragment
+// reads, 8 = no hidden conversion, 16 = no panel epilogue
+#ifndef FFN_ABLATE
+#define FFN_ABLATE 0
+#endif
 
 
 namespace veto {
@@ -73,6 +78,7 @@ template <int V> struct Tag { static constexpr int value = V; };
 // its own vmcnt).  The s_nop covers the SALU-writes-M0 -> LDS-DMA wait state and the five states between a scalar write of
 // the base (the compiler computes it right in front of the statement) and its use by a vector-memory instruction.
 __device__ __forceinline__ void glds16(const char* base, unsigned voff, unsigned lds_addr) {
+  if (FFN_ABLATE & 1) return;
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_addr), "v"(voff), "s"(base) : "memory");
 }
 __device__ __forceinline__ void wg_barrier() {
@@ -92,7 +98,11 @@ __device__ __forceinline__ unsigned long long stamp() {
 }
 #define STAMP(x) x = stamp()
 #define ACC(a, t1, t0) a += (t1) - (t0)
+// timeline of one chunk (workgroup 0, first panel, chunk 2; waves 0 and 4): [wave][position][top, waited, barrier, group 0..5]
+__device__ unsigned long long g_ffn_timeline[2 * 36 * 9];
+#define TL(P, k) do { if (b == 0 && it == 0 && c == 2 && (w & 3) == 0) g_ffn_timeline[((w >> 2) * 36 + (P)) * 9 + (k)] = stamp(); } while (0)
 #else
+#define TL(P, k)
 #define STAMP(x)
 #define ACC(a, t1, t0)
 #endif
@@ -169,6 +179,10 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs g) {
   // tools/audit_ffn_asm.py checks the generated code for compiler instructions that touch accumulator registers near an MFMA.
   auto mma = [&](auto kind_tag, f32x4& acc, const i32x4& fw0, const i32x4& fw1, const i32x4& fa0, const i32x4& fa1, int scale) {
     constexpr int KIND = decltype(kind_tag)::value;
+    if (FFN_ABLATE & 2) {
+      asm volatile("" : "+v"(acc) : "v"(fw0), "v"(fw1), "v"(fa0), "v"(fa1));
+      return;
+    }
     if constexpr (KIND == 0) {
       asm("s_nop 1\n\tv_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(fw0), "v"(fa0));
       asm("s_nop 1\n\tv_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(fw1), "v"(fa1));
@@ -193,20 +207,45 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs g) {
   // sched_barrier(0) after every group keeps that order.
   typedef __attribute__((address_space(3))) i32x4 lds_i32x4_t;
   typedef const lds_i32x4_t* lds_frag_t;
-  auto stage = [&](auto kind_tag, auto ab_tag, auto sb_tag, f32x4 (&acc)[6][2], int scale, auto&& dma) {
+  auto stage = [&](auto kind_tag, auto ab_tag, auto sb_tag, f32x4 (&acc)[6][2], int scale, auto&& dma, auto reuse_tag, i32x4 (&fa0)[2],
+                   i32x4 (&fa1)[2], auto&& valu, auto&& mark) {
     constexpr int AB = decltype(ab_tag)::value, SB = decltype(sb_tag)::value;
+    constexpr bool REUSE = decltype(reuse_tag)::value != 0;    // the activation fragments of the previous sub-stage are still valid
     int fo = frag_off;
     asm volatile("" : "+v"(fo));
     const unsigned a0 = lds0 + AB + wm * 4096 + fo, a1 = lds0 + AB + wm * 4096 + (fo ^ 64);
     const unsigned w0 = lds0 + SB + kAB + wn * 4096 + fo, w1 = lds0 + SB + kAB + wn * 4096 + (fo ^ 64);
-    i32x4 fa0[2], fa1[2], fw0[2], fw1[2];
+    i32x4 fw0[2], fw1[2];
+    if (FFN_ABLATE & 4) {
 #pragma unroll
-    for (int m = 0; m < 2; ++m) {
-      fa0[m] = *(lds_frag_t)(size_t)(a0 + m * 2048);
-      fa1[m] = *(lds_frag_t)(size_t)(a1 + m * 2048);
+      for (int m = 0; m < 2; ++m) {
+        fa0[m] = fa1[m] = fw0[m] = fw1[m] = i32x4{0, 0, 0, 0};
+        asm volatile("" : "+v"(fa0[m]), "+v"(fa1[m]), "+v"(fw0[m]), "+v"(fw1[m]));
+      }
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m) mma(kind_tag, acc[i][m], fw0[i & 1], fw1[i & 1], fa0[m], fa1[m], scale);
+        if (i == 0) { dma(0); dma(1); }
+        dma(i + 2);
+        valu(i);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      return;
+    }
+    if constexpr (!REUSE) {
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        fa0[m] = *(lds_frag_t)(size_t)(a0 + m * 2048);
+        fa1[m] = *(lds_frag_t)(size_t)(a1 + m * 2048);
+      }
     }
     fw0[0] = *(lds_frag_t)(size_t)(w0);
     fw1[0] = *(lds_frag_t)(size_t)(w1);
+    // the first two DMA instructions go out while the first fragments are on their way from the LDS (their issue back-pressure
+    // and the LDS latency overlap instead of adding up); the others follow groups 0, 1, 2
+    dma(0);
+    dma(1);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
@@ -216,10 +255,17 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs g) {
       }
 #pragma unroll
       for (int m = 0; m < 2; ++m) mma(kind_tag, acc[i][m], fw0[i & 1], fw1[i & 1], fa0[m], fa1[m], scale);
-      dma(i);
+      dma(i + 2);
+      valu(i);
+      mark(i);
       __builtin_amdgcn_sched_barrier(0);
     }
   };
+  // The hidden images of block j of a chunk: blocks 0 and 2 in the dedicated area, block 1 in the activation parts of ring
+  // slots 0 and 1 (idle between the last fc1 stage and the prefetch of the next chunk's first stages at positions 34 / 35), so
+  // that block j + 1 can be written while block j is being read: no barrier between them, and the conversion runs beside MFMAs.
+  auto hid_f16 = [](int j) { return j == 1 ? 0 : kHidOff; };
+  auto hid_e4m3 = [](int j) { return j == 1 ? kSlot : kHidOff + kAB; };
   // bias + GELU + mixed-row conversion of hidden block J of chunk c (this wave's 32 columns x 32 rows) into the hidden images
   auto hidden_write = [&](auto j_tag, int c, f32x4 (&acc1)[6][2]) {
     constexpr int J = decltype(j_tag)::value;
@@ -255,11 +301,11 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs g) {
 #pragma unroll
     for (int ib = 0; ib < 2; ++ib) {
       const int ls = wn * 4 + ib * 2 + (hq >> 1);                       // 16-byte slot of this lane's 4 columns in the 128-byte row
-      char* hp = smem + kHidOff + (wm * 32 + hr) * 128 + ((ls ^ ((hr >> 1) & 7)) << 4) + (hq & 1) * 8;
+      const int ho = (wm * 32 + hr) * 128 + ((ls ^ ((hr >> 1) & 7)) << 4) + (hq & 1) * 8;
 #pragma unroll
       for (int m = 0; m < 2; ++m) {
-        *(f16x4*)(hp + m * 2048) = hh[ib][m];
-        *(u32x2*)(hp + kAB + m * 2048) = xy[ib][m];
+        *(f16x4*)(smem + hid_f16(J) + ho + m * 2048) = hh[ib][m];
+        *(u32x2*)(smem + hid_e4m3(J) + ho + m * 2048) = xy[ib][m];
       }
     }
   };
@@ -298,32 +344,35 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs g) {
 #pragma unroll
         for (int m = 0; m < 2; ++m) acc1[i][m] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+      i32x4 fa0[2], fa1[2];     // activation fragments: re-read every fc1 stage, held across the three column thirds in fc2
       static_for<0, kPer>([&](auto p_tag) {
         constexpr int P = decltype(p_tag)::value;
-        constexpr int Q = P - kS1;                                        // fc2 sub-stage index (P >= 18)
-        if constexpr (Q >= 0 && Q % 6 == 0) {                             // a new hidden block
+        constexpr int Q = P >= kS1 ? P - kS1 : 0;                        // fc2 sub-stage index (P >= 18)
+        constexpr int J = Q / 6, S = Q % 6, KIND2 = S / 3, T = S % 3;    // hidden block, sub-stage of the block = kind x third
+        if constexpr (P == kS1) {                                         // hidden block 0 of the chunk: nothing to overlap it with
           STAMP(t0);
-          if (Q > 0) wg_barrier();                                        // every wave has finished reading the previous one
-          {
-            constexpr int JJ = Q >= 0 ? Q / 6 : 0;
-            mfma_drain4(acc1[2 * JJ][0], acc1[2 * JJ][1], acc1[2 * JJ + 1][0], acc1[2 * JJ + 1][1]);
-          }
-          hidden_write(Tag<(Q >= 0 ? Q / 6 : 0)>(), c, acc1);
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // published by the barrier of the interval below
+          mfma_drain4(acc1[0][0], acc1[0][1], acc1[1][0], acc1[1][1]);   // (every fc1 MFMA of the chunk is behind these three)
+          mfma_drain4(acc1[2][0], acc1[2][1], acc1[3][0], acc1[3][1]);
+          mfma_drain4(acc1[4][0], acc1[4][1], acc1[5][0], acc1[5][1]);
+          if (!(FFN_ABLATE & 8)) hidden_write(Tag<0>(), c, acc1);
           STAMP(t1); ACC(s_hid, t1, t0);
         }
         // top of the interval: this wave's part of stage P has landed (all but the instructions of stage P + 1 are done),
         // everybody's after the barrier, and the slot of stage P - 1 is free
         STAMP(t0);
+        TL(P, 0);
         if (skip > 0) --skip;
         else if (P == kPer - 1) {
           if (stream_ends) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
         } else if (P + 1 < kS1) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        if (P >= kS1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's hidden-image stores are in the LDS
         STAMP(t1);
+        TL(P, 1);
         wg_barrier();
         STAMP(t2);
+        TL(P, 2);
         ACC(s_wait, t1, t0); ACC(s_bar, t2, t1);
         auto dma = [&](int k) {       // instruction k of this wave's share of the stage two positions on
           constexpr int P2 = P + 2, S2 = P2 % kRing;
@@ -337,8 +386,48 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs g) {
           }
         };
         constexpr int SB = (P % kRing) * kSlot;
-        if constexpr (P < kS1) stage(Tag<P % 2>(), Tag<SB>(), Tag<SB>(), acc1, sc1, dma);
-        else stage(Tag<((Q >= 0 ? Q : 0) % 6) / 3>(), Tag<kHidOff + (((Q >= 0 ? Q : 0) % 6) / 3) * kAB>(), Tag<SB>(), acc2[(Q >= 0 ? Q : 0) % 3], sc2, dma);
+        auto mark = [&](int i) { (void)i; TL(P, 3 + i); };
+        if constexpr (P < kS1) {
+          stage(Tag<P % 2>(), Tag<SB>(), Tag<SB>(), acc1, sc1, dma, Tag<0>(), fa0, fa1, [](int) {}, mark);
+        } else {
+          // beside the MFMAs of sub-stages 0..3 of block J: bias + GELU + conversion of one (16 columns x 16 rows) unit of block
+          // J + 1, a value per group, packed and stored in group 4
+          constexpr bool CONV = J < 2 && S < 4 && !(FFN_ABLATE & 8);
+          constexpr int IB = (S >> 1) & 1, MM = S & 1;
+          f32x4 gv, pre;
+          int ho = 0;
+          auto valu = [&](int i) {
+            if constexpr (CONV) {
+              if (i == 0) {
+                int lane_h = lane;
+                asm volatile("" : "+v"(lane_h));
+                const int hr = lane_h & 15, hq = lane_h >> 4;
+                const int ls = wn * 4 + IB * 2 + (hq >> 1);
+                ho = (wm * 32 + MM * 16 + hr) * 128 + ((ls ^ ((hr >> 1) & 7)) << 4) + (hq & 1) * 8;
+                pre = acc1[2 * (J + 1) + IB][MM] + *(const f32x4*)(smem + kB1Off + (c * FC + (J + 1) * 64 + wn * 32 + IB * 16 + hq * 4) * 4);
+              }
+              if (i < 4) {
+                gv[i] = gelu_sigmoid(pre[i]);
+                asm volatile("" : "+v"(gv[i]));      // pins the piece in its group (register-only code carries no order of its own)
+              }
+              if (i == 4) {
+                f16x4 h;
+                float l[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                  h[e] = (_Float16)gv[e];
+                  l[e] = gv[e] - (float)h[e];
+                }
+                u32x2 xy = u32x2{pack_e4m3x4_scaled<kMixActExp>(l[0], l[1], l[2], l[3]), pack_e4m3x4_scaled<kMixActHiExp>(gv[0], gv[1], gv[2], gv[3])};
+                asm volatile("" : "+v"(h), "+v"(xy));
+                *(f16x4*)(smem + hid_f16(J + 1) + ho) = h;
+                *(u32x2*)(smem + hid_e4m3(J + 1) + ho) = xy;
+              }
+            }
+          };
+          stage(Tag<KIND2>(), Tag<(KIND2 == 0 ? (J == 1 ? 0 : kHidOff) : (J == 1 ? kSlot : kHidOff + kAB))>(), Tag<SB>(), acc2[T], sc2, dma,
+                Tag<(T > 0)>(), fa0, fa1, valu, mark);
+        }
         STAMP(t0);
         ACC(s_cmp, t0, t2);
       });
@@ -348,7 +437,7 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs g) {
     // l >> 4; one ds_bpermute per value (lane 4 r + q takes lane 16 q + r) makes every quad of lanes cover 64 contiguous bytes
     // of one row (gemm_split_ps.hip).  Every residual read is issued before the first store (one in-order counter per wave).
     STAMP(t0);
-    {
+    if (!(FFN_ABLATE & 16)) {
       int lane_e = lane;
       asm volatile("" : "+v"(lane_e));
       const int er = lane_e >> 2, eq = lane_e & 3;
@@ -372,9 +461,10 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs g) {
         }                                            // sched_barrier before instruction selection (they carry no chain)
         __builtin_amdgcn_sched_barrier(0);
       }
-      // phase B: six groups (row group m, column third t) of six blocks; the residual of group u + 1 is in flight while group
-      // u is combined (two buffers of 24 registers: the fc1 accumulators are dead here); sched_barrier keeps the groups apart
-      f32x4 res[2][6];
+      // phase B: six groups (row group m, column third t) of six blocks; the residuals of groups u + 1 and u + 2 are in flight
+      // while group u is combined (three buffers of 24 registers: the fc1 accumulators and the fragments are dead here: every
+      // round trip to HBM is ~2 us with all 256 CUs in their epilogues at once); sched_barrier keeps the groups apart
+      f32x4 res[3][6];
       auto load_res = [&](int u, f32x4 (&r)[6]) {
         int row = row0 + (u / 3) * 16;
         if (row >= g.M) row = g.M - 1;          // clamp: the value is never stored
@@ -383,15 +473,16 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs g) {
         for (int i = 0; i < 6; ++i) r[i] = *(const f32x4*)(rp + (i >> 1) * 64 + (i & 1) * 16);
       };
       load_res(0, res[0]);
+      load_res(1, res[1]);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int u = 0; u < 6; ++u) {
         const int m = u / 3, t = u % 3;
-        if (u < 5) load_res(u + 1, res[(u + 1) & 1]);
+        if (u < 4) load_res(u + 2, res[(u + 2) % 3]);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
-          acc2[t][i][m] = acc2[t][i][m] + res[u & 1][i] + *(const f32x4*)(b2l + t * FC + (i >> 1) * 64 + (i & 1) * 16);
+          acc2[t][i][m] = acc2[t][i][m] + res[u % 3][i] + *(const f32x4*)(b2l + t * FC + (i >> 1) * 64 + (i & 1) * 16);
           asm volatile("" : "+v"(acc2[t][i][m]));
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -409,6 +500,8 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs g) {
         }
       }
       skip = 2;   // stages 0 and 1 of the next panel landed before the drain above
+    } else {
+      asm volatile("" ::"v"(acc2[0][0][0]), "v"(acc2[2][5][1]));
     }
     STAMP(t1); ACC(s_epi, t1, t0);
   }
@@ -447,6 +540,19 @@ hipError_t launch_ffn_fused(FfnArgs g, hipStream_t s) {
     const int nb = nblocks < 256 ? nblocks : 256;
     for (int bb = 0; bb < nb; ++bb)
       for (int k = 0; k < 8; ++k) sum[k] += (double)host[bb * 8 + k];
+    static int printed = 0;
+    if (!printed++) {
+      static unsigned long long tl[2 * 36 * 9];
+      hipMemcpyFromSymbol(tl, HIP_SYMBOL(g_ffn_timeline), sizeof(tl));
+      for (int wv = 0; wv < 2; ++wv)
+        for (int p = 0; p < 36; ++p) {
+          const unsigned long long* r = tl + (wv * 36 + p) * 9;
+          const unsigned long long t00 = tl[(wv * 36) * 9];
+          fprintf(stderr, "[ffn timeline] wave %d pos %2d: top %7llu | wait %5llu bar %5llu | groups", wv * 4, p, r[0] - t00, r[1] - r[0], r[2] - r[1]);
+          for (int k = 0; k < 6; ++k) fprintf(stderr, " %5llu", r[3 + k] - r[2 + k]);
+          fprintf(stderr, "\n");
+        }
+    }
     fprintf(stderr, "[ffn stamps M%d] wave 0 of each workgroup, mean cycles: load wait %.0f barrier %.0f dma issue %.0f mfma %.0f hidden %.0f "
             "epilogue %.0f total %.0f (%.2f panels x %d chunks x %d stages)\n", g.M, sum[0] / nb, sum[1] / nb, sum[2] / nb, sum[3] / nb,
             sum[4] / nb, sum[5] / nb, sum[6] / nb, sum[7] / nb, kChunks, kPer);

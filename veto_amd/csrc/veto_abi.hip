@@ -503,6 +503,8 @@ int veto_forward(veto_handle_t h, void* stream, const veto_inputs_t* in, void* w
   // CLS-row GEMMs (8 % of the GEMM work) stay on split-bf16 operands.  The out projection only behind the MFMA attention kernel.
   const bool mixed = h->cfg.precision == VETO_MIXED;
   const bool mixed_out = mixed && attention_reads_tables(H);
+  static const bool ffn_off = getenv("VETO_FFN_FUSED") && !strcmp(getenv("VETO_FFN_FUSED"), "0");          // A/B knob
+  const bool ffn_fused = !ffn_off;   // VETO_MIXED: fc1 -> GELU -> fc2 + residual as one launch
   if (qkv0_tables) {
     const int R = n_obj * 16;
     HIP_TRY(launch_centre_split(ws.patch_tab, ws.ptab_split, R, s));
@@ -602,12 +604,22 @@ int veto_forward(veto_handle_t h, void* stream, const veto_inputs_t* in, void* w
           ProfScope ps(h, s, "layernorm", 0, (double)M * kDim * 8);
           HIP_TRY(launch_layernorm(ws.x, kDim, w.ln2_w, w.ln2_b, ws.a, M, s, mixed ? FMT_MIXED : FMT_SPLIT));
         }
-        rc = run_gemm(h, s, "gemm_fc1", ws.a, mixed ? w.fc1_m : w.fc1, w.fc1_b, nullptr, 0, nullptr, hid, 4 * kDim, M, 2 * kDim, kDim,
-                      EPI_GELU_SPLIT, 0, 0, DropSite(), mixed ? w.exp_m + 2 : nullptr);
-        if (rc) return rc;
-        rc = run_gemm(h, s, "gemm_fc2", hid, mixed ? w.fc2_m : w.fc2, w.fc2_b, ws.x, kDim, ws.x, nullptr, kDim, M, kDim, 2 * kDim, EPI_RESID,
-                      0, 0, DropSite(), mixed ? w.exp_m + 3 : nullptr);
-        if (rc) return rc;
+        if (mixed && ffn_fused) {
+          // FeedForward in one launch (ffn_fused.hip): the hidden activation never leaves the CU
+          FfnArgs f{};
+          f.a = (const char*)ws.a; f.w1 = (const char*)w.fc1_m; f.w2 = (const char*)w.fc2_m; f.b1 = w.fc1_b; f.b2 = w.fc2_b;
+          f.resid = ws.x; f.out = ws.x; f.ldr = kDim; f.ldo = kDim; f.M = M; f.exp1 = w.exp_m + 2; f.exp2 = w.exp_m + 3;
+          // bytes: the LayerNorm'ed rows in, the residual stream in and out, the two weight matrices
+          ProfScope ps(h, s, "ffn_fused", 2.0 * 2.0 * M * (double)kDim * 2 * kDim, (double)M * kDim * 12 + 2.0 * 2 * kDim * kDim * 4);
+          HIP_TRY(launch_ffn_fused(f, s));
+        } else {
+          rc = run_gemm(h, s, "gemm_fc1", ws.a, mixed ? w.fc1_m : w.fc1, w.fc1_b, nullptr, 0, nullptr, hid, 4 * kDim, M, 2 * kDim, kDim,
+                        EPI_GELU_SPLIT, 0, 0, DropSite(), mixed ? w.exp_m + 2 : nullptr);
+          if (rc) return rc;
+          rc = run_gemm(h, s, "gemm_fc2", hid, mixed ? w.fc2_m : w.fc2, w.fc2_b, ws.x, kDim, ws.x, nullptr, kDim, M, kDim, 2 * kDim, EPI_RESID,
+                        0, 0, DropSite(), mixed ? w.exp_m + 3 : nullptr);
+          if (rc) return rc;
+        }
         {
           const LayerW& nx = h->layers[l + 1];
           if (l + 1 == L - 1 && fold_last) {
