@@ -257,6 +257,46 @@ def test_parity_under_sharp_attention(precision):
     assert err <= 3e-4, err
 
 
+@pytest.mark.parametrize("precision", ["mixed", "precise"])
+def test_parity_on_trained_like_activations(precision):
+    """Random-init weights keep every activation small (max |LayerNorm out| 5.6, max |GELU hidden| 2.6 on the fixtures); trained
+    transformers do not.  The same FUNCTION is re-parameterised the way training leaves it: LayerNorm gains x 8 with shifted
+    biases (the consuming to_qkv / fc1 weights / 8), 3 % of the FeedForward hidden units x 30 and a handful x 300 (their fc2
+    columns scaled back), and one outlier entry (20 x the maximum) in every Linear weight.  LayerNorm outputs then reach +-40,
+    hidden activations several hundred, a few exceed the e4m3 range of the mixed operand format (448: they degrade to the fp16
+    class, element by element) -- the fixed activation exponents of round 2 saturated at 28.  Against the fp64 oracle."""
+    from oracle import veto_oracle as vo
+    from veto_amd import synth, testing
+    dev = _dev()
+    layers, heads = 4, 8
+    sd = {k: np.array(v).copy() for k, v in synth.predictor_state_dict(0, layers=layers).items()}
+    rng = np.random.RandomState(3)
+    T = "fusion_transformer.transformer.layers.%d."
+    for l in range(layers):
+        for norm, lin in (("0.norm", "0.fn.to_qkv"), ("1.norm", "1.fn.net.0")):
+            sd[(T % l) + norm + ".weight"] *= 8.0
+            sd[(T % l) + norm + ".bias"] += 3.0 * rng.randn(576).astype(np.float32)
+            sd[(T % l) + lin + ".weight"] /= 8.0
+        w1, b1, w2 = (T % l) + "1.fn.net.0.weight", (T % l) + "1.fn.net.0.bias", (T % l) + "1.fn.net.3.weight"
+        units = rng.permutation(1152)
+        for sel, f in ((units[:35], 30.0), (units[35:41], 300.0)):
+            sd[w1][sel] *= f
+            sd[b1][sel] *= f
+            sd[w2][:, sel] /= f
+        for name in ("0.fn.to_qkv", "0.fn.to_out.0", "1.fn.net.0", "1.fn.net.3"):
+            w = sd[(T % l) + name + ".weight"]
+            w[rng.randint(w.shape[0]), rng.randint(w.shape[1])] = 20.0 * np.abs(w).max()
+    batch = synth.synthetic_batch(11, 2, [12, 9])
+    model = testing.make_predictor(testing.make_config(layers, heads, precision=precision), sd, dev)
+    out, _ = _run(model, batch, "predcls", dev)
+    ref, _, _ = vo.forward(sd, vo.OracleConfig(layers=layers, heads=heads), batch, dtype=torch.float64)
+    got = torch.cat(list(out[1])).cpu().double()
+    assert torch.isfinite(got).all()
+    err = (got - ref).abs().max().item()
+    print("trained-like activations [%s]: logit max-abs-err %.3e (max |logit| %.2f)" % (precision, err, ref.abs().max().item()))
+    assert err <= 3e-4, err
+
+
 def test_fast_mode_error_is_reported_not_trusted():
     from veto_amd import testing
     dev = _dev()
