@@ -51,13 +51,34 @@ def flops_per_pair(layers, heads):
     return patch + loc + cls + layers * (qkv + att + out + mlp) + head
 
 
+def count_gpus_sysfs():
+    """GPUs of this node from the KFD topology (nodes with simd_count > 0), WITHOUT touching the HIP runtime: the parent of a
+    multi-rank launch must not open the device (a child started from a process that holds it is the exec this pool forbids).
+    None when the topology is not readable (then the ranks themselves report what they find)."""
+    import glob
+    if not os.path.isdir("/sys/class/kfd/kfd/topology/nodes"):
+        return 0            # no KFD driver on this host: no GPU
+    nodes = glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties")
+    if not nodes:
+        return None
+    n = 0
+    for path in nodes:
+        try:
+            for line in open(path):
+                parts = line.split()
+                if len(parts) == 2 and parts[0] == "simd_count" and int(parts[1]) > 0:
+                    n += 1
+        except OSError:
+            return None
+    return n
+
+
 def self_launch(args):
-    """--gpus N > 1 outside torch.distributed.run: start the N ranks as a child process group and relay.
-    Nothing here initialises a GPU (torch.cuda.device_count() does not, on this image), so the parent
-    never has to exec or fork a process that holds one."""
+    """--gpus N > 1 outside torch.distributed.run: start the N ranks as a child process group (subprocess: fresh children, never
+    an exec of this process) and relay.  The parent makes NO torch.cuda call: the GPU count comes from sysfs."""
     dry = os.environ.get("VETO_BENCH_DRYRUN") == "1"
-    have = torch.cuda.device_count()
-    if not dry and have < args.gpus:
+    have = count_gpus_sysfs()
+    if not dry and have is not None and have < args.gpus:
         print("bench.py --gpus %d: this node exposes %d GPU(s); nothing was run" % (args.gpus, have), file=sys.stderr)
         return 2
     sock = socket.socket()
@@ -168,8 +189,12 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     ranks_seen, devices = 1, [0 if dry else torch.cuda.current_device()]
+    rank_elapsed = [elapsed]
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        allt = torch.empty(dist.get_world_size(), dtype=torch.float64, device=dev)
+        dist.all_gather_into_tensor(allt, t)          # every rank's own clock: a straggler is visible in the line
+        rank_elapsed = [float(x) for x in allt.tolist()]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         ranks_seen = dist.get_world_size()
@@ -185,6 +210,7 @@ def main():
             print(json.dumps({"metric": "DRY RUN of the launch path (gloo, CPU, no model): not a measurement", "value": 0.0,
                               "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                               "ms_per_step": elapsed / args.steps * 1e3, "ranks_seen": ranks_seen, "devices": devices,
+                              "per_rank_units_per_s": [round(n_pairs * args.steps / e, 1) for e in rank_elapsed],
                               "gathered_rows": int(last.shape[0]), "dry_run": True}), flush=True)
         if dist is not None:
             dist.barrier()
@@ -246,6 +272,7 @@ def main():
                        "layers": args.layers, "heads": args.heads, "precision": args.precision,
                        "parallelism": "image-sharded x%d, RCCL all-gather of logits" % world if world > 1 else "single GPU"},
             "ranks_seen": ranks_seen, "devices": devices,
+            "per_rank_pairs_per_s": [round(n_pairs * args.steps / e, 1) for e in rank_elapsed],
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": PEAK_BF16_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic,
                          "note": "achieved = algorithmic 2*M*N*K of one launch / its mean hipEvent duration; this precision mode "

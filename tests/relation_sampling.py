@@ -1,4 +1,8 @@
-"""Relation pair sampling of the relation head (host-side index bookkeeping, mirrors the reference interface).
+"""TEST INFRASTRUCTURE (not part of the product package: SURVEY.md section 2 marks the relation head's pair sampling out of
+scope).  A stand-in for the reference's RelationSampling, used by the tests that drive VETORelationHead in training mode; a
+drop-in deployment passes the reference's own sampler to VETORelationHead(samp_processor=...).
+
+Relation pair sampling of the relation head (host-side index bookkeeping, mirrors the reference interface).
 
   RelationSampling.prepare_test_pairs   sampling.py:31-52   -> veto_amd.pairs.prepare_test_pairs (HIP enumeration)
   RelationSampling.gtbox_relsample      sampling.py:54-107  training with GT boxes: per image up to
@@ -8,7 +12,7 @@ The random draws are torch.randperm calls at the same two points per image, on t
 reference, so a run seeded like the reference selects the same pairs.  detect_relsample (sgdet) is not built."""
 import torch
 
-from .pairs import prepare_test_pairs
+from veto_amd.pairs import prepare_test_pairs
 
 
 class RelationSampling(object):

@@ -1,6 +1,8 @@
 """world_size-2 tests of the multi-GPU exchanges on the gloo backend (CPU): image sharding, the variable-length
 all-gather of predicate logits (eval) and the flat-bucket gradient all-reduce (training), veto_amd/distributed.py."""
 import os
+
+import pytest
 import socket
 
 import torch
@@ -129,9 +131,11 @@ def test_replicas_stay_identical_with_rank_dependent_unused_parameters(tmp_path)
     assert torch.equal(p0[6], init[6]) and torch.equal(p0[7], init[7])       # ... the never-used one did not
 
 
-def test_bench_self_launch_dry_run(tmp_path):
-    """`python bench.py --gpus 2` outside torch.distributed.run starts its own two ranks (gloo / CPU dry run of the launch,
-    rendezvous and all-gather plumbing: no model, no GPU) and relays ONE JSON line that shows both ranks took part."""
+@pytest.mark.parametrize("ranks", [2, 8])
+def test_bench_self_launch_dry_run(tmp_path, ranks):
+    """`python bench.py --gpus N` outside torch.distributed.run starts its own N ranks (gloo / CPU dry run of the launch,
+    rendezvous and all-gather plumbing: no model, no GPU) and relays ONE JSON line that shows every rank took part, with
+    every rank's own rate (a straggler would be visible).  N = 8 is the node size the scaling bench runs at."""
     import json
     import subprocess
     import sys
@@ -139,17 +143,21 @@ def test_bench_self_launch_dry_run(tmp_path):
     env = dict(os.environ, VETO_BENCH_DRYRUN="1")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
-                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=300)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(ranks), "--steps", "2", "--warmup", "1"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["dry_run"] is True
-    assert d["gathered_rows"] == 2 * 12 * 36 * 35
+    assert d["n_gpus"] == ranks and d["ranks_seen"] == ranks and d["dry_run"] is True
+    assert d["gathered_rows"] == ranks * 12 * 36 * 35
+    assert len(d["per_rank_units_per_s"]) == ranks and all(v > 0 for v in d["per_rank_units_per_s"])
+    if ranks != 2:
+        return
     # without the dry-run switch and without two GPUs the parent refuses cleanly before touching a device
     env.pop("VETO_BENCH_DRYRUN")
-    if torch.cuda.device_count() < 2:
+    import bench
+    if (bench.count_gpus_sysfs() or 0) < 2:
         r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], stdout=subprocess.PIPE,
                            stderr=subprocess.PIPE, text=True, env=env, timeout=300)
         assert r.returncode == 2 and "nothing was run" in r.stderr and r.stdout.strip() == ""

@@ -164,11 +164,11 @@ def test_synthetic_generators_are_bit_stable():
 
 
 def test_gtbox_relsample_matches_reference_sampler():
-    """veto_amd.sampling.RelationSampling.gtbox_relsample against the reference's own function run with the same torch
-    seed (tests/golden/relsample_gtbox.npz): same pairs, same labels, same order."""
+    """The tests' stand-in sampler (tests/relation_sampling.py, used to drive VETORelationHead in training mode) against the
+    reference's own function run with the same torch seed (tests/golden/relsample_gtbox.npz): same pairs, labels, order."""
     import os
     from conftest import GOLDEN_DIR
-    from veto_amd.sampling import make_roi_relation_samp_processor
+    from relation_sampling import make_roi_relation_samp_processor
     props, targets = [], []
     for boxes, rel in synth.synthetic_relation_targets():
         props.append(BoxList(torch.from_numpy(boxes), (800, 600)))
@@ -184,3 +184,20 @@ def test_gtbox_relsample_matches_reference_sampler():
         assert np.array_equal(pairs[i].numpy(), g["pairs_%d" % i]) and np.array_equal(labels[i].numpy(), g["labels_%d" % i])
         assert np.array_equal(binaries[i].numpy(), g["binary_%d" % i])
     assert len(pairs[1]) == 1024 and int((labels[1] > 0).sum()) == 256 and len(pairs[3]) == 0     # budget hit; single object
+
+
+def test_relation_head_forward_has_the_reference_signature():
+    """ROIRelationHead.forward(features, proposals, depth_features=None, targets=None, logger=None, x=None)
+    (relation_head.py:90), called by the reference as self.relation(features, detections, targets=..., depth_features=...,
+    logger=..., x=x) (roi_heads.py:69): same parameter names, order and defaults, and that keyword set binds."""
+    import inspect
+    from veto_amd.relation_head import VETORelationHead
+    sig = inspect.signature(VETORelationHead.forward)
+    assert list(sig.parameters) == ["self", "features", "proposals", "depth_features", "targets", "logger", "x"]
+    assert all(sig.parameters[k].default is None for k in ("depth_features", "targets", "logger", "x"))
+    head = VETORelationHead(testing.make_config(2, 8))
+    with pytest.raises(ValueError, match="depth_features"):     # binds, then fails on the missing depth maps (not a TypeError)
+        head(features=[torch.zeros(1, 256, 8, 8)], proposals=[], targets=None, depth_features=None, logger=None, x=None)
+    head.train()
+    with pytest.raises(ValueError, match="sampler"):            # pair sampling belongs to the host code base
+        head([torch.zeros(1, 256, 8, 8)], [], torch.zeros(1, 256, 2, 2), targets=[object()])

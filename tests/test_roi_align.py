@@ -215,7 +215,7 @@ def test_relation_head_from_feature_maps():
     head.predictor = testing.make_predictor(cfg, synth.predictor_state_dict(3, layers=2), dev)
     head.eval()
     props = testing.make_proposals(batch, "predcls", dev)
-    roi, result, losses = head([torch.from_numpy(f).to(dev) for f in feats], props, None, None,
+    roi, result, losses = head([torch.from_numpy(f).to(dev) for f in feats], props, targets=None, logger=None, x=None,
                                depth_features=torch.from_numpy(depth).to(dev))
     boxes, start = [], 0
     for n in num_objs:
@@ -253,7 +253,7 @@ def test_device_eval_chain_feature_maps_to_recall():
     head.predictor = testing.make_predictor(cfg, sd, dev)
     head.eval()
     props = testing.make_proposals(batch, "predcls", dev)
-    _, result, _ = head([torch.from_numpy(f).to(dev) for f in feats], props, None, None, depth_features=torch.from_numpy(depth).to(dev))
+    _, result, _ = head([torch.from_numpy(f).to(dev) for f in feats], props, torch.from_numpy(depth).to(dev))   # depth_features is the third parameter (relation_head.py:90)
     # ground truth: a few relations per image whose predicate is what the ORACLE chain ranks first for that pair
     boxes, start = [], 0
     for n in num_objs:

@@ -320,7 +320,8 @@ def test_relation_head_training_branch_end_to_end():
     depth = torch.from_numpy((0.5 * rng.randn(2, 256, H >> 4, W >> 4)).astype(np.float32)).to(dev).requires_grad_(True)
     feats[1].requires_grad_(True)
     cfg = testing.make_config(2, 8)
-    head = VETORelationHead(cfg)
+    from relation_sampling import make_roi_relation_samp_processor    # tests/: a stand-in for the host code base's sampler
+    head = VETORelationHead(cfg, samp_processor=make_roi_relation_samp_processor(cfg))
     head.predictor = testing.make_predictor(cfg, synth.predictor_state_dict(3, layers=2), dev)
     head.train()
     props, targets = [], []
@@ -336,7 +337,7 @@ def test_relation_head_training_branch_end_to_end():
         props.append(p)
         targets.append(t)
     torch.manual_seed(5)
-    roi, out_props, losses = head(feats, props, targets, None, depth_features=depth)
+    roi, out_props, losses = head(feats, props, targets=targets, depth_features=depth, logger=None, x=None)
     assert set(losses) == {"rel_loss"} and losses["rel_loss"].requires_grad and roi.shape == (12, 256, 8, 8)
     assert all(p.has_field("locating_match") if hasattr(p, "has_field") else "locating_match" in p.extra_fields for p in out_props)
     losses["rel_loss"].backward()

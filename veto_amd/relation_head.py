@@ -19,7 +19,6 @@ from . import registry
 from .pairs import prepare_test_pairs
 from .poolers import make_roi_box_feature_extractor
 from .postprocess import make_roi_relation_post_processor
-from .sampling import make_roi_relation_samp_processor
 
 
 def to_onehot(vec, num_classes, fill=1000.0):
@@ -30,7 +29,9 @@ def to_onehot(vec, num_classes, fill=1000.0):
 
 
 class VETORelationHead(nn.Module):
-    def __init__(self, cfg, in_channels=512):
+    def __init__(self, cfg, in_channels=512, samp_processor=None):
+        """samp_processor: the relation sampler of the host code base (the reference's make_roi_relation_samp_processor(cfg),
+        relation_head.py:66); only the training branch uses it (gtbox_relsample).  Pair sampling is outside this package."""
         super().__init__()
         self.cfg = cfg
         rh = cfg.MODEL.ROI_RELATION_HEAD
@@ -42,13 +43,15 @@ class VETORelationHead(nn.Module):
         self.box_feature_extractor = make_roi_box_feature_extractor(cfg, in_channels, for_relation=True)  # :53
         self.predictor = registry.make_roi_relation_predictor(cfg, in_channels)
         self.post_processor = make_roi_relation_post_processor(cfg)
-        self.samp_processor = make_roi_relation_samp_processor(cfg)
+        self.samp_processor = samp_processor
         self.num_obj_cls = self.predictor.num_obj_cls
         self.max_proposal_pairs = int(getattr(rh, "MAX_PROPOSAL_PAIR", 2048))
 
-    def forward(self, features, proposals, targets=None, logger=None, depth_features=None):
-        """The reference's signature (:90): features = list of FPN maps [B, 256, H_l, W_l], depth_features =
-        [B, 256, H/16, W/16], proposals = list[BoxList] (xyxy) on the HIP device.
+    def forward(self, features, proposals, depth_features=None, targets=None, logger=None, x=None):
+        """The reference's signature, parameter for parameter (relation_head.py:90; called as `self.relation(features,
+        detections, targets=..., depth_features=..., logger=..., x=x)`, roi_heads.py:69): features = list of FPN maps
+        [B, 256, H_l, W_l], depth_features = [B, 256, H/16, W/16], proposals = list[BoxList] (xyxy) on the HIP device; `x` (the
+        box head's pooled features, unused by the VETO branch of the reference as well) is accepted and ignored.
         Returns (roi_features, result, {}) like the reference's test branch (:243)."""
         if depth_features is None:
             raise ValueError("the VETO predictors need depth_features (relation_head.py:141)")
@@ -56,6 +59,8 @@ class VETORelationHead(nn.Module):
             # :112-121 GT-box relation sampling, :140-141 ROI features, :196-203 predictor -> losses, :247 return
             if targets is None:
                 raise ValueError("training needs the targets (GT BoxLists with a 'relation' matrix)")
+            if self.samp_processor is None:
+                raise ValueError("training needs the host code base's relation sampler: VETORelationHead(cfg, samp_processor=...)")
             self._overload_predcls_fields(proposals, features[0].device)
             with torch.no_grad():
                 proposals, rel_labels, rel_pair_idxs, _ = self.samp_processor.gtbox_relsample(proposals, targets)
