@@ -294,10 +294,11 @@ size_t veto_debug_gemm_workspace_bytes(int32_t m, int32_t n, int32_t k);
  * with the residual of :21) on VETO_MIXED operands; mode 0 = two GEMM launches with the hidden activation in HBM, mode 1 = the
  * fused kernel (hidden activation stays on the CU).  a [m, 576] (the LayerNorm'ed rows), w1 [1152, 576], w2 [576, 1152],
  * x [m, 576] in / out.  flags & 1: rebuild the mixed operands in the workspace first.  Runs `reps` times; *ms_per_rep (host,
- * optional) = mean device time of one run. */
+ * optional) = mean device time of one run.  ln_rows (optional, m x 2304 bytes): LayerNorm(x_out; ln_w, ln_b) as mixed activation
+ * rows -- the next layer's PreNorm -- from the fused kernel's epilogue (mode 1) or a LayerNorm launch (mode 0). */
 int veto_debug_ffn(void* stream, const float* a, const float* w1, const float* b1, const float* w2, const float* b2,
                    float* x, int32_t m, int32_t mode, int32_t flags, int32_t reps, float* ms_per_rep, void* workspace,
-                   size_t workspace_bytes);
+                   size_t workspace_bytes, const float* ln_w, const float* ln_b, void* ln_rows);
 size_t veto_debug_ffn_workspace_bytes(int32_t m);
 
 /* ---- training losses and MEET expert sampling (partial) -------------------------

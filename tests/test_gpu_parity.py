@@ -124,7 +124,7 @@ def test_fused_feedforward_matches_two_launch_form_and_fp64(m):
     for mode in (0, 1):
         x = x0.clone()
         native.check(lib.veto_debug_ffn(None, a.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), x.data_ptr(),
-                                        m, mode, 1, 1, None, ws.data_ptr(), ws.numel()))
+                                        m, mode, 1, 1, None, ws.data_ptr(), ws.numel(), None, None, None))
         torch.cuda.synchronize()
         assert torch.isfinite(x).all()
         rel = ((x.double() - ref).abs() / scale).max().item()
@@ -136,9 +136,54 @@ def test_fused_feedforward_matches_two_launch_form_and_fp64(m):
         xs = x0[:k].clone()
         ws2 = torch.empty(lib.veto_debug_ffn_workspace_bytes(k), dtype=torch.uint8, device=dev)
         native.check(lib.veto_debug_ffn(None, a[:k].contiguous().data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(),
-                                        xs.data_ptr(), k, 1, 1, 1, None, ws2.data_ptr(), ws2.numel()))
+                                        xs.data_ptr(), k, 1, 1, 1, None, ws2.data_ptr(), ws2.numel(), None, None, None))
         torch.cuda.synchronize()
         assert torch.equal(xs, out[1][:k])
+
+
+def _decode_mixed_rows(raw, k):
+    """[rows, 4k] uint8 mixed ACTIVATION rows (veto_amd/csrc/common.h) -> (h fp16 plane, h + X * 2^-11, Y) as float64 [rows, k]."""
+    rows = raw.shape[0]
+    blk = raw.reshape(rows, k // 64, 256)
+    h = blk[:, :, :128].contiguous().view(torch.float16).reshape(rows, k).double()
+    grp = blk[:, :, 128:].reshape(rows, k // 64, 16, 8)
+    x = grp[..., :4].contiguous().view(torch.float8_e4m3fn).double().reshape(rows, k)
+    y = grp[..., 4:].contiguous().view(torch.float8_e4m3fn).double().reshape(rows, k)
+    return h, h + x * 2.0 ** -11, y
+
+
+@pytest.mark.parametrize("m", [129, 5000])
+def test_fused_feedforward_layernorm_epilogue(m):
+    """The next layer's LayerNorm written by the fused FeedForward epilogue as mixed rows (model_veto.py:125-132 behind :137-143):
+    the rows are decoded plane by plane -- fp16 value, e4m3 residual (2^11), e4m3 value -- and compared with the LayerNorm of the
+    kernel's own fp32 result, and with the rows a LayerNorm launch writes behind the two-launch form."""
+    from veto_amd import native
+    lib = native.load_library()
+    dev = _dev()
+    g = torch.Generator(device="cpu").manual_seed(m)
+    a = torch.randn(m, 576, generator=g).to(dev)
+    x0 = (torch.randn(m, 576, generator=g) + 0.7).to(dev)          # a row mean away from zero
+    w1 = (torch.randn(1152, 576, generator=g) * 0.04).to(dev)
+    b1 = (torch.randn(1152, generator=g) * 0.1).to(dev)
+    w2 = (torch.randn(576, 1152, generator=g) * 0.03).to(dev)
+    b2 = (torch.randn(576, generator=g) * 0.1).to(dev)
+    lw = (1.0 + 0.3 * torch.randn(576, generator=g)).to(dev)
+    lb = (0.2 * torch.randn(576, generator=g)).to(dev)
+    ws = torch.empty(lib.veto_debug_ffn_workspace_bytes(m), dtype=torch.uint8, device=dev)
+    planes = []
+    for mode in (0, 1):
+        x = x0.clone()
+        rows = torch.zeros(m, 4 * 576, dtype=torch.uint8, device=dev)
+        native.check(lib.veto_debug_ffn(None, a.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), x.data_ptr(),
+                                        m, mode, 1, 1, None, ws.data_ptr(), ws.numel(), lw.data_ptr(), lb.data_ptr(), rows.data_ptr()))
+        torch.cuda.synchronize()
+        ref = torch.nn.functional.layer_norm(x.double(), (576,), lw.double(), lb.double(), 1e-5)
+        h, hx, y = _decode_mixed_rows(rows, 576)
+        assert (h - ref).abs().max().item() <= 2.0 ** -11 * ref.abs().max().item() * 1.01 + 1e-6, mode      # fp16 plane
+        assert ((hx - ref).abs() / ref.abs().clamp_min(0.05)).max().item() < 2.0 ** -14, mode                # + e4m3 residual
+        assert ((y - ref).abs() / ref.abs().clamp_min(0.05)).max().item() < 2.0 ** -3, mode                  # e4m3 value (4 bits)
+        planes.append(hx)
+    assert (planes[0] - planes[1]).abs().max().item() < 2e-4
 
 
 @pytest.mark.parametrize("n", [1, 2, 3, 10, 36, 50])

@@ -32,7 +32,7 @@ for m in rows:
     for mode, name in (((1, "fused"),) if fast else ((0, "two launches"), (1, "fused"))):
         x = x0.clone()
         native.check(lib.veto_debug_ffn(None, a.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), x.data_ptr(),
-                                        m, mode, 1, 1, None, ws.data_ptr(), ws.numel()))
+                                        m, mode, 1, 1, None, ws.data_ptr(), ws.numel(), None, None, None))
         torch.cuda.synchronize()
         if fast:
             msg = "M=%d %-12s %s" % (m, name, os.path.basename(os.environ.get("VETO_AMD_LIB", "libveto_amd.so")))
@@ -43,7 +43,7 @@ for m in rows:
         ms = ctypes.c_float(0)
         for _ in range(2):   # the first timed batch warms the clocks
             native.check(lib.veto_debug_ffn(None, a.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), x.data_ptr(),
-                                            m, mode, 0, reps, ctypes.byref(ms), ws.data_ptr(), ws.numel()))
+                                            m, mode, 0, reps, ctypes.byref(ms), ws.data_ptr(), ws.numel(), None, None, None))
         flops = 2.0 * m * 576 * 1152 * 2
         print("%s  %.3f ms  %.0f TFLOP/s alg." % (msg, ms.value, flops / (ms.value * 1e-3) / 1e12), flush=True)
     if not fast:

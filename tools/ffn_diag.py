@@ -17,7 +17,7 @@ def run(a, w1, b1, w2, b2, x0, mode=1):
     ws = torch.empty(lib.veto_debug_ffn_workspace_bytes(m), dtype=torch.uint8, device=dev)
     x = x0.clone()
     native.check(lib.veto_debug_ffn(None, a.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), x.data_ptr(),
-                                    m, mode, 1, 1, None, ws.data_ptr(), ws.numel()))
+                                    m, mode, 1, 1, None, ws.data_ptr(), ws.numel(), None, None, None))
     torch.cuda.synchronize()
     return x
 

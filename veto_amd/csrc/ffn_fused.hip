@@ -100,8 +100,11 @@ __device__ __forceinline__ unsigned long long stamp() {
 #define ACC(a, t1, t0) a += (t1) - (t0)
 // timeline of one chunk (workgroup 0, first panel, chunk 2; waves 0 and 4): [wave][position][top, waited, barrier, group 0..5]
 __device__ unsigned long long g_ffn_timeline[2 * 36 * 9];
+__device__ unsigned long long g_ffn_epi[2 * 12];
+#define EP(k) do { if (b == 0 && it == 1 && (w & 3) == 0) g_ffn_epi[(w >> 2) * 12 + (k)] = stamp(); } while (0)
 #define TL(P, k) do { if (b == 0 && it == 0 && c == 2 && (w & 3) == 0) g_ffn_timeline[((w >> 2) * 36 + (P)) * 9 + (k)] = stamp(); } while (0)
 #else
+#define EP(k)
 #define TL(P, k)
 #define STAMP(x)
 #define ACC(a, t1, t0)
@@ -132,6 +135,11 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs g) {
   const int my_panels = g.n_panels > b ? (g.n_panels - b + G - 1) / G : 0;   // panels b, b + G, ...
   if (my_panels == 0) return;
 
+  // Start-phase stagger (speed only): equal panels keep the persistent workgroups in lockstep, so all 256 CUs would reach their
+  // panel epilogue -- 0.6 / 0.9 MB of HBM traffic per workgroup with no matrix work beside it -- at the same moment and share
+  // the HBM bandwidth (~10 B/clk/CU: 42 us per panel, measured).  The phases are per XCD (b & 7): the 32 workgroups of an XCD
+  // stay in step, because they stream the same weight stages through their shared L2 at the same time.
+  for (int i = g.stagger * (b & 7); i > 0; --i) __builtin_amdgcn_s_sleep(32);   // ~1 us per unit
   for (int i = tid; i < FH; i += 512) ((float*)(smem + kB1Off))[i] = g.b1[i];
   for (int i = tid; i < kDim; i += 512) ((float*)(smem + kB2Off))[i] = g.b2[i];
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -437,6 +445,7 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs g) {
     // l >> 4; one ds_bpermute per value (lane 4 r + q takes lane 16 q + r) makes every quad of lanes cover 64 contiguous bytes
     // of one row (gemm_split_ps.hip).  Every residual read is issued before the first store (one in-order counter per wave).
     STAMP(t0);
+    EP(0);
     if (!(FFN_ABLATE & 16)) {
       int lane_e = lane;
       asm volatile("" : "+v"(lane_e));
@@ -461,6 +470,7 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs g) {
         }                                            // sched_barrier before instruction selection (they carry no chain)
         __builtin_amdgcn_sched_barrier(0);
       }
+      EP(1);
       // phase B: six groups (row group m, column third t) of six blocks; the residuals of groups u + 1 and u + 2 are in flight
       // while group u is combined (three buffers of 24 registers: the fc1 accumulators and the fragments are dead here: every
       // round trip to HBM is ~2 us with all 256 CUs in their epilogues at once); sched_barrier keeps the groups apart
@@ -487,7 +497,9 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs g) {
         }
         __builtin_amdgcn_sched_barrier(0);
       }
+      EP(2);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the reads are consumed; the two prefetched stages have landed too)
+      EP(3);
 #pragma unroll
       for (int m = 0; m < 2; ++m) {
         const int row = row0 + m * 16;
@@ -498,6 +510,66 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs g) {
 #pragma unroll
             for (int i = 0; i < 6; ++i) *(f32x4*)(op + t * FC + (i >> 1) * 64 + (i & 1) * 16) = acc2[t][i][m];
         }
+      }
+      EP(4);
+      if (g.ln_out) {
+        // ---- LayerNorm of the finished rows (model_veto.py:125-132 of the NEXT layer's attention PreNorm) as mixed rows: the
+        // workgroup holds complete rows, so the standalone LayerNorm launch (0.66 GB read + 0.66 GB written) disappears.  A row's
+        // 576 columns sit in the two waves of its row group (wn = 0, 1), 4 lanes x 72 values each: quad reduction by DPP, the two
+        // waves exchange through LDS (the idle activation part of ring slot 2); two passes (mean, then centred squares) like
+        // rowq_stats in rowops.hip.  Both waves add the same two partial sums: identical statistics in either.
+        float* red = (float*)(smem + 2 * kSlot);          // [pass][wave][m][row] floats
+        float mean[2], rstd[2];
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+          float part[2];
+#pragma unroll
+          for (int m = 0; m < 2; ++m) {
+            float p = 0.f;
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+#pragma unroll
+              for (int i = 0; i < 6; ++i) {
+                if (pass == 0) {
+                  p += (acc2[t][i][m][0] + acc2[t][i][m][1]) + (acc2[t][i][m][2] + acc2[t][i][m][3]);
+                } else {
+#pragma unroll
+                  for (int e = 0; e < 4; ++e) { const float d = acc2[t][i][m][e] - mean[m]; p += d * d; }
+                }
+              }
+            p += __shfl_xor(p, 1, 64);
+            p += __shfl_xor(p, 2, 64);
+            part[m] = p;
+            if (eq == 0) red[((pass * 8 + w) * 2 + m) * 16 + er] = p;
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          wg_barrier();
+#pragma unroll
+          for (int m = 0; m < 2; ++m) {
+            const float tot = part[m] + red[((pass * 8 + (w ^ 1)) * 2 + m) * 16 + er];
+            if (pass == 0) mean[m] = tot * (1.f / kDim);
+            else rstd[m] = 1.f / sqrtf(tot * (1.f / kDim) + 1e-5f);
+          }
+          EP(5 + pass);
+        }
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+          for (int i = 0; i < 6; ++i) {
+            const int col = col0 + t * FC + (i >> 1) * 64 + (i & 1) * 16;
+            const f32x4 wv = *(const f32x4*)(g.ln_w + col), bv = *(const f32x4*)(g.ln_b + col);
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+              const int row = row0 + m * 16;
+              f32x4 y;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) y[e] = (acc2[t][i][m][e] - mean[m]) * rstd[m] * wv[e] + bv[e];
+              if (row < g.M) store_act4<FMT_MIXED>((__bf16*)(g.ln_out + (size_t)row * kRow1), col, y);
+            }
+          }
+        EP(7);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        EP(8);
       }
       skip = 2;   // stages 0 and 1 of the next panel landed before the drain above
     } else {
@@ -528,6 +600,8 @@ hipError_t launch_ffn_fused(FfnArgs g, hipStream_t s) {
     if (num_cu < 1) num_cu = 1;
   }
   g.n_panels = (g.M + FR - 1) / FR;
+  static const int stagger = getenv("VETO_FFN_STAGGER") ? atoi(getenv("VETO_FFN_STAGGER")) : 0;   // A/B knob (speed only)
+  g.stagger = stagger;
   const int nblocks = g.n_panels < num_cu ? g.n_panels : num_cu;   // one persistent workgroup per CU (LDS: 159 KiB each)
   VETO_LAUNCH(ffn_fused_kernel, dim3(nblocks), dim3(512), 0, s, g);
   hipError_t rc = hipGetLastError();
@@ -541,6 +615,15 @@ hipError_t launch_ffn_fused(FfnArgs g, hipStream_t s) {
     for (int bb = 0; bb < nb; ++bb)
       for (int k = 0; k < 8; ++k) sum[k] += (double)host[bb * 8 + k];
     static int printed = 0;
+    {
+      static unsigned long long ep[2 * 12];
+      hipMemcpyFromSymbol(ep, HIP_SYMBOL(g_ffn_epi), sizeof(ep));
+      for (int wv = 0; wv < 2; ++wv) {
+        fprintf(stderr, "[ffn epilogue] wave %d:", wv * 4);
+        for (int k = 1; k < 9; ++k) fprintf(stderr, " %6lld", (long long)(ep[wv * 12 + k] - ep[wv * 12 + k - 1]));
+        fprintf(stderr, "  (transpose | resid loads+adds | drain | x stores | LN pass 1 | pass 2 | normalise+stores | their drain)\n");
+      }
+    }
     if (!printed++) {
       static unsigned long long tl[2 * 36 * 9];
       hipMemcpyFromSymbol(tl, HIP_SYMBOL(g_ffn_timeline), sizeof(tl));

@@ -62,7 +62,13 @@ struct FfnArgs {
   int M;
   const int* exp1;
   const int* exp2;
+  // optional: LayerNorm (eps 1e-5) of the result rows with ln_w / ln_b, written as mixed activation rows to ln_out (row pitch
+  // 4*576 B; may be the buffer `a` points to: a panel's rows are written after its last read) -- the next layer's PreNorm
+  const float* ln_w;
+  const float* ln_b;
+  char* ln_out;
   int n_panels;          // filled by the launcher
+  int stagger;           // filled by the launcher (speed only): start delay of workgroup b = (b & 7) * stagger * s_sleep(32) (~1 us): one phase per XCD
 };
 int ffn_panel_rows();
 hipError_t launch_ffn_fused(FfnArgs g, hipStream_t s);

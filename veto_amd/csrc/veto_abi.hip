@@ -505,6 +505,7 @@ int veto_forward(veto_handle_t h, void* stream, const veto_inputs_t* in, void* w
   const bool mixed_out = mixed && attention_reads_tables(H);
   static const bool ffn_off = getenv("VETO_FFN_FUSED") && !strcmp(getenv("VETO_FFN_FUSED"), "0");          // A/B knob
   const bool ffn_fused = !ffn_off;   // VETO_MIXED: fc1 -> GELU -> fc2 + residual as one launch
+  static const bool ffn_ln_off = getenv("VETO_FFN_LN") && !strcmp(getenv("VETO_FFN_LN"), "0");              // A/B knob
   if (qkv0_tables) {
     const int R = n_obj * 16;
     HIP_TRY(launch_centre_split(ws.patch_tab, ws.ptab_split, R, s));
@@ -604,11 +605,16 @@ int veto_forward(veto_handle_t h, void* stream, const veto_inputs_t* in, void* w
           ProfScope ps(h, s, "layernorm", 0, (double)M * kDim * 8);
           HIP_TRY(launch_layernorm(ws.x, kDim, w.ln2_w, w.ln2_b, ws.a, M, s, mixed ? FMT_MIXED : FMT_SPLIT));
         }
+        // ... and the LayerNorm in front of the next layer's QKV GEMM in its epilogue, when that GEMM takes mixed rows
+        const bool ffn_ln_next = mixed && ffn_fused && !ffn_ln_off && l + 1 < L - 1;
         if (mixed && ffn_fused) {
           // FeedForward in one launch (ffn_fused.hip): the hidden activation never leaves the CU
           FfnArgs f{};
           f.a = (const char*)ws.a; f.w1 = (const char*)w.fc1_m; f.w2 = (const char*)w.fc2_m; f.b1 = w.fc1_b; f.b2 = w.fc2_b;
           f.resid = ws.x; f.out = ws.x; f.ldr = kDim; f.ldo = kDim; f.M = M; f.exp1 = w.exp_m + 2; f.exp2 = w.exp_m + 3;
+          if (ffn_ln_next) {   // the next layer's LayerNorm1 in the epilogue (mixed rows, in place over this launch's input rows)
+            f.ln_w = h->layers[l + 1].ln1_w; f.ln_b = h->layers[l + 1].ln1_b; f.ln_out = (char*)ws.a;
+          }
           // bytes: the LayerNorm'ed rows in, the residual stream in and out, the two weight matrices
           ProfScope ps(h, s, "ffn_fused", 2.0 * 2.0 * M * (double)kDim * 2 * kDim, (double)M * kDim * 12 + 2.0 * 2 * kDim * kDim * 4);
           HIP_TRY(launch_ffn_fused(f, s));
@@ -624,6 +630,8 @@ int veto_forward(veto_handle_t h, void* stream, const veto_inputs_t* in, void* w
           const LayerW& nx = h->layers[l + 1];
           if (l + 1 == L - 1 && fold_last) {
             // the folded last layer LayerNorms its token rows itself
+          } else if (ffn_ln_next) {
+            // written by the fused FeedForward launch
           } else {
             ProfScope ps(h, s, "layernorm", 0, (double)M * kDim * 8);
             // the next layer's QKV GEMM takes mixed rows unless it is the (unfolded) last layer
@@ -1440,9 +1448,11 @@ size_t veto_debug_ffn_workspace_bytes(int32_t m) {
 }
 
 int veto_debug_ffn(void* stream, const float* a, const float* w1, const float* b1, const float* w2, const float* b2, float* x,
-                   int32_t m, int32_t mode, int32_t flags, int32_t reps, float* ms_per_rep, void* workspace, size_t workspace_bytes) {
+                   int32_t m, int32_t mode, int32_t flags, int32_t reps, float* ms_per_rep, void* workspace, size_t workspace_bytes,
+                   const float* ln_w, const float* ln_b, void* ln_rows) {
   if (!a || !w1 || !b1 || !w2 || !b2 || !x || !workspace) return fail(VETO_ERR_INVALID, "null argument");
   if (m <= 0 || reps <= 0 || (mode != 0 && mode != 1)) return fail(VETO_ERR_INVALID, "bad m / reps / mode");
+  if (ln_rows && (!ln_w || !ln_b)) return fail(VETO_ERR_INVALID, "ln_rows needs ln_w and ln_b");
   if (workspace_bytes < veto_debug_ffn_workspace_bytes(m)) return fail(VETO_ERR_WORKSPACE, "workspace too small");
   hipStream_t s = (hipStream_t)stream;
   const size_t mp = (size_t)gemm_rows_padded(m);
@@ -1469,6 +1479,7 @@ int veto_debug_ffn(void* stream, const float* a, const float* w1, const float* b
       FfnArgs f{};
       f.a = (const char*)a_m; f.w1 = (const char*)w1_m; f.w2 = (const char*)w2_m; f.b1 = b1; f.b2 = b2;
       f.resid = x; f.out = x; f.ldr = kDim; f.ldo = kDim; f.M = m; f.exp1 = exps + 0; f.exp2 = exps + 1;
+      if (ln_rows) { f.ln_w = ln_w; f.ln_b = ln_b; f.ln_out = (char*)ln_rows; }
       HIP_TRY(launch_ffn_fused(f, s));
     } else {
       GemmArgs g1{};
@@ -1479,6 +1490,7 @@ int veto_debug_ffn(void* stream, const float* a, const float* w1, const float* b
       g2.fmt = FMT_MIXED; g2.w_exp = exps + 1; g2.a = hid; g2.w = w2_m; g2.bias = b2; g2.resid = x; g2.c = x;
       g2.M = m; g2.N = kDim; g2.K = 2 * kDim; g2.ldr = kDim; g2.ldc = kDim;
       HIP_TRY(launch_gemm_split(g2, EPI_RESID, 0, s));
+      if (ln_rows) HIP_TRY(launch_layernorm(x, kDim, ln_w, ln_b, (__bf16*)ln_rows, m, s, FMT_MIXED));
     }
   }
   if (ms_per_rep) {

@@ -141,7 +141,7 @@ def load_library():
     lib.veto_debug_gemm_workspace_bytes.argtypes = [c_int32, c_int32, c_int32]
     lib.veto_debug_gemm_workspace_bytes.restype = c_size_t
     lib.veto_debug_ffn.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32,
-                                   c_int32, POINTER(ctypes.c_float), c_void_p, c_size_t]
+                                   c_int32, POINTER(ctypes.c_float), c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]
     lib.veto_debug_ffn_workspace_bytes.argtypes = [c_int32]
     lib.veto_debug_ffn_workspace_bytes.restype = c_size_t
     lib.veto_postprocess_workspace_bytes.argtypes = [c_int32, c_int32]
