@@ -42,6 +42,13 @@
 #ifndef FFN_ABLATE
 #define FFN_ABLATE 0
 #endif
+// micro-variants (A/B with tools/ffn_variants.sh)
+#ifndef FFN_PRIO
+#define FFN_PRIO 0          // 1: s_setprio 1 for waves 4..7 (the younger wave of every SIMD loses the issue arbitration otherwise)
+#endif
+#ifndef FFN_DMA_EARLY
+#define FFN_DMA_EARLY 1     // DMA instructions issued before the first MFMA group of a stage (the rest follow groups 0, 1, ...)
+#endif
 
 
 namespace veto {
@@ -252,8 +259,8 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs g) {
     fw1[0] = *(lds_frag_t)(size_t)(w1);
     // the first two DMA instructions go out while the first fragments are on their way from the LDS (their issue back-pressure
     // and the LDS latency overlap instead of adding up); the others follow groups 0, 1, 2
-    dma(0);
-    dma(1);
+#pragma unroll
+    for (int k = 0; k < FFN_DMA_EARLY; ++k) dma(k);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
@@ -263,7 +270,7 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs g) {
       }
 #pragma unroll
       for (int m = 0; m < 2; ++m) mma(kind_tag, acc[i][m], fw0[i & 1], fw1[i & 1], fa0[m], fa1[m], scale);
-      dma(i + 2);
+      dma(i + FFN_DMA_EARLY);
       valu(i);
       mark(i);
       __builtin_amdgcn_sched_barrier(0);
@@ -318,6 +325,7 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs g) {
     }
   };
 
+  if (FFN_PRIO && w >= 4) __builtin_amdgcn_s_setprio(1);
   unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t_begin = 0, s_wait = 0, s_bar = 0, s_iss = 0, s_cmp = 0, s_hid = 0, s_epi = 0;
   (void)t0; (void)t1; (void)t2; (void)t3; (void)t_begin; (void)s_wait; (void)s_bar; (void)s_iss; (void)s_cmp; (void)s_hid; (void)s_epi;
   STAMP(t_begin);
