@@ -43,7 +43,12 @@ enum veto_precision {
   VETO_FAST = 1,     /* single bf16 MFMA pass, ~1e-2 logit error; reported separately */
   VETO_MIXED = 2     /* fp16 MFMA main product + e4m3 K=128 MFMA correction terms on the token-row Linears: 2/3 of the
                         matrix-pipe time of VETO_PRECISE, logit error 4-9e-5 measured (1e-3 tolerance); what the Python
-                        plugin selects by default (VETO_AMD.PRECISION = "mixed") */
+                        plugin selects by default (VETO_AMD.PRECISION = "mixed").  Supported activation range: the e4m3
+                        planes keep full precision for |activation| <= 448 (an element beyond degrades to the fp16
+                        class, 2^-11; fp16 overflows at 65504); 6.3e-5 on trained-like activations
+                        (tests/test_gpu_parity.py::test_parity_on_trained_like_activations).  In this mode the
+                        FeedForward of every full layer runs as ONE launch (ffn_fused.hip).  The inference path uses
+                        the one-exponential GELU (|error| <= 1e-6) in every mode; the training path keeps the erf form */
 };
 
 /* MODEL.ROI_RELATION_HEAD.VETOTRANSFORMER.* (config/defaults.py:331-338) + class counts. */
