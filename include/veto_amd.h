@@ -306,6 +306,15 @@ int veto_debug_ffn(void* stream, const float* a, const float* w1, const float* b
                    size_t workspace_bytes, const float* ln_w, const float* ln_b, void* ln_rows);
 size_t veto_debug_ffn_workspace_bytes(int32_t m);
 
+/* ---- test / measurement hook: the attention out projection + residual, x <- x + a W^T + b (model_veto.py:96 `to_out`, :20) on
+ * VETO_MIXED operands, optionally followed by LayerNorm rows (ln_rows, m x 2304 bytes of mixed activation rows: the FeedForward
+ * PreNorm).  mode 0 = the GEMM launch (+ a LayerNorm launch), mode 1 = the full-row panel kernel (one launch).  a [m, 576],
+ * w [576, 576], x [m, 576] in / out. */
+int veto_debug_outproj(void* stream, const float* a, const float* w, const float* b, float* x, int32_t m, int32_t mode,
+                       int32_t flags, int32_t reps, float* ms_per_rep, void* workspace, size_t workspace_bytes,
+                       const float* ln_w, const float* ln_b, void* ln_rows);
+size_t veto_debug_outproj_workspace_bytes(int32_t m);
+
 /* ---- training losses and MEET expert sampling (partial) -------------------------
  * veto_ce_loss: nn.CrossEntropyLoss(weight)(logits[rows], labels), mean reduction -- the relation loss of
  * VETOPredictor.forward (roi_relation_predictors.py:4133, BETA_LOSS weights :4057-4068) and, on a row subset with

@@ -186,6 +186,40 @@ def test_fused_feedforward_layernorm_epilogue(m):
     assert (planes[0] - planes[1]).abs().max().item() < 2e-4
 
 
+@pytest.mark.parametrize("m", [1, 129, 5000, 40000])
+def test_fused_out_projection_residual_layernorm(m):
+    """The attention out projection + residual (+ the FeedForward PreNorm as mixed rows) on the full-row panel kernel
+    (ffn_fused.hip MODE 1; model_veto.py:96, :20, :125-132) against fp64 and against the GEMM launch + LayerNorm launch."""
+    from veto_amd import native
+    lib = native.load_library()
+    dev = _dev()
+    g = torch.Generator(device="cpu").manual_seed(m + 7)
+    a = torch.randn(m, 576, generator=g).to(dev)
+    x0 = (torch.randn(m, 576, generator=g) - 0.4).to(dev)
+    w = (torch.randn(576, 576, generator=g) * 0.05).to(dev)
+    b = (torch.randn(576, generator=g) * 0.1).to(dev)
+    lw = (1.0 + 0.3 * torch.randn(576, generator=g)).to(dev)
+    lb = (0.2 * torch.randn(576, generator=g)).to(dev)
+    ref = x0.double() + a.double() @ w.double().t() + b.double()
+    scale = (a.abs().double() @ w.abs().double().t()).clamp_min(1e-6)
+    ws = torch.empty(lib.veto_debug_outproj_workspace_bytes(m), dtype=torch.uint8, device=dev)
+    xs, planes = [], []
+    for mode in (0, 1):
+        x = x0.clone()
+        rows = torch.zeros(m, 4 * 576, dtype=torch.uint8, device=dev)
+        native.check(lib.veto_debug_outproj(None, a.data_ptr(), w.data_ptr(), b.data_ptr(), x.data_ptr(), m, mode, 1, 1, None,
+                                            ws.data_ptr(), ws.numel(), lw.data_ptr(), lb.data_ptr(), rows.data_ptr()))
+        torch.cuda.synchronize()
+        assert ((x.double() - ref).abs() / scale).max().item() < 1.5e-5, mode
+        lnref = torch.nn.functional.layer_norm(x.double(), (576,), lw.double(), lb.double(), 1e-5)
+        h, hx, y = _decode_mixed_rows(rows, 576)
+        assert ((hx - lnref).abs() / lnref.abs().clamp_min(0.05)).max().item() < 2.0 ** -14, mode
+        xs.append(x)
+        planes.append(hx)
+    assert torch.equal(xs[0], xs[1])        # same operands, same summation order, same epilogue arithmetic
+    assert (planes[0] - planes[1]).abs().max().item() < 2e-4
+
+
 @pytest.mark.parametrize("n", [1, 2, 3, 10, 36, 50])
 def test_enumerate_pairs_bit_exact(n):
     from veto_amd.pairs import prepare_test_pairs

@@ -18,8 +18,8 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # launches of gemm_split_ps_kernel inside one forward step of the L4 / mixed workload, in order (round 3: the FeedForward
 # Linears of the three full layers are the ffn_fused_kernel launches, labelled by kernel name below)
-GEMM_ORDER_L4 = ["gemm_patch", "gemm_qkv0_tab", "gemm_qkv0_tab", "gemm_qkv0_lc", "gemm_qkv0_lc", "gemm_out", "gemm_qkv",
-                 "gemm_out", "gemm_qkv", "gemm_out", "gemm_u_cls", "gemm_out_cls", "gemm_fc1_cls", "gemm_fc2_cls"]
+GEMM_ORDER_L4 = ["gemm_patch", "gemm_qkv0_tab", "gemm_qkv0_tab", "gemm_qkv0_lc", "gemm_qkv0_lc", "gemm_qkv", "gemm_qkv",
+                 "gemm_u_cls", "gemm_out_cls", "gemm_fc1_cls", "gemm_fc2_cls"]
 
 
 def load(d):
@@ -57,8 +57,8 @@ def per_label(steps):
             else:
                 label = name.replace("void ", "").replace("veto::", "").replace("(anonymous namespace)::", "")
                 label = re.split(r"[<(]", label)[0].strip() or name[:40]
-                if label == "ffn_fused_kernel":
-                    label = "ffn_fused"          # the name bench.py's per-kernel timers use
+                if label == "ffn_fused_kernel":  # the names bench.py's per-kernel timers use: MODE 0 FeedForward, MODE 1 out projection
+                    label = "out_ln_fused" if re.search(r"ffn_fused_kernel<1>", name) else "ffn_fused"
                 if "attention_mfma_kernel" in name:          # the table form of layer 0 is its own instantiation
                     label += "_tab" if re.search(r"attention_mfma_kernel<\d+, *(true|1)", name) else ""
             acc[label].append((v, us))

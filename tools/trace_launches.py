@@ -12,14 +12,14 @@ ORDER_L4_UNFUSED = ["gemm_patch", "gemm_qkv0_tab (S)", "gemm_qkv0_tab (O)", "gem
                     "gemm_fc2", "gemm_qkv", "gemm_out", "gemm_fc1", "gemm_fc2", "gemm_qkv", "gemm_out", "gemm_fc1", "gemm_fc2", "gemm_u_cls",
                     "gemm_out_cls", "gemm_fc1_cls", "gemm_fc2_cls"]
 # round 3 (VETO_MIXED): the FeedForward Linears of the three full layers run in ffn_fused_kernel (listed separately below)
-ORDER_L4 = ["gemm_patch", "gemm_qkv0_tab (S)", "gemm_qkv0_tab (O)", "gemm_qkv0_lc (t17)", "gemm_qkv0_lc (t18)", "gemm_out", "gemm_qkv",
-            "gemm_out", "gemm_qkv", "gemm_out", "gemm_u_cls", "gemm_out_cls", "gemm_fc1_cls", "gemm_fc2_cls"]
+ORDER_L4 = ["gemm_patch", "gemm_qkv0_tab (S)", "gemm_qkv0_tab (O)", "gemm_qkv0_lc (t17)", "gemm_qkv0_lc (t18)", "gemm_qkv", "gemm_qkv",
+            "gemm_u_cls", "gemm_out_cls", "gemm_fc1_cls", "gemm_fc2_cls"]
 
 
 def main(path):
     rows = list(csv.DictReader(open(path)))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    steps, cur, ffn = [], None, []
+    steps, cur, ffn, outp = [], None, [], []
     for r in rows:
         name = r["Kernel_Name"]
         if "pair_indices_kernel" in name:
@@ -28,8 +28,10 @@ def main(path):
         elif cur is not None and "gemm_split_ps_kernel" in name:
             inst = re.search(r"gemm_split_ps_kernel<([^>]*)>", name).group(1)
             cur.append((inst, (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3))
-        elif cur is not None and "ffn_fused_kernel" in name:
+        elif cur is not None and "ffn_fused_kernel<0>" in name:
             ffn.append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+        elif cur is not None and "ffn_fused_kernel<1>" in name:
+            outp.append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
     n = max(len(s) for s in steps)
     steps = [s for s in steps if len(s) == n]
     acc = defaultdict(list)
@@ -39,7 +41,9 @@ def main(path):
     order = ORDER_L4 if n == len(ORDER_L4) else ORDER_L4_UNFUSED if n == len(ORDER_L4_UNFUSED) else None
     print("%d forward steps, %d GEMM launches each (4-layer order: %s)" % (len(steps), n, "yes" if order else "n/a"))
     if ffn:
-        print("  ffn_fused_kernel: %d launches, mean %8.1f us  (min %8.1f, max %8.1f)" % (len(ffn), sum(ffn) / len(ffn), min(ffn), max(ffn)))
+        print("  ffn_fused_kernel<0> (FeedForward): %d launches, mean %8.1f us  (min %8.1f, max %8.1f)" % (len(ffn), sum(ffn) / len(ffn), min(ffn), max(ffn)))
+    if outp:
+        print("  ffn_fused_kernel<1> (out projection + LayerNorm2): %d launches, mean %8.1f us  (min %8.1f, max %8.1f)" % (len(outp), sum(outp) / len(outp), min(outp), max(outp)))
     for (i, inst), v in sorted(acc.items()):
         label = order[i] if order else ""
         print("  launch %2d  gemm_split_ps_kernel<%s>  mean %8.1f us  (min %8.1f, max %8.1f)  %s" % (i, inst, sum(v) / len(v), min(v), max(v), label))

@@ -125,6 +125,10 @@ __device__ __forceinline__ void static_for(F&& f) {
   }
 }
 
+// MODE 0: the FeedForward block.  MODE 1: the attention out projection + residual (+ LayerNorm2 epilogue) on the same skeleton: ONE
+// GEMM x <- x + a W^T + b with the [128 x 576] result in registers, 18 k-slices x 3 column thirds = 54 positions per panel, the
+// activation slice of a k-slice rides with its first third (always ring slot 0) and its fragments are held across the thirds.
+template <int MODE>
 __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs g) {
   __shared__ __attribute__((aligned(16))) char smem[kLds];
   const int tid = threadIdx.x;
@@ -147,7 +151,8 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs g) {
   // the HBM bandwidth (~10 B/clk/CU: 42 us per panel, measured).  The phases are per XCD (b & 7): the 32 workgroups of an XCD
   // stay in step, because they stream the same weight stages through their shared L2 at the same time.
   for (int i = g.stagger * (b & 7); i > 0; --i) __builtin_amdgcn_s_sleep(32);   // ~1 us per unit
-  for (int i = tid; i < FH; i += 512) ((float*)(smem + kB1Off))[i] = g.b1[i];
+  if (MODE == 0)
+    for (int i = tid; i < FH; i += 512) ((float*)(smem + kB1Off))[i] = g.b1[i];
   for (int i = tid; i < kDim; i += 512) ((float*)(smem + kB2Off))[i] = g.b2[i];
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   wg_barrier();
@@ -173,13 +178,22 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs g) {
     glds16(g.w2 + (size_t)t * ((size_t)FC * kRow2) + slice * 128 + (size_t)k * 64 * kRow2, voff2, dst + k * 8 * 1024);
   };
 
+  // MODE 1, instruction k of position (ks, t): t == 0: the activation slice (k = 0, 1; ring slot 0) + the weight third (2..4);
+  // t > 0: the weight third (k = 0..2).  The weight rows have K = 576 (row pitch kRow1).
+  auto issue_out = [&](const char* a_panel, int ks, int t, int slot, int k) {
+    const int kw = t == 0 ? k - 2 : k;
+    if (t == 0 && k < 2) glds16(a_panel + ks * 128 + k * 64 * kRow1, voff1, lds0 + w * 1024 + k * 8 * 1024);
+    else if (kw >= 0 && kw < 3)
+      glds16(g.w2 + (size_t)t * ((size_t)FC * kRow1) + ks * 128 + kw * 64 * kRow1, voff1, lds0 + slot * kSlot + kAB + w * 1024 + kw * 8 * 1024);
+  };
+
   // ---- MFMA side ---------------------------------------------------------------------------------------------------------
   // block i = 0..5 of a wave = weight rows (i >> 1) * 64 + wn * 32 + (i & 1) * 16 of the stage; row group m = 0, 1
   const int fr = lane & 15, fq = lane >> 4;
   const int frag_off = fr * 128 + ((fq ^ ((fr >> 1) & 7)) << 4);
   const int a_off = (wm * 32) * 128 + frag_off;            // + m * 2048
   const int w_off = kAB + (wn * 32) * 128 + frag_off;      // + (i >> 1) * 8192 + (i & 1) * 2048
-  const int sc1 = (127 - kMixActExp - __builtin_amdgcn_readfirstlane(*g.exp1)) * 0x01010101;
+  const int sc1 = MODE == 0 ? (127 - kMixActExp - __builtin_amdgcn_readfirstlane(*g.exp1)) * 0x01010101 : 0;
   const int sc2 = (127 - kMixActExp - __builtin_amdgcn_readfirstlane(*g.exp2)) * 0x01010101;
 
 
@@ -334,9 +348,13 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs g) {
   // {fp16, e4m3} x column third 0..2).  Position P lives in ring slot P % 3 (36 is a multiple of 3: every LDS address is a
   // compile-time constant).  The stage two positions on is issued during interval P, into the slot position P - 1 used.
 #pragma unroll
-  for (int k = 0; k < 5; ++k) issue_fc1(panel_base(0), 0, 0, 0, k);
+  for (int k = 0; k < 5; ++k) {
+    if (MODE == 0) issue_fc1(panel_base(0), 0, 0, 0, k); else issue_out(panel_base(0), 0, 0, 0, k);
+  }
 #pragma unroll
-  for (int k = 0; k < 5; ++k) issue_fc1(panel_base(0), 0, 1, 1, k);
+  for (int k = 0; k < 5; ++k) {
+    if (MODE == 0) issue_fc1(panel_base(0), 0, 1, 1, k); else issue_out(panel_base(0), 0, 1, 1, k);
+  }
   int skip = 0;                       // intervals whose stage is known to have landed (behind a full drain)
 
   for (int it = 0; it < my_panels; ++it) {
@@ -350,6 +368,33 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs g) {
 #pragma unroll
         for (int m = 0; m < 2; ++m) acc2[t][i][m] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    if constexpr (MODE == 1) {
+      const bool stream_ends = it == my_panels - 1;
+      const char* a_next = panel_base(it + 1);          // (not dereferenced when the stream ends)
+      i32x4 fa0[2], fa1[2];
+      static_for<0, 54>([&](auto p_tag) {
+        constexpr int P = decltype(p_tag)::value, KS = P / 3, T = P % 3;
+        STAMP(t0);
+        if (skip > 0) --skip;
+        else if (P == 53) {
+          if (stream_ends) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        } else if ((P + 1) % 3 == 0) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        STAMP(t1);
+        wg_barrier();
+        STAMP(t2);
+        ACC(s_wait, t1, t0); ACC(s_bar, t2, t1);
+        auto dma = [&](int k) {
+          constexpr int P2 = P + 2;
+          if constexpr (P2 < 54) issue_out(a_panel, P2 / 3, P2 % 3, P2 % 3, k);
+          else if (!stream_ends) issue_out(a_next, (P2 - 54) / 3, (P2 - 54) % 3, (P2 - 54) % 3, k);
+        };
+        stage(Tag<KS & 1>(), Tag<0>(), Tag<T * kSlot>(), acc2[T], sc2, dma, Tag<(T > 0)>(), fa0, fa1, [](int) {}, [](int) {});
+        STAMP(t0);
+        ACC(s_cmp, t0, t2);
+      });
+    } else
     for (int c = 0; c < kChunks; ++c) {
       const bool stream_ends = it == my_panels - 1 && c == kChunks - 1;   // no stage behind this chunk
       const int c_next = c == kChunks - 1 ? 0 : c + 1;
@@ -597,8 +642,10 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs g) {
 
 int ffn_panel_rows() { return FR; }
 
-hipError_t launch_ffn_fused(FfnArgs g, hipStream_t s) {
-  if (g.M <= 0 || !g.a || !g.w1 || !g.w2 || !g.b1 || !g.b2 || !g.resid || !g.out || !g.exp1 || !g.exp2) return hipErrorInvalidValue;
+namespace {
+hipError_t launch_panel(FfnArgs g, int mode, hipStream_t s) {
+  if (g.M <= 0 || !g.a || !g.w2 || !g.b2 || !g.resid || !g.out || !g.exp2) return hipErrorInvalidValue;
+  if (mode == 0 && (!g.w1 || !g.b1 || !g.exp1)) return hipErrorInvalidValue;
   static int num_cu = 0;
   if (num_cu == 0) {
     int dev = 0;
@@ -611,7 +658,8 @@ hipError_t launch_ffn_fused(FfnArgs g, hipStream_t s) {
   static const int stagger = getenv("VETO_FFN_STAGGER") ? atoi(getenv("VETO_FFN_STAGGER")) : 0;   // A/B knob (speed only)
   g.stagger = stagger;
   const int nblocks = g.n_panels < num_cu ? g.n_panels : num_cu;   // one persistent workgroup per CU (LDS: 159 KiB each)
-  VETO_LAUNCH(ffn_fused_kernel, dim3(nblocks), dim3(512), 0, s, g);
+  if (mode == 0) VETO_LAUNCH(ffn_fused_kernel<0>, dim3(nblocks), dim3(512), 0, s, g);
+  else VETO_LAUNCH(ffn_fused_kernel<1>, dim3(nblocks), dim3(512), 0, s, g);
   hipError_t rc = hipGetLastError();
 #ifdef VETO_FFN_STAMPS
   {
@@ -651,5 +699,12 @@ hipError_t launch_ffn_fused(FfnArgs g, hipStream_t s) {
 #endif
   return rc;
 }
+
+}  // namespace
+
+hipError_t launch_ffn_fused(FfnArgs g, hipStream_t s) { return launch_panel(g, 0, s); }
+// x <- x + a W^T + b (attention out projection + residual) with optional LayerNorm rows; w2 = W [576, 4*576 B] mixed rows,
+// exp2 its exponent, b2 the bias; w1 / b1 / exp1 unused
+hipError_t launch_out_fused(FfnArgs g, hipStream_t s) { return launch_panel(g, 1, s); }
 
 }  // namespace veto

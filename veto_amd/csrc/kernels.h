@@ -72,6 +72,8 @@ struct FfnArgs {
 };
 int ffn_panel_rows();
 hipError_t launch_ffn_fused(FfnArgs g, hipStream_t s);
+// the same skeleton as ONE GEMM: out = resid + a . w2^T + b2 (K = 576: the attention out projection + residual), optional LayerNorm rows
+hipError_t launch_out_fused(FfnArgs g, hipStream_t s);
 
 // ---- weight preparation (once per weight upload) ---------------------------------------------
 // src [rows, K] fp32 -> dst [rows, 2K] split rows

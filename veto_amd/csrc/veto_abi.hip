@@ -505,6 +505,8 @@ int veto_forward(veto_handle_t h, void* stream, const veto_inputs_t* in, void* w
   const bool mixed_out = mixed && attention_reads_tables(H);
   static const bool ffn_off = getenv("VETO_FFN_FUSED") && !strcmp(getenv("VETO_FFN_FUSED"), "0");          // A/B knob
   const bool ffn_fused = !ffn_off;   // VETO_MIXED: fc1 -> GELU -> fc2 + residual as one launch
+  static const bool out_off = getenv("VETO_OUT_FUSED") && !strcmp(getenv("VETO_OUT_FUSED"), "0");           // A/B knob
+  const bool out_fused = !out_off;   // VETO_MIXED: out projection + residual + LayerNorm2 as one launch on full rows
   static const bool ffn_ln_off = getenv("VETO_FFN_LN") && !strcmp(getenv("VETO_FFN_LN"), "0");              // A/B knob
   if (qkv0_tables) {
     const int R = n_obj * 16;
@@ -598,12 +600,22 @@ int veto_forward(veto_handle_t h, void* stream, const veto_inputs_t* in, void* w
         HIP_TRY(launch_attention(a, s));
       }
       if (!last) {
-        rc = run_gemm(h, s, "gemm_out", ws.a, mixed_out ? w.out_m : w.out, w.out_b, ws.x, kDim, ws.x, nullptr, kDim, M, kDim, kDim, EPI_RESID,
-                      0, 0, DropSite(), mixed_out ? w.exp_m + 1 : nullptr);
-        if (rc) return rc;
-        {
-          ProfScope ps(h, s, "layernorm", 0, (double)M * kDim * 8);
-          HIP_TRY(launch_layernorm(ws.x, kDim, w.ln2_w, w.ln2_b, ws.a, M, s, mixed ? FMT_MIXED : FMT_SPLIT));
+        if (mixed_out && out_fused) {
+          // out projection + residual + LayerNorm2 in one launch on full rows (ffn_fused.hip, MODE 1): x <- x + a Wo^T + bo, then
+          // a <- LayerNorm2(x) as mixed rows in place over the attention output
+          FfnArgs f{};
+          f.a = (const char*)ws.a; f.w2 = (const char*)w.out_m; f.b2 = w.out_b; f.resid = ws.x; f.out = ws.x; f.ldr = kDim; f.ldo = kDim;
+          f.M = M; f.exp2 = w.exp_m + 1; f.ln_w = w.ln2_w; f.ln_b = w.ln2_b; f.ln_out = (char*)ws.a;
+          ProfScope ps(h, s, "out_ln_fused", 2.0 * M * (double)kDim * kDim, (double)M * kDim * 16 + (double)kDim * kDim * 4);
+          HIP_TRY(launch_out_fused(f, s));
+        } else {
+          rc = run_gemm(h, s, "gemm_out", ws.a, mixed_out ? w.out_m : w.out, w.out_b, ws.x, kDim, ws.x, nullptr, kDim, M, kDim, kDim, EPI_RESID,
+                        0, 0, DropSite(), mixed_out ? w.exp_m + 1 : nullptr);
+          if (rc) return rc;
+          {
+            ProfScope ps(h, s, "layernorm", 0, (double)M * kDim * 8);
+            HIP_TRY(launch_layernorm(ws.x, kDim, w.ln2_w, w.ln2_b, ws.a, M, s, mixed ? FMT_MIXED : FMT_SPLIT));
+          }
         }
         // ... and the LayerNorm in front of the next layer's QKV GEMM in its epilogue, when that GEMM takes mixed rows
         const bool ffn_ln_next = mixed && ffn_fused && !ffn_ln_off && l + 1 < L - 1;
@@ -1499,6 +1511,68 @@ int veto_debug_ffn(void* stream, const float* a, const float* w1, const float* b
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
     *ms_per_rep = ms / reps;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+  }
+  return VETO_OK;
+}
+
+// Test / measurement hook of the attention out projection + residual (model_veto.py:96 `to_out`, :20) on VETO_MIXED operands:
+// x <- x + a W^T + b for m token rows, optionally followed by LayerNorm rows (the FeedForward PreNorm, :125-132).  mode 0 = the GEMM
+// launch with the residual epilogue (+ a LayerNorm launch), mode 1 = the full-row panel kernel (ffn_fused.hip, MODE 1).
+size_t veto_debug_outproj_workspace_bytes(int32_t m) {
+  if (m <= 0) return 0;
+  const size_t mp = (size_t)gemm_rows_padded(m);
+  return align_up(mp * kDim * 4, 256) + align_up((size_t)kDim * kDim * 4, 256) + 256;
+}
+
+int veto_debug_outproj(void* stream, const float* a, const float* w, const float* b, float* x, int32_t m, int32_t mode, int32_t flags,
+                       int32_t reps, float* ms_per_rep, void* workspace, size_t workspace_bytes, const float* ln_w, const float* ln_b,
+                       void* ln_rows) {
+  if (!a || !w || !b || !x || !workspace) return fail(VETO_ERR_INVALID, "null argument");
+  if (m <= 0 || reps <= 0 || (mode != 0 && mode != 1)) return fail(VETO_ERR_INVALID, "bad m / reps / mode");
+  if (ln_rows && (!ln_w || !ln_b)) return fail(VETO_ERR_INVALID, "ln_rows needs ln_w and ln_b");
+  if (workspace_bytes < veto_debug_outproj_workspace_bytes(m)) return fail(VETO_ERR_WORKSPACE, "workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  const size_t mp = (size_t)gemm_rows_padded(m);
+  char* base = (char*)workspace;
+  __bf16* a_m = (__bf16*)base;
+  __bf16* w_m = (__bf16*)(base + align_up(mp * kDim * 4, 256));
+  int* exps = (int*)((char*)w_m + align_up((size_t)kDim * kDim * 4, 256));
+  if (flags & 1) HIP_TRY(launch_mixed_weight_rows(w, w_m, (size_t)kDim, kDim, exps, s));
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (ms_per_rep) {
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+  }
+  float total = 0.f;
+  for (int r = 0; r < reps; ++r) {
+    // the fused form writes its LayerNorm rows over its input rows: rebuild them for every run (outside the timed span)
+    HIP_TRY(hipMemsetAsync(a_m, 0, mp * kDim * 4, s));
+    HIP_TRY(launch_mixed_act_rows(a, a_m, (size_t)m, kDim, s));
+    if (ms_per_rep) HIP_TRY(hipEventRecord(e0, s));
+    if (mode == 1) {
+      FfnArgs f{};
+      f.a = (const char*)a_m; f.w2 = (const char*)w_m; f.b2 = b; f.resid = x; f.out = x; f.ldr = kDim; f.ldo = kDim; f.M = m; f.exp2 = exps;
+      if (ln_rows) { f.ln_w = ln_w; f.ln_b = ln_b; f.ln_out = (char*)ln_rows; }
+      HIP_TRY(launch_out_fused(f, s));
+    } else {
+      GemmArgs g{};
+      g.fmt = FMT_MIXED; g.w_exp = exps; g.a = a_m; g.w = w_m; g.bias = b; g.resid = x; g.c = x;
+      g.M = m; g.N = kDim; g.K = kDim; g.ldr = kDim; g.ldc = kDim;
+      HIP_TRY(launch_gemm_split(g, EPI_RESID, 0, s));
+      if (ln_rows) HIP_TRY(launch_layernorm(x, kDim, ln_w, ln_b, (__bf16*)ln_rows, m, s, FMT_MIXED));
+    }
+    if (ms_per_rep) {
+      HIP_TRY(hipEventRecord(e1, s));
+      HIP_TRY(hipEventSynchronize(e1));
+      float ms = 0.f;
+      HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+      total += ms;
+    }
+  }
+  if (ms_per_rep) {
+    *ms_per_rep = total / reps;
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
   }
