@@ -103,6 +103,7 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 // contiguous eighth of the items, so that an image's table rows meet in one L2, measured neutral.)
 template <int DH, bool TAB = false>
 __global__ __launch_bounds__(128) void attention_mfma_kernel(AttnArgs a) {
+  saturating_conversions_on();   // (the mixed-row output path converts without clamps, common.h)
   constexpr int DHP = (DH + 15) / 16 * 16;  // contraction extent of QK^T (zero padded)
   constexpr int RB = DHP * 2;               // bytes per row of the Q / K images (bf16)
   constexpr int NT = (DH + 31) / 32;        // 32-wide output tiles of PV

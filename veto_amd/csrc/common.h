@@ -62,7 +62,8 @@ __device__ __forceinline__ void split_bf16(float x, __bf16& hi, __bf16& lo) {
 // (The K = 128 MFMA sums the products of corresponding bytes of the two operands' 128-byte stage rows, so ANY byte order that
 // activation and weight rows share is right; this one lets a producer that owns 4 consecutive columns write its X and Y
 // bytes as ONE 8-byte store and one that owns 8 columns as one 16-byte store.)
-// e4m3 conversions do NOT saturate on gfx950 (480 -> NaN, profiles/r02_mfma_mix_probe.txt): values are clamped to +-448.
+// e4m3 conversions do NOT saturate on gfx950 by default (480 -> NaN, profiles/r02_mfma_mix_probe.txt); they do with
+// MODE.FP16_OVFL = 1 (saturating_conversions_on() below), which every producer of mixed rows sets.
 // One GEMM stage (128 B of a row) is either the h part or the X|Y part of a block: same addressing as the split rows.
 enum OperandFmt { FMT_SPLIT = 0, FMT_MIXED = 1 };
 #ifndef VETO_MIX_ACT_HI_EXP
@@ -73,7 +74,26 @@ constexpr int kMixActExp = kMixActHiExp + 11;
 constexpr int kMixWLoShift = kMixActExp - kMixActHiExp;   // weight residual scale = weight value scale x 2^11
 typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
 
-__device__ __forceinline__ float clamp448(float x) { return __builtin_amdgcn_fmed3f(x, -448.f, 448.f); }
+// Saturating conversions (round 3, tools/micro/ovfl_probe.hip): with MODE.FP16_OVFL = 1 the f32 -> e4m3 conversions saturate at
+// +-448 (0x7e) instead of producing NaN, and f32 -> f16 saturates at +-65504 instead of Inf (measured on gfx950 for
+// v_cvt_scalef32_pk_fp8_f32, v_cvt_pk_fp8_f32 and v_cvt_f16_f32; a NaN stays a NaN).  Every kernel that writes mixed rows sets the
+// bit on entry (the mode is per wave), and the v_med3_f32 clamps in front of every conversion -- 8 of ~22 instructions per 4
+// values in the VALU-bound producers -- are gone.  -DVETO_FP16_OVFL=0 rebuilds the clamped form.
+#ifndef VETO_FP16_OVFL
+#define VETO_FP16_OVFL 1
+#endif
+__device__ __forceinline__ void saturating_conversions_on() {
+#if VETO_FP16_OVFL
+  __builtin_amdgcn_s_setreg(1 /* HW_REG_MODE */ | (23 << 6) /* bit 23: FP16_OVFL */ | ((1 - 1) << 11), 1);
+#endif
+}
+__device__ __forceinline__ float clamp448(float x) {
+#if VETO_FP16_OVFL
+  return x;
+#else
+  return __builtin_amdgcn_fmed3f(x, -448.f, 448.f);
+#endif
+}
 __device__ __forceinline__ uint32_t pack_e4m3x4(float a, float b, float c, float d) {
   int r = __builtin_amdgcn_cvt_pk_fp8_f32(clamp448(a), clamp448(b), 0, false);
   r = __builtin_amdgcn_cvt_pk_fp8_f32(clamp448(c), clamp448(d), r, true);
@@ -86,8 +106,14 @@ __device__ __forceinline__ uint32_t pack_e4m3x4_scaled(float a, float b, float c
   typedef short v2s __attribute__((ext_vector_type(2)));
   constexpr float lim = 448.f / (float)(1 << EXP), inv = 1.f / (float)(1 << EXP);
   v2s r = {0, 0};
+#if VETO_FP16_OVFL
+  (void)lim;
+  r = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(r, a, b, inv, false);
+  r = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(r, c, d, inv, true);
+#else
   r = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(r, __builtin_amdgcn_fmed3f(a, -lim, lim), __builtin_amdgcn_fmed3f(b, -lim, lim), inv, false);
   r = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(r, __builtin_amdgcn_fmed3f(c, -lim, lim), __builtin_amdgcn_fmed3f(d, -lim, lim), inv, true);
+#endif
   return __builtin_bit_cast(uint32_t, r);
 }
 // byte offset of column k's fp16 inside a mixed row; its X byte is at mixed_x_offset(k), its Y byte 4 further

@@ -130,6 +130,7 @@ __device__ __forceinline__ void static_for(F&& f) {
 // activation slice of a k-slice rides with its first third (always ring slot 0) and its fragments are held across the thirds.
 template <int MODE>
 __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs g) {
+  saturating_conversions_on();   // (the hidden and LayerNorm conversions to mixed rows carry no clamps, common.h)
   __shared__ __attribute__((aligned(16))) char smem[kLds];
   const int tid = threadIdx.x;
   const int lane = tid & 63;

@@ -39,6 +39,7 @@ __global__ void split_rows_kernel(const float* __restrict__ src, __bf16* __restr
 
 // fp32 [rows, K] -> mixed ACTIVATION rows (common.h); test hook of the mixed GEMM
 __global__ void mixed_act_rows_kernel(const float* __restrict__ src, __bf16* __restrict__ dst, size_t n, int K) {
+  saturating_conversions_on();
   for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += (size_t)gridDim.x * blockDim.x * 4) {
     const size_t row = i / K;
     store_act4<FMT_MIXED>(dst + row * (2 * (size_t)K), (int)(i % K), *(const f32x4*)(src + i));
@@ -66,6 +67,7 @@ __device__ __forceinline__ int weight_exp_of(unsigned maxbits) {
 // Pass 2: 4 consecutive k's per thread: h = fp16(w) (8 B), { X = e4m3(2^e h), Y = e4m3(2^(e+11) (w - h)) } (8 B)
 __global__ void mixed_weight_rows_kernel(const float* __restrict__ src, __bf16* __restrict__ dst, size_t n, int K,
                                          const int* __restrict__ maxbits) {
+  saturating_conversions_on();
   const int e = weight_exp_of((unsigned)*maxbits);
   const float sx = ldexpf(1.f, e), sy = ldexpf(1.f, e + kMixWLoShift);
   for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += (size_t)gridDim.x * blockDim.x * 4) {
@@ -606,6 +608,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
                                                         const float* __restrict__ w,
                                                         const float* __restrict__ b,
                                                         __bf16* __restrict__ dst, int rows, long ldd) {
+  saturating_conversions_on();
   const int row = blockIdx.x * 16 + (threadIdx.x >> 4);
   if (row >= rows) return;
   const int q = threadIdx.x & 15;
