@@ -238,9 +238,10 @@ def main():
                         tflops=(v["flops_per_launch"] / (v["total_ms"] / v["launches"] * 1e-3) / 1e12)
                         if v["flops_per_launch"] else None)
                 for k, v in prof.items()}
-        gemms = {k: v for k, v in kern.items() if k.startswith("gemm_") or k in ("ffn_fused", "out_ln_fused")}
-        # the dominant kernel = the matrix launch with the longest duration (round 3: the fused FeedForward launch, fc1 -> GELU ->
-        # fc2 + residual of a full layer; before that the QKV projection); `gemm_all` below is the rate over all matrix launches
+        gemms = {k: v for k, v in kern.items() if k.startswith("gemm_") or k in ("ffn_fused", "out_ln_fused", "layer_tail_fused")}
+        # the dominant kernel = the matrix launch with the longest duration (round 3: the layer-tail launch -- out projection +
+        # residual + LayerNorm2 + FeedForward + residual + next LayerNorm1 of a full layer, 953 GF; before that the QKV projection);
+        # `gemm_all` below is the rate over all matrix launches
         dom = max(gemms, key=lambda k: gemms[k]["avg_ms"])
         achieved = gemms[dom]["tflops"]
         gemm_ms = sum(v["ms_per_step"] for v in gemms.values())

@@ -315,6 +315,16 @@ int veto_debug_outproj(void* stream, const float* a, const float* w, const float
                        const float* ln_w, const float* ln_b, void* ln_rows);
 size_t veto_debug_outproj_workspace_bytes(int32_t m);
 
+/* ---- test / measurement hook: everything of one layer behind its attention (model_veto.py:96, :20-21, :125-143) on VETO_MIXED
+ * operands: x1 = x + a Wo^T + bo, h = LayerNorm(x1; ln2_w, ln2_b), x = x1 + W2 gelu(W1 h + b1) + b2, and optionally ln_rows =
+ * LayerNorm(x; ln_w, ln_b) as mixed activation rows (m x 2304 bytes).  mode 0 = the out-projection panel launch + the FeedForward
+ * panel launch, mode 1 = one launch.  a [m, 576] (attention output), wo [576, 576], w1 [1152, 576], w2 [576, 1152], x in / out. */
+int veto_debug_layer_tail(void* stream, const float* a, const float* wo, const float* bo, const float* ln2_w, const float* ln2_b,
+                          const float* w1, const float* b1, const float* w2, const float* b2, float* x, int32_t m, int32_t mode,
+                          int32_t reps, float* ms_per_rep, void* workspace, size_t workspace_bytes, const float* ln_w,
+                          const float* ln_b, void* ln_rows);
+size_t veto_debug_layer_tail_workspace_bytes(int32_t m);
+
 /* ---- training losses and MEET expert sampling (partial) -------------------------
  * veto_ce_loss: nn.CrossEntropyLoss(weight)(logits[rows], labels), mean reduction -- the relation loss of
  * VETOPredictor.forward (roi_relation_predictors.py:4133, BETA_LOSS weights :4057-4068) and, on a row subset with

@@ -220,6 +220,50 @@ def test_fused_out_projection_residual_layernorm(m):
     assert (planes[0] - planes[1]).abs().max().item() < 2e-4
 
 
+@pytest.mark.parametrize("m", [1, 129, 5000, 40000])
+def test_fused_layer_tail(m):
+    """Everything of a layer behind its attention in one launch (ffn_fused.hip MODE 2: out projection + residual + LayerNorm2 +
+    FeedForward + residual + the next LayerNorm; model_veto.py:96, :20-21, :125-143) against fp64 and against the two panel launches
+    it replaces.  The LayerNorm2 rows are written and re-read by the same CU within the launch (L1 invalidate in between): 40 000
+    rows = more panels than CUs, so every workgroup goes through that hand-off several times."""
+    from veto_amd import native
+    lib = native.load_library()
+    dev = _dev()
+    g = torch.Generator(device="cpu").manual_seed(m + 11)
+    a = torch.randn(m, 576, generator=g).to(dev)
+    x0 = (torch.randn(m, 576, generator=g) + 0.3).to(dev)
+    wo = (torch.randn(576, 576, generator=g) * 0.05).to(dev)
+    bo = (torch.randn(576, generator=g) * 0.1).to(dev)
+    l2w = (1.0 + 0.3 * torch.randn(576, generator=g)).to(dev)
+    l2b = (0.2 * torch.randn(576, generator=g)).to(dev)
+    w1 = (torch.randn(1152, 576, generator=g) * 0.04).to(dev)
+    b1 = (torch.randn(1152, generator=g) * 0.1).to(dev)
+    w2 = (torch.randn(576, 1152, generator=g) * 0.03).to(dev)
+    b2 = (torch.randn(576, generator=g) * 0.1).to(dev)
+    lw = (1.0 + 0.3 * torch.randn(576, generator=g)).to(dev)
+    lb = (0.2 * torch.randn(576, generator=g)).to(dev)
+    x1 = x0.double() + a.double() @ wo.double().t() + bo.double()
+    hin = torch.nn.functional.layer_norm(x1, (576,), l2w.double(), l2b.double(), 1e-5)
+    ref = x1 + torch.nn.functional.gelu(hin @ w1.double().t() + b1.double()) @ w2.double().t() + b2.double()
+    ws = torch.empty(lib.veto_debug_layer_tail_workspace_bytes(m), dtype=torch.uint8, device=dev)
+    xs, planes = [], []
+    for mode in (0, 1):
+        x = x0.clone()
+        rows = torch.zeros(m, 4 * 576, dtype=torch.uint8, device=dev)
+        native.check(lib.veto_debug_layer_tail(None, a.data_ptr(), wo.data_ptr(), bo.data_ptr(), l2w.data_ptr(), l2b.data_ptr(), w1.data_ptr(),
+                                               b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), x.data_ptr(), m, mode, 1, None, ws.data_ptr(),
+                                               ws.numel(), lw.data_ptr(), lb.data_ptr(), rows.data_ptr()))
+        torch.cuda.synchronize()
+        assert torch.isfinite(x).all()
+        err = (x.double() - ref).abs().max().item()
+        assert err < 3e-4, (m, mode, err)
+        lnref = torch.nn.functional.layer_norm(x.double(), (576,), lw.double(), lb.double(), 1e-5)
+        h, hx, y = _decode_mixed_rows(rows, 576)
+        assert ((hx - lnref).abs() / lnref.abs().clamp_min(0.05)).max().item() < 2.0 ** -14, mode
+        xs.append(x)
+    assert (xs[0] - xs[1]).abs().max().item() < 3e-4
+
+
 @pytest.mark.parametrize("n", [1, 2, 3, 10, 36, 50])
 def test_enumerate_pairs_bit_exact(n):
     from veto_amd.pairs import prepare_test_pairs

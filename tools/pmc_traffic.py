@@ -58,7 +58,7 @@ def per_label(steps):
                 label = name.replace("void ", "").replace("veto::", "").replace("(anonymous namespace)::", "")
                 label = re.split(r"[<(]", label)[0].strip() or name[:40]
                 if label == "ffn_fused_kernel":  # the names bench.py's per-kernel timers use: MODE 0 FeedForward, MODE 1 out projection
-                    label = "out_ln_fused" if re.search(r"ffn_fused_kernel<1>", name) else "ffn_fused"
+                    label = {"0": "ffn_fused", "1": "out_ln_fused", "2": "layer_tail_fused"}[re.search(r"ffn_fused_kernel<(\d)>", name).group(1)]
                 if "attention_mfma_kernel" in name:          # the table form of layer 0 is its own instantiation
                     label += "_tab" if re.search(r"attention_mfma_kernel<\d+, *(true|1)", name) else ""
             acc[label].append((v, us))

@@ -19,7 +19,7 @@ ORDER_L4 = ["gemm_patch", "gemm_qkv0_tab (S)", "gemm_qkv0_tab (O)", "gemm_qkv0_l
 def main(path):
     rows = list(csv.DictReader(open(path)))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    steps, cur, ffn, outp = [], None, [], []
+    steps, cur, ffn, outp, tail = [], None, [], [], []
     for r in rows:
         name = r["Kernel_Name"]
         if "pair_indices_kernel" in name:
@@ -32,6 +32,8 @@ def main(path):
             ffn.append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
         elif cur is not None and "ffn_fused_kernel<1>" in name:
             outp.append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+        elif cur is not None and "ffn_fused_kernel<2>" in name:
+            tail.append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
     n = max(len(s) for s in steps)
     steps = [s for s in steps if len(s) == n]
     acc = defaultdict(list)
@@ -42,6 +44,8 @@ def main(path):
     print("%d forward steps, %d GEMM launches each (4-layer order: %s)" % (len(steps), n, "yes" if order else "n/a"))
     if ffn:
         print("  ffn_fused_kernel<0> (FeedForward): %d launches, mean %8.1f us  (min %8.1f, max %8.1f)" % (len(ffn), sum(ffn) / len(ffn), min(ffn), max(ffn)))
+    if tail:
+        print("  ffn_fused_kernel<2> (layer tail: out projection + LayerNorm2 + FeedForward + LayerNorm1): %d launches, mean %8.1f us  (min %8.1f, max %8.1f)" % (len(tail), sum(tail) / len(tail), min(tail), max(tail)))
     if outp:
         print("  ffn_fused_kernel<1> (out projection + LayerNorm2): %d launches, mean %8.1f us  (min %8.1f, max %8.1f)" % (len(outp), sum(outp) / len(outp), min(outp), max(outp)))
     for (i, inst), v in sorted(acc.items()):

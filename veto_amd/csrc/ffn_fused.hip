@@ -108,7 +108,7 @@ __device__ __forceinline__ unsigned long long stamp() {
 // timeline of one chunk (workgroup 0, first panel, chunk 2; waves 0 and 4): [wave][position][top, waited, barrier, group 0..5]
 __device__ unsigned long long g_ffn_timeline[2 * 36 * 9];
 __device__ unsigned long long g_ffn_epi[2 * 12];
-#define EP(k) do { if (b == 0 && it == 1 && (w & 3) == 0) g_ffn_epi[(w >> 2) * 12 + (k)] = stamp(); } while (0)
+#define EP(k) do { if (b == 0 && cur_it == 1 && (w & 3) == 0) g_ffn_epi[(w >> 2) * 12 + (k)] = stamp(); } while (0)
 #define TL(P, k) do { if (b == 0 && it == 0 && c == 2 && (w & 3) == 0) g_ffn_timeline[((w >> 2) * 36 + (P)) * 9 + (k)] = stamp(); } while (0)
 #else
 #define EP(k)
@@ -125,6 +125,9 @@ __device__ __forceinline__ void static_for(F&& f) {
   }
 }
 
+// MODE 2: MODE 1's GEMM and MODE 0's FeedForward back to back on one panel -- everything of a layer behind its attention in one
+// launch: x1 = x + a Wo^T + bo stays in the accumulators, LayerNorm2(x1) is written as the FeedForward's input rows, fc2 accumulates
+// on top of x1 (the residual needs no second read), the final epilogue stores x2 (+ the next layer's LayerNorm1 rows).
 // MODE 0: the FeedForward block.  MODE 1: the attention out projection + residual (+ LayerNorm2 epilogue) on the same skeleton: ONE
 // GEMM x <- x + a W^T + b with the [128 x 576] result in registers, 18 k-slices x 3 column thirds = 54 positions per panel, the
 // activation slice of a k-slice rides with its first third (always ring slot 0) and its fragments are held across the thirds.
@@ -152,7 +155,7 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs g) {
   // the HBM bandwidth (~10 B/clk/CU: 42 us per panel, measured).  The phases are per XCD (b & 7): the 32 workgroups of an XCD
   // stay in step, because they stream the same weight stages through their shared L2 at the same time.
   for (int i = g.stagger * (b & 7); i > 0; --i) __builtin_amdgcn_s_sleep(32);   // ~1 us per unit
-  if (MODE == 0)
+  if (MODE != 1)
     for (int i = tid; i < FH; i += 512) ((float*)(smem + kB1Off))[i] = g.b1[i];
   for (int i = tid; i < kDim; i += 512) ((float*)(smem + kB2Off))[i] = g.b2[i];
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -166,7 +169,10 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs g) {
   const int slot16 = ((lane & 7) ^ ((r16 >> 1) & 7)) << 4;               // source-side swizzle (the LDS side is lane-linear)
   const unsigned voff1 = (unsigned)((w * 8 + rr) * kRow1 + slot16);
   const unsigned voff2 = (unsigned)((w * 8 + rr) * kRow2 + slot16);
+  const char* const w_out = MODE == 2 ? g.wo : g.w2;       // weight rows of the out-projection phase (MODE 1: the only GEMM)
   auto panel_base = [&](int it) { return g.a + (size_t)(b + (size_t)it * G) * ((size_t)FR * kRow1); };
+  // MODE 2: the FeedForward phase of a panel reads the LayerNorm2 rows its out-projection phase wrote (ln_out; normally = a)
+  auto ffn_base = [&](int it) { return (MODE == 2 ? (const char*)g.ln_out : g.a) + (size_t)(b + (size_t)it * G) * ((size_t)FR * kRow1); };
   // instruction k (of 5) of fc1 stage ks of hidden chunk c: 16 KiB of activation rows (k = 0, 1) + 24 KiB of W1 rows (2..4)
   auto issue_fc1 = [&](const char* a_panel, int c, int ks, int slot, int k) {
     const unsigned dst = lds0 + slot * kSlot + w * 1024;
@@ -185,7 +191,7 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs g) {
     const int kw = t == 0 ? k - 2 : k;
     if (t == 0 && k < 2) glds16(a_panel + ks * 128 + k * 64 * kRow1, voff1, lds0 + w * 1024 + k * 8 * 1024);
     else if (kw >= 0 && kw < 3)
-      glds16(g.w2 + (size_t)t * ((size_t)FC * kRow1) + ks * 128 + kw * 64 * kRow1, voff1, lds0 + slot * kSlot + kAB + w * 1024 + kw * 8 * 1024);
+      glds16(w_out + (size_t)t * ((size_t)FC * kRow1) + ks * 128 + kw * 64 * kRow1, voff1, lds0 + slot * kSlot + kAB + w * 1024 + kw * 8 * 1024);
   };
 
   // ---- MFMA side ---------------------------------------------------------------------------------------------------------
@@ -194,7 +200,8 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs g) {
   const int frag_off = fr * 128 + ((fq ^ ((fr >> 1) & 7)) << 4);
   const int a_off = (wm * 32) * 128 + frag_off;            // + m * 2048
   const int w_off = kAB + (wn * 32) * 128 + frag_off;      // + (i >> 1) * 8192 + (i & 1) * 2048
-  const int sc1 = MODE == 0 ? (127 - kMixActExp - __builtin_amdgcn_readfirstlane(*g.exp1)) * 0x01010101 : 0;
+  const int sc1 = MODE != 1 ? (127 - kMixActExp - __builtin_amdgcn_readfirstlane(*g.exp1)) * 0x01010101 : 0;
+  const int sco = MODE == 2 ? (127 - kMixActExp - __builtin_amdgcn_readfirstlane(*g.expo)) * 0x01010101 : 0;
   const int sc2 = (127 - kMixActExp - __builtin_amdgcn_readfirstlane(*g.exp2)) * 0x01010101;
 
 
@@ -358,7 +365,169 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs g) {
   }
   int skip = 0;                       // intervals whose stage is known to have landed (behind a full drain)
 
+  int cur_it = 0; (void)cur_it;
+    // ---- panel epilogue: out = acc + b2 + residual.  The MFMA leaves lane l with row l & 15, 4 consecutive columns of chunk
+    // l >> 4; one ds_bpermute per value (lane 4 r + q takes lane 16 q + r) makes every quad of lanes cover 64 contiguous bytes
+    // of one row (gemm_split_ps.hip).  Every residual read is issued before the first store (one in-order counter per wave).
+  auto epilogue = [&](f32x4 (&acc2)[3][6][2], int panel, auto resid_tag, auto store_tag, auto back_tag, const float* bias_g, const float* lw,
+                      const float* lb) {
+    constexpr bool RESID = decltype(resid_tag)::value != 0;   // add the residual rows g.resid
+    constexpr bool STORE = decltype(store_tag)::value != 0;   // store the fp32 rows to g.out
+    constexpr bool BACK = decltype(back_tag)::value != 0;     // return the accumulators to the MFMA layout (the panel goes on)
+    {
+      int lane_e = lane;
+      asm volatile("" : "+v"(lane_e));
+      const int er = lane_e >> 2, eq = lane_e & 3;
+      const int perm_addr = ((eq << 4) + er) << 2;
+      const int row0 = panel * FR + wm * 32 + er;
+      const int col0 = wn * 32 + eq * 4;                     // + t * 192 + (i >> 1) * 64 + (i & 1) * 16
+      const float* b2l = (const float*)(smem + kB2Off) + col0;
+      // phase A: the lane transposition, in place, three blocks at a time
+#pragma unroll
+      for (int u = 0; u < 12; ++u) {
+        const int m = u / 6, t = (u % 6) >> 1, i0 = (u & 1) * 3;
+        mfma_drain3(acc2[t][i0][m], acc2[t][i0 + 1][m], acc2[t][i0 + 2][m]);
+#pragma unroll
+        for (int i = i0; i < i0 + 3; ++i) {
+          f32x4 tv;
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            tv[e] = __int_as_float(__builtin_amdgcn_ds_bpermute(perm_addr, __float_as_int(acc2[t][i][m][e])));
+          acc2[t][i][m] = tv;
+          asm volatile("" : "+v"(acc2[t][i][m]));    // pins the group here: register-only instructions are not ordered by
+        }                                            // sched_barrier before instruction selection (they carry no chain)
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      EP(1);
+      // phase B: six groups (row group m, column third t) of six blocks; the residuals of groups u + 1 and u + 2 are in flight
+      // while group u is combined (three buffers of 24 registers: the fc1 accumulators and the fragments are dead here: every
+      // round trip to HBM is ~2 us with all 256 CUs in their epilogues at once); sched_barrier keeps the groups apart
+      f32x4 res[3][6];
+      auto load_res = [&](int u, f32x4 (&r)[6]) {
+        int row = row0 + (u / 3) * 16;
+        if (row >= g.M) row = g.M - 1;          // clamp: the value is never stored
+        const float* rp = g.resid + (size_t)row * g.ldr + col0 + (u % 3) * FC;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) r[i] = *(const f32x4*)(rp + (i >> 1) * 64 + (i & 1) * 16);
+      };
+      if constexpr (RESID) {
+        load_res(0, res[0]);
+        load_res(1, res[1]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < 6; ++u) {
+        const int m = u / 3, t = u % 3;
+        if (RESID && u < 4) load_res(u + 2, res[(u + 2) % 3]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+          const f32x4 bias4 = bias_g ? *(const f32x4*)(bias_g + col0 + t * FC + (i >> 1) * 64 + (i & 1) * 16)
+                                     : *(const f32x4*)(b2l + t * FC + (i >> 1) * 64 + (i & 1) * 16);
+          if constexpr (RESID) acc2[t][i][m] = acc2[t][i][m] + res[u % 3][i] + bias4;
+          else acc2[t][i][m] = acc2[t][i][m] + bias4;
+          asm volatile("" : "+v"(acc2[t][i][m]));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      EP(2);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the reads are consumed; the two prefetched stages have landed too)
+      EP(3);
+      if constexpr (STORE)
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        const int row = row0 + m * 16;
+        if (row < g.M) {
+          float* op = g.out + (size_t)row * g.ldo + col0;
+#pragma unroll
+          for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int i = 0; i < 6; ++i) *(f32x4*)(op + t * FC + (i >> 1) * 64 + (i & 1) * 16) = acc2[t][i][m];
+        }
+      }
+      EP(4);
+      if (g.ln_out && lw) {
+        // ---- LayerNorm of the finished rows (model_veto.py:125-132 of the NEXT layer's attention PreNorm) as mixed rows: the
+        // workgroup holds complete rows, so the standalone LayerNorm launch (0.66 GB read + 0.66 GB written) disappears.  A row's
+        // 576 columns sit in the two waves of its row group (wn = 0, 1), 4 lanes x 72 values each: quad reduction by DPP, the two
+        // waves exchange through LDS (the idle activation part of ring slot 2); two passes (mean, then centred squares) like
+        // rowq_stats in rowops.hip.  Both waves add the same two partial sums: identical statistics in either.
+        float* red = (float*)(smem + 2 * kSlot);          // [pass][wave][m][row] floats
+        float mean[2], rstd[2];
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+          float part[2];
+#pragma unroll
+          for (int m = 0; m < 2; ++m) {
+            float p = 0.f;
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+#pragma unroll
+              for (int i = 0; i < 6; ++i) {
+                if (pass == 0) {
+                  p += (acc2[t][i][m][0] + acc2[t][i][m][1]) + (acc2[t][i][m][2] + acc2[t][i][m][3]);
+                } else {
+#pragma unroll
+                  for (int e = 0; e < 4; ++e) { const float d = acc2[t][i][m][e] - mean[m]; p += d * d; }
+                }
+              }
+            p += __shfl_xor(p, 1, 64);
+            p += __shfl_xor(p, 2, 64);
+            part[m] = p;
+            if (eq == 0) red[((pass * 8 + w) * 2 + m) * 16 + er] = p;
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          wg_barrier();
+#pragma unroll
+          for (int m = 0; m < 2; ++m) {
+            const float tot = part[m] + red[((pass * 8 + (w ^ 1)) * 2 + m) * 16 + er];
+            if (pass == 0) mean[m] = tot * (1.f / kDim);
+            else rstd[m] = 1.f / sqrtf(tot * (1.f / kDim) + 1e-5f);
+          }
+          EP(5 + pass);
+        }
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+          for (int i = 0; i < 6; ++i) {
+            const int col = col0 + t * FC + (i >> 1) * 64 + (i & 1) * 16;
+            const f32x4 wv = *(const f32x4*)(lw + col), bv = *(const f32x4*)(lb + col);
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+              const int row = row0 + m * 16;
+              f32x4 y;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) y[e] = (acc2[t][i][m][e] - mean[m]) * rstd[m] * wv[e] + bv[e];
+              if (row < g.M) store_act4<FMT_MIXED>((__bf16*)(g.ln_out + (size_t)row * kRow1), col, y);
+            }
+          }
+        EP(7);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        EP(8);
+      }
+      if constexpr (BACK) {
+        // back to the MFMA layout (lane 16 q + r takes lane 4 r + q): the panel's FeedForward phase accumulates on these rows
+        const int perm_inv = (((lane_e & 15) << 2) + (lane_e >> 4)) << 2;
+#pragma unroll
+        for (int u = 0; u < 12; ++u) {
+          const int m = u / 6, t = (u % 6) >> 1, i0 = (u & 1) * 3;
+#pragma unroll
+          for (int i = i0; i < i0 + 3; ++i) {
+            f32x4 tv;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              tv[e] = __int_as_float(__builtin_amdgcn_ds_bpermute(perm_inv, __float_as_int(acc2[t][i][m][e])));
+            acc2[t][i][m] = tv;
+            asm volatile("" : "+v"(acc2[t][i][m]));
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+  };
+
   for (int it = 0; it < my_panels; ++it) {
+    cur_it = it;
     const int panel = b + it * G;
     const char* a_panel = panel_base(it);
     f32x4 acc2[3][6][2];     // [column third t][block i][row group m]
@@ -369,8 +538,10 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs g) {
 #pragma unroll
         for (int m = 0; m < 2; ++m) acc2[t][i][m] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    if constexpr (MODE == 1) {
-      const bool stream_ends = it == my_panels - 1;
+    if constexpr (MODE != 0) {
+      // ---- out projection: 18 k-slices x 3 column thirds.  MODE 2: nothing is prefetched behind position 53 (the FeedForward
+      // phase streams the LayerNorm2 rows the epilogue below has yet to write)
+      const bool stream_ends = MODE == 2 || it == my_panels - 1;
       const char* a_next = panel_base(it + 1);          // (not dereferenced when the stream ends)
       i32x4 fa0[2], fa1[2];
       static_for<0, 54>([&](auto p_tag) {
@@ -391,15 +562,37 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs g) {
           if constexpr (P2 < 54) issue_out(a_panel, P2 / 3, P2 % 3, P2 % 3, k);
           else if (!stream_ends) issue_out(a_next, (P2 - 54) / 3, (P2 - 54) % 3, (P2 - 54) % 3, k);
         };
-        stage(Tag<KS & 1>(), Tag<0>(), Tag<T * kSlot>(), acc2[T], sc2, dma, Tag<(T > 0)>(), fa0, fa1, [](int) {}, [](int) {});
+        stage(Tag<KS & 1>(), Tag<0>(), Tag<T * kSlot>(), acc2[T], MODE == 2 ? sco : sc2, dma, Tag<(T > 0)>(), fa0, fa1, [](int) {}, [](int) {});
         STAMP(t0);
         ACC(s_cmp, t0, t2);
       });
-    } else
+    }
+    if constexpr (MODE == 2) {
+      // ---- x1 = x + a Wo^T + bo stays in the accumulators (the FeedForward's residual needs no second read: fc2 accumulates on top
+      // of it); LayerNorm2(x1) goes to ln_out as mixed rows.  Those rows are re-read by this CU's DMA right away, through an L1
+      // that may still hold lines of the attention-output rows they replace: stores drained, one L1 invalidate per workgroup.
+      STAMP(t0);
+      epilogue(acc2, panel, Tag<1>(), Tag<0>(), Tag<1>(), g.bo, g.lnm_w, g.lnm_b);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      wg_barrier();
+      if (w == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      wg_barrier();
+#pragma unroll
+      for (int k = 0; k < 5; ++k) issue_fc1(ffn_base(it), 0, 0, 0, k);
+#pragma unroll
+      for (int k = 0; k < 5; ++k) issue_fc1(ffn_base(it), 0, 1, 1, k);
+      skip = 0;
+      STAMP(t1); ACC(s_epi, t1, t0);
+    }
+    if constexpr (MODE != 1)
     for (int c = 0; c < kChunks; ++c) {
       const bool stream_ends = it == my_panels - 1 && c == kChunks - 1;   // no stage behind this chunk
       const int c_next = c == kChunks - 1 ? 0 : c + 1;
-      const char* a_next = c == kChunks - 1 ? panel_base(it + 1) : a_panel;    // (not dereferenced when the stream ends)
+      const char* const f_panel = ffn_base(it);
+      const char* a_next = c == kChunks - 1 ? (MODE == 2 ? panel_base(it + 1) : ffn_base(it + 1)) : f_panel;   // (not dereferenced when the stream ends)
       f32x4 acc1[6][2];        // [block i][row group m]
 #pragma unroll
       for (int i = 0; i < 6; ++i)
@@ -439,12 +632,15 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs g) {
         auto dma = [&](int k) {       // instruction k of this wave's share of the stage two positions on
           constexpr int P2 = P + 2, S2 = P2 % kRing;
           if constexpr (P2 < kS1) {
-            if (k < 5) issue_fc1(a_panel, c, P2, S2, k);
+            if (k < 5) issue_fc1(f_panel, c, P2, S2, k);
           } else if constexpr (P2 < kPer) {
             constexpr int Q2 = P2 - kS1;
             if (k < 3) issue_fc2((c * 3 + Q2 / 6) * 2 + (Q2 % 6) / 3, Q2 % 3, S2, k);
           } else {
-            if (k < 5 && !stream_ends) issue_fc1(a_next, c_next, P2 - kPer, S2, k);
+            if (k < 5 && !stream_ends) {
+              if (MODE == 2 && c == kChunks - 1) issue_out(a_next, 0, P2 - kPer, S2, k);   // the next panel opens with its out projection
+              else issue_fc1(a_next, c_next, P2 - kPer, S2, k);
+            }
           }
         };
         constexpr int SB = (P % kRing) * kSlot;
@@ -495,137 +691,11 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs g) {
       });
     }
 
-    // ---- panel epilogue: out = acc + b2 + residual.  The MFMA leaves lane l with row l & 15, 4 consecutive columns of chunk
-    // l >> 4; one ds_bpermute per value (lane 4 r + q takes lane 16 q + r) makes every quad of lanes cover 64 contiguous bytes
-    // of one row (gemm_split_ps.hip).  Every residual read is issued before the first store (one in-order counter per wave).
     STAMP(t0);
     EP(0);
     if (!(FFN_ABLATE & 16)) {
-      int lane_e = lane;
-      asm volatile("" : "+v"(lane_e));
-      const int er = lane_e >> 2, eq = lane_e & 3;
-      const int perm_addr = ((eq << 4) + er) << 2;
-      const int row0 = panel * FR + wm * 32 + er;
-      const int col0 = wn * 32 + eq * 4;                     // + t * 192 + (i >> 1) * 64 + (i & 1) * 16
-      const float* b2l = (const float*)(smem + kB2Off) + col0;
-      // phase A: the lane transposition, in place, three blocks at a time
-#pragma unroll
-      for (int u = 0; u < 12; ++u) {
-        const int m = u / 6, t = (u % 6) >> 1, i0 = (u & 1) * 3;
-        mfma_drain3(acc2[t][i0][m], acc2[t][i0 + 1][m], acc2[t][i0 + 2][m]);
-#pragma unroll
-        for (int i = i0; i < i0 + 3; ++i) {
-          f32x4 tv;
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            tv[e] = __int_as_float(__builtin_amdgcn_ds_bpermute(perm_addr, __float_as_int(acc2[t][i][m][e])));
-          acc2[t][i][m] = tv;
-          asm volatile("" : "+v"(acc2[t][i][m]));    // pins the group here: register-only instructions are not ordered by
-        }                                            // sched_barrier before instruction selection (they carry no chain)
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      EP(1);
-      // phase B: six groups (row group m, column third t) of six blocks; the residuals of groups u + 1 and u + 2 are in flight
-      // while group u is combined (three buffers of 24 registers: the fc1 accumulators and the fragments are dead here: every
-      // round trip to HBM is ~2 us with all 256 CUs in their epilogues at once); sched_barrier keeps the groups apart
-      f32x4 res[3][6];
-      auto load_res = [&](int u, f32x4 (&r)[6]) {
-        int row = row0 + (u / 3) * 16;
-        if (row >= g.M) row = g.M - 1;          // clamp: the value is never stored
-        const float* rp = g.resid + (size_t)row * g.ldr + col0 + (u % 3) * FC;
-#pragma unroll
-        for (int i = 0; i < 6; ++i) r[i] = *(const f32x4*)(rp + (i >> 1) * 64 + (i & 1) * 16);
-      };
-      load_res(0, res[0]);
-      load_res(1, res[1]);
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int u = 0; u < 6; ++u) {
-        const int m = u / 3, t = u % 3;
-        if (u < 4) load_res(u + 2, res[(u + 2) % 3]);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-          acc2[t][i][m] = acc2[t][i][m] + res[u % 3][i] + *(const f32x4*)(b2l + t * FC + (i >> 1) * 64 + (i & 1) * 16);
-          asm volatile("" : "+v"(acc2[t][i][m]));
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      EP(2);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the reads are consumed; the two prefetched stages have landed too)
-      EP(3);
-#pragma unroll
-      for (int m = 0; m < 2; ++m) {
-        const int row = row0 + m * 16;
-        if (row < g.M) {
-          float* op = g.out + (size_t)row * g.ldo + col0;
-#pragma unroll
-          for (int t = 0; t < 3; ++t)
-#pragma unroll
-            for (int i = 0; i < 6; ++i) *(f32x4*)(op + t * FC + (i >> 1) * 64 + (i & 1) * 16) = acc2[t][i][m];
-        }
-      }
-      EP(4);
-      if (g.ln_out) {
-        // ---- LayerNorm of the finished rows (model_veto.py:125-132 of the NEXT layer's attention PreNorm) as mixed rows: the
-        // workgroup holds complete rows, so the standalone LayerNorm launch (0.66 GB read + 0.66 GB written) disappears.  A row's
-        // 576 columns sit in the two waves of its row group (wn = 0, 1), 4 lanes x 72 values each: quad reduction by DPP, the two
-        // waves exchange through LDS (the idle activation part of ring slot 2); two passes (mean, then centred squares) like
-        // rowq_stats in rowops.hip.  Both waves add the same two partial sums: identical statistics in either.
-        float* red = (float*)(smem + 2 * kSlot);          // [pass][wave][m][row] floats
-        float mean[2], rstd[2];
-#pragma unroll
-        for (int pass = 0; pass < 2; ++pass) {
-          float part[2];
-#pragma unroll
-          for (int m = 0; m < 2; ++m) {
-            float p = 0.f;
-#pragma unroll
-            for (int t = 0; t < 3; ++t)
-#pragma unroll
-              for (int i = 0; i < 6; ++i) {
-                if (pass == 0) {
-                  p += (acc2[t][i][m][0] + acc2[t][i][m][1]) + (acc2[t][i][m][2] + acc2[t][i][m][3]);
-                } else {
-#pragma unroll
-                  for (int e = 0; e < 4; ++e) { const float d = acc2[t][i][m][e] - mean[m]; p += d * d; }
-                }
-              }
-            p += __shfl_xor(p, 1, 64);
-            p += __shfl_xor(p, 2, 64);
-            part[m] = p;
-            if (eq == 0) red[((pass * 8 + w) * 2 + m) * 16 + er] = p;
-          }
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          wg_barrier();
-#pragma unroll
-          for (int m = 0; m < 2; ++m) {
-            const float tot = part[m] + red[((pass * 8 + (w ^ 1)) * 2 + m) * 16 + er];
-            if (pass == 0) mean[m] = tot * (1.f / kDim);
-            else rstd[m] = 1.f / sqrtf(tot * (1.f / kDim) + 1e-5f);
-          }
-          EP(5 + pass);
-        }
-#pragma unroll
-        for (int t = 0; t < 3; ++t)
-#pragma unroll
-          for (int i = 0; i < 6; ++i) {
-            const int col = col0 + t * FC + (i >> 1) * 64 + (i & 1) * 16;
-            const f32x4 wv = *(const f32x4*)(g.ln_w + col), bv = *(const f32x4*)(g.ln_b + col);
-#pragma unroll
-            for (int m = 0; m < 2; ++m) {
-              const int row = row0 + m * 16;
-              f32x4 y;
-#pragma unroll
-              for (int e = 0; e < 4; ++e) y[e] = (acc2[t][i][m][e] - mean[m]) * rstd[m] * wv[e] + bv[e];
-              if (row < g.M) store_act4<FMT_MIXED>((__bf16*)(g.ln_out + (size_t)row * kRow1), col, y);
-            }
-          }
-        EP(7);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        EP(8);
-      }
-      skip = 2;   // stages 0 and 1 of the next panel landed before the drain above
+      epilogue(acc2, panel, Tag<(MODE == 2 ? 0 : 1)>(), Tag<1>(), Tag<0>(), nullptr, g.ln_w, g.ln_b);
+      skip = 2;   // stages 0 and 1 of the next panel landed before the drain inside
     } else {
       asm volatile("" ::"v"(acc2[0][0][0]), "v"(acc2[2][5][1]));
     }
@@ -646,7 +716,8 @@ int ffn_panel_rows() { return FR; }
 namespace {
 hipError_t launch_panel(FfnArgs g, int mode, hipStream_t s) {
   if (g.M <= 0 || !g.a || !g.w2 || !g.b2 || !g.resid || !g.out || !g.exp2) return hipErrorInvalidValue;
-  if (mode == 0 && (!g.w1 || !g.b1 || !g.exp1)) return hipErrorInvalidValue;
+  if (mode != 1 && (!g.w1 || !g.b1 || !g.exp1)) return hipErrorInvalidValue;
+  if (mode == 2 && (!g.wo || !g.bo || !g.expo || !g.lnm_w || !g.lnm_b || !g.ln_out)) return hipErrorInvalidValue;
   static int num_cu = 0;
   if (num_cu == 0) {
     int dev = 0;
@@ -660,7 +731,8 @@ hipError_t launch_panel(FfnArgs g, int mode, hipStream_t s) {
   g.stagger = stagger;
   const int nblocks = g.n_panels < num_cu ? g.n_panels : num_cu;   // one persistent workgroup per CU (LDS: 159 KiB each)
   if (mode == 0) VETO_LAUNCH(ffn_fused_kernel<0>, dim3(nblocks), dim3(512), 0, s, g);
-  else VETO_LAUNCH(ffn_fused_kernel<1>, dim3(nblocks), dim3(512), 0, s, g);
+  else if (mode == 1) VETO_LAUNCH(ffn_fused_kernel<1>, dim3(nblocks), dim3(512), 0, s, g);
+  else VETO_LAUNCH(ffn_fused_kernel<2>, dim3(nblocks), dim3(512), 0, s, g);
   hipError_t rc = hipGetLastError();
 #ifdef VETO_FFN_STAMPS
   {
@@ -707,5 +779,6 @@ hipError_t launch_ffn_fused(FfnArgs g, hipStream_t s) { return launch_panel(g, 0
 // x <- x + a W^T + b (attention out projection + residual) with optional LayerNorm rows; w2 = W [576, 4*576 B] mixed rows,
 // exp2 its exponent, b2 the bias; w1 / b1 / exp1 unused
 hipError_t launch_out_fused(FfnArgs g, hipStream_t s) { return launch_panel(g, 1, s); }
+hipError_t launch_layer_tail(FfnArgs g, hipStream_t s) { return launch_panel(g, 2, s); }
 
 }  // namespace veto

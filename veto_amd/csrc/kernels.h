@@ -67,6 +67,13 @@ struct FfnArgs {
   const float* ln_w;
   const float* ln_b;
   char* ln_out;
+  // launch_layer_tail only: the attention out projection in front of the FeedForward -- x1 = resid + a . wo^T + bo stays in
+  // registers, lnm_w / lnm_b (LayerNorm2) turn it into the FeedForward's input rows, written to ln_out (= a, in place)
+  const char* wo;        // [576, 4*576 B] mixed weight rows, exponent expo
+  const float* bo;
+  const int* expo;
+  const float* lnm_w;
+  const float* lnm_b;
   int n_panels;          // filled by the launcher
   int stagger;           // filled by the launcher (speed only): start delay of workgroup b = (b & 7) * stagger * s_sleep(32) (~1 us): one phase per XCD
 };
@@ -74,6 +81,10 @@ int ffn_panel_rows();
 hipError_t launch_ffn_fused(FfnArgs g, hipStream_t s);
 // the same skeleton as ONE GEMM: out = resid + a . w2^T + b2 (K = 576: the attention out projection + residual), optional LayerNorm rows
 hipError_t launch_out_fused(FfnArgs g, hipStream_t s);
+// out projection + residual + LayerNorm2 + FeedForward + residual (+ the next layer's LayerNorm1) in ONE launch: everything of a
+// transformer layer behind its attention (model_veto.py:96, :20-21, :125-143).  a = attention output rows (mixed), resid = x in,
+// out = x out, ln_out = a (the LayerNorm2 rows, then the next layer's LayerNorm1 rows, in place); wo / bo / expo / lnm_* as above
+hipError_t launch_layer_tail(FfnArgs g, hipStream_t s);
 
 // ---- weight preparation (once per weight upload) ---------------------------------------------
 // src [rows, K] fp32 -> dst [rows, 2K] split rows

@@ -507,6 +507,8 @@ int veto_forward(veto_handle_t h, void* stream, const veto_inputs_t* in, void* w
   const bool ffn_fused = !ffn_off;   // VETO_MIXED: fc1 -> GELU -> fc2 + residual as one launch
   static const bool out_off = getenv("VETO_OUT_FUSED") && !strcmp(getenv("VETO_OUT_FUSED"), "0");           // A/B knob
   const bool out_fused = !out_off;   // VETO_MIXED: out projection + residual + LayerNorm2 as one launch on full rows
+  static const bool tail_off = getenv("VETO_TAIL_FUSED") && !strcmp(getenv("VETO_TAIL_FUSED"), "0");        // A/B knob
+  const bool tail_fused = !tail_off;   // ... and both of them as ONE launch per layer
   static const bool ffn_ln_off = getenv("VETO_FFN_LN") && !strcmp(getenv("VETO_FFN_LN"), "0");              // A/B knob
   if (qkv0_tables) {
     const int R = n_obj * 16;
@@ -600,6 +602,21 @@ int veto_forward(veto_handle_t h, void* stream, const veto_inputs_t* in, void* w
         HIP_TRY(launch_attention(a, s));
       }
       if (!last) {
+        // ... and the LayerNorm in front of the next layer's QKV GEMM in the FeedForward epilogue, when that GEMM takes mixed rows
+        const bool ffn_ln_next = mixed && ffn_fused && !ffn_ln_off && l + 1 < L - 1;
+        if (mixed_out && out_fused && ffn_fused && tail_fused) {
+          // everything of the layer behind its attention in ONE launch (ffn_fused.hip, MODE 2): x1 = x + a Wo^T + bo stays in
+          // registers, LayerNorm2(x1) is written in place over the attention output and streamed back as the FeedForward's
+          // input, fc2 accumulates on top of x1, the epilogue stores x (and the next layer's LayerNorm1 rows)
+          FfnArgs f{};
+          f.a = (const char*)ws.a; f.wo = (const char*)w.out_m; f.bo = w.out_b; f.expo = w.exp_m + 1; f.lnm_w = w.ln2_w; f.lnm_b = w.ln2_b;
+          f.w1 = (const char*)w.fc1_m; f.w2 = (const char*)w.fc2_m; f.b1 = w.fc1_b; f.b2 = w.fc2_b; f.exp1 = w.exp_m + 2; f.exp2 = w.exp_m + 3;
+          f.resid = ws.x; f.out = ws.x; f.ldr = kDim; f.ldo = kDim; f.M = M; f.ln_out = (char*)ws.a;
+          if (ffn_ln_next) { f.ln_w = h->layers[l + 1].ln1_w; f.ln_b = h->layers[l + 1].ln1_b; }
+          ProfScope ps(h, s, "layer_tail_fused", 2.0 * M * (double)kDim * kDim + 2.0 * 2.0 * M * (double)kDim * 2 * kDim,
+                       (double)M * kDim * 16 + 5.0 * kDim * kDim * 4);
+          HIP_TRY(launch_layer_tail(f, s));
+        } else {
         if (mixed_out && out_fused) {
           // out projection + residual + LayerNorm2 in one launch on full rows (ffn_fused.hip, MODE 1): x <- x + a Wo^T + bo, then
           // a <- LayerNorm2(x) as mixed rows in place over the attention output
@@ -617,8 +634,6 @@ int veto_forward(veto_handle_t h, void* stream, const veto_inputs_t* in, void* w
             HIP_TRY(launch_layernorm(ws.x, kDim, w.ln2_w, w.ln2_b, ws.a, M, s, mixed ? FMT_MIXED : FMT_SPLIT));
           }
         }
-        // ... and the LayerNorm in front of the next layer's QKV GEMM in its epilogue, when that GEMM takes mixed rows
-        const bool ffn_ln_next = mixed && ffn_fused && !ffn_ln_off && l + 1 < L - 1;
         if (mixed && ffn_fused) {
           // FeedForward in one launch (ffn_fused.hip): the hidden activation never leaves the CU
           FfnArgs f{};
@@ -637,6 +652,7 @@ int veto_forward(veto_handle_t h, void* stream, const veto_inputs_t* in, void* w
           rc = run_gemm(h, s, "gemm_fc2", hid, mixed ? w.fc2_m : w.fc2, w.fc2_b, ws.x, kDim, ws.x, nullptr, kDim, M, kDim, 2 * kDim, EPI_RESID,
                         0, 0, DropSite(), mixed ? w.exp_m + 3 : nullptr);
           if (rc) return rc;
+        }
         }
         {
           const LayerW& nx = h->layers[l + 1];
@@ -1571,6 +1587,76 @@ int veto_debug_outproj(void* stream, const float* a, const float* w, const float
       total += ms;
     }
   }
+  if (ms_per_rep) {
+    *ms_per_rep = total / reps;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+  }
+  return VETO_OK;
+}
+
+// Test / measurement hook of everything behind the attention of one layer (model_veto.py:96, :20-21, :125-143): x1 = x + a Wo^T +
+// bo, h = LayerNorm2(x1), x2 = x1 + W2 gelu(W1 h + b1) + b2 (+ LayerNorm rows of x2) on VETO_MIXED operands.  mode 0 = the
+// out-projection panel launch + the FeedForward panel launch, mode 1 = ONE launch (ffn_fused.hip MODE 2).
+size_t veto_debug_layer_tail_workspace_bytes(int32_t m) {
+  if (m <= 0) return 0;
+  const size_t mp = (size_t)gemm_rows_padded(m);
+  return align_up(mp * kDim * 4, 256) + align_up((size_t)kDim * kDim * 4, 256) + 2 * align_up((size_t)2 * kDim * kDim * 4, 256) + 256;
+}
+
+int veto_debug_layer_tail(void* stream, const float* a, const float* wo, const float* bo, const float* ln2_w, const float* ln2_b,
+                          const float* w1, const float* b1, const float* w2, const float* b2, float* x, int32_t m, int32_t mode,
+                          int32_t reps, float* ms_per_rep, void* workspace, size_t workspace_bytes, const float* ln_w, const float* ln_b,
+                          void* ln_rows) {
+  if (!a || !wo || !bo || !ln2_w || !ln2_b || !w1 || !b1 || !w2 || !b2 || !x || !workspace) return fail(VETO_ERR_INVALID, "null argument");
+  if (m <= 0 || reps <= 0 || (mode != 0 && mode != 1)) return fail(VETO_ERR_INVALID, "bad m / reps / mode");
+  if (ln_rows && (!ln_w || !ln_b)) return fail(VETO_ERR_INVALID, "ln_rows needs ln_w and ln_b");
+  if (workspace_bytes < veto_debug_layer_tail_workspace_bytes(m)) return fail(VETO_ERR_WORKSPACE, "workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  const size_t mp = (size_t)gemm_rows_padded(m);
+  char* base = (char*)workspace;
+  __bf16* a_m = (__bf16*)base;
+  __bf16* wo_m = (__bf16*)(base + align_up(mp * kDim * 4, 256));
+  __bf16* w1_m = (__bf16*)((char*)wo_m + align_up((size_t)kDim * kDim * 4, 256));
+  __bf16* w2_m = (__bf16*)((char*)w1_m + align_up((size_t)2 * kDim * kDim * 4, 256));
+  int* exps = (int*)((char*)w2_m + align_up((size_t)2 * kDim * kDim * 4, 256));
+  HIP_TRY(launch_mixed_weight_rows(wo, wo_m, (size_t)kDim, kDim, exps + 0, s));
+  HIP_TRY(launch_mixed_weight_rows(w1, w1_m, (size_t)2 * kDim, kDim, exps + 1, s));
+  HIP_TRY(launch_mixed_weight_rows(w2, w2_m, (size_t)kDim, 2 * kDim, exps + 2, s));
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (ms_per_rep) {
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+  }
+  float total = 0.f;
+  for (int r = 0; r < reps; ++r) {
+    HIP_TRY(hipMemsetAsync(a_m, 0, mp * kDim * 4, s));       // the activation rows are overwritten in place: rebuilt per run, untimed
+    HIP_TRY(launch_mixed_act_rows(a, a_m, (size_t)m, kDim, s));
+    if (ms_per_rep) HIP_TRY(hipEventRecord(e0, s));
+    FfnArgs f{};
+    f.a = (const char*)a_m; f.resid = x; f.out = x; f.ldr = kDim; f.ldo = kDim; f.M = m; f.ln_out = (char*)a_m;
+    if (mode == 1) {
+      f.wo = (const char*)wo_m; f.bo = bo; f.expo = exps + 0; f.lnm_w = ln2_w; f.lnm_b = ln2_b;
+      f.w1 = (const char*)w1_m; f.w2 = (const char*)w2_m; f.b1 = b1; f.b2 = b2; f.exp1 = exps + 1; f.exp2 = exps + 2;
+      if (ln_rows) { f.ln_w = ln_w; f.ln_b = ln_b; }
+      HIP_TRY(launch_layer_tail(f, s));
+    } else {
+      FfnArgs o = f;
+      o.w2 = (const char*)wo_m; o.b2 = bo; o.exp2 = exps + 0; o.ln_w = ln2_w; o.ln_b = ln2_b;
+      HIP_TRY(launch_out_fused(o, s));
+      f.w1 = (const char*)w1_m; f.w2 = (const char*)w2_m; f.b1 = b1; f.b2 = b2; f.exp1 = exps + 1; f.exp2 = exps + 2;
+      if (ln_rows) { f.ln_w = ln_w; f.ln_b = ln_b; } else f.ln_out = nullptr;
+      HIP_TRY(launch_ffn_fused(f, s));
+    }
+    if (ms_per_rep) {
+      HIP_TRY(hipEventRecord(e1, s));
+      HIP_TRY(hipEventSynchronize(e1));
+      float ms = 0.f;
+      HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+      total += ms;
+    }
+  }
+  if (ln_rows) HIP_TRY(hipMemcpyAsync(ln_rows, a_m, (size_t)m * kDim * 4, hipMemcpyDeviceToDevice, s));
   if (ms_per_rep) {
     *ms_per_rep = total / reps;
     (void)hipEventDestroy(e0);
