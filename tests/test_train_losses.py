@@ -352,8 +352,8 @@ def test_relation_head_training_branch_end_to_end():
 @pytest.mark.gpu
 def test_ce_loss_edge_cases_follow_torch():
     """No rows (a MEET tail group that received no sampled relation): NaN like the reference's CE over nothing, empty gradient,
-    no launch.  Labels outside [0, C) -- nn.CrossEntropyLoss's ignore_index -100 in particular -- are ignored rows: same loss and
-    gradients as torch's own criterion."""
+    no launch.  NEGATIVE labels -- nn.CrossEntropyLoss's ignore_index -100 -- are ignored rows: same loss and gradients as torch's
+    own criterion.  A label >= C (a class-mapping bug: torch raises) poisons the loss with NaN instead of dropping the row."""
     from veto_amd.losses import ce_loss, relation_ce_loss
     dev = torch.device("cuda:0")
     loss, grad = relation_ce_loss(torch.zeros((0, 7), device=dev), torch.zeros(0, dtype=torch.int64, device=dev), want_grad=True)
@@ -375,6 +375,9 @@ def test_ce_loss_edge_cases_follow_torch():
     assert abs(float(got.detach()) - float(ref.detach())) < 1e-6
     assert (got_in.grad.cpu() - ref_in.grad).abs().max() < 1e-7
     assert float(got_in.grad[[3, 17, 18]].abs().max()) == 0.0
+    bad = labels.clone()
+    bad[5] = 11
+    assert torch.isnan(ce_loss(logits.to(dev), bad.to(dev), weight=w.to(dev)).detach()).all()
 
 
 @pytest.mark.gpu

@@ -29,14 +29,15 @@ __global__ __launch_bounds__(256) void ce_rows_kernel(CeLossArgs a) {
   for (int c = lane; c < a.C; c += 64) sum += expf(z[c] - mx);
   sum = wave_sum(sum);
   if (lane == 0) {
-    // a label outside [0, C) -- nn.CrossEntropyLoss's ignore_index (-100) in particular -- is an ignored row: weight 0
+    // a NEGATIVE label -- nn.CrossEntropyLoss's ignore_index (-100) -- is an ignored row: weight 0.  A label >= C is a bug in the
+    // caller's class mapping (torch raises): the row poisons the loss with NaN instead of silently dropping out of it.
     const long yl = a.labels[i];
-    const bool valid = yl >= 0 && yl < a.C;
+    const bool valid = yl >= 0 && yl < a.C, bad = yl >= a.C;
     const int y = valid ? (int)yl : 0;
     const float lse = mx + logf(sum);
     const float w = valid ? (a.weight ? a.weight[y] : 1.f) : 0.f;
     a.lse[i] = lse;
-    a.nll_w[i] = valid ? w * (lse - z[y]) : 0.f;
+    a.nll_w[i] = bad ? __builtin_nanf("") : valid ? w * (lse - z[y]) : 0.f;
     a.w_row[i] = w;
   }
 }

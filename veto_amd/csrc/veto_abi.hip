@@ -71,6 +71,10 @@ struct veto_handle_s {
   float* raw = nullptr;      // fp32 copies of every state-dict tensor
   char* derived = nullptr;   // split planes, transposes, folded tables
   bool dirty = true;
+  // generation of the derived weight operands (bumped by every finalize_weights) and, per training workspace, the generation its
+  // saved activations were computed with: veto_backward refuses a workspace whose forward saw other weights
+  uint64_t weight_gen = 0;
+  std::map<const void*, uint64_t> train_gen;
   std::vector<LayerW> layers;
   SplitW patch_w = nullptr;
   // last layer, folded CLS attention (attention.hip): Mcat [heads*576, 2*576], Ncat [576, 2*heads*576], and their fp32 staging
@@ -186,6 +190,7 @@ int finalize_weights(veto_handle_t h, hipStream_t s) {
     HIP_TRY(launch_split_rows(h->fold_tmp, h->fold_n, (size_t)kDim, H * kDim, s));
   }
   h->dirty = false;
+  ++h->weight_gen;
   return VETO_OK;
 }
 
@@ -768,7 +773,11 @@ TrainWs carve_train(char* base, veto_handle_t h, int n_obj, int n_pair) {
   w.dmid = (float*)take(mpad * kDim * 4);
   w.dtmp = (float*)take(mpad * kDim * 4);
   w.dbig = (float*)take(mpad * 3 * kDim * 4);
-  w.dsplit = (__bf16*)take(mpad * 6 * kDim * 2);
+  {   // the token-row gradients (6 * 576 bf16 per row) and, for the input gradient of the patch projection, the split rows of
+      // dpatch (prow rows x 2 * 1152 bf16) share this buffer: size it for the larger (n_obj * 16 can exceed 19 * n_pair / 1.5)
+    const size_t tok = mpad * 6 * kDim * 2, obj = prow * 4 * kDim * 2;
+    w.dsplit = (__bf16*)take(tok > obj ? tok : obj);
+  }
   w.mp2 = (M + 32 * 64 + 31) / 32 * 32;   // room for any split count up to 64
   w.zero = (__bf16*)take(1024);           // what the weight-gradient GEMM reads for reduction rows past the last one
   w.wdg = (__bf16*)take((size_t)3 * kDim * kDim * 4);
@@ -897,6 +906,7 @@ int veto_forward_train(veto_handle_t h, void* stream, const veto_inputs_t* in, c
   hipStream_t s = (hipStream_t)stream;
   HIP_TRY(hipSetDevice(h->cfg.device));
   if (h->dirty) { rc = finalize_weights(h, s); if (rc) return rc; }
+  h->train_gen[workspace] = h->weight_gen;
   const int n_obj = in->n_obj, n_pair = in->n_pair, L = h->cfg.layers, H = h->cfg.heads, n_out = h->cfg.num_out;
   const int M = n_pair * kTokens;
   TrainWs ws = carve_train((char*)workspace, h, n_obj, n_pair);
@@ -995,6 +1005,12 @@ int veto_backward(veto_handle_t h, void* stream, const veto_inputs_t* in, const 
   // the backward reads the derived operands the matching forward used: a weight upload in between would pair this
   // workspace's activations with different weights
   if (h->dirty) return fail(VETO_ERR_WEIGHTS, "weights were reloaded between veto_forward_train and veto_backward");
+  {
+    auto it = h->train_gen.find(workspace);
+    if (it == h->train_gen.end()) return fail(VETO_ERR_INVALID, "veto_backward: this workspace holds no veto_forward_train activations");
+    if (it->second != h->weight_gen)
+      return fail(VETO_ERR_WEIGHTS, "veto_backward: the weights were refreshed (by a later forward) since this workspace's veto_forward_train");
+  }
   const int n_obj = in->n_obj, n_pair = in->n_pair, L = h->cfg.layers, H = h->cfg.heads, n_out = h->cfg.num_out, E = h->cfg.embed_dim;
   const int M = n_pair * kTokens;
   TrainWs ws = carve_train((char*)workspace, h, n_obj, n_pair);

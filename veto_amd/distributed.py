@@ -95,11 +95,12 @@ def all_reduce_gradients(params, group=None, average=True, bucket_bytes=256 << 2
         n = sum(p.numel() for p in bucket)
         flat = torch.zeros(n + len(bucket), dtype=torch.float32, device=bucket[0].device)
         off = 0
-        for k, p in enumerate(bucket):
+        for p in bucket:
             if p.grad is not None:
                 flat[off:off + p.numel()] = p.grad.reshape(-1)
-                flat[n + k] = 1.0
             off += p.numel()
+        # the "has a gradient" flags of the bucket in ONE copy (not one tiny device kernel per parameter)
+        flat[n:] = torch.tensor([0.0 if p.grad is None else 1.0 for p in bucket], dtype=torch.float32).to(flat.device)
         dist.all_reduce(flat, group=group)
         if average:
             flat[:n] /= world
@@ -109,7 +110,7 @@ def all_reduce_gradients(params, group=None, average=True, bucket_bytes=256 << 2
             if used[k] > 0:
                 g = flat[off:off + p.numel()].view_as(p)
                 if p.grad is None:
-                    p.grad = g.clone()
+                    p.grad = g.to(p.dtype).clone()       # (a bf16 / fp16 parameter takes a gradient of its own dtype)
                 else:
                     p.grad.copy_(g)
             off += p.numel()
