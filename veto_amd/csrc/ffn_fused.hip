@@ -382,6 +382,8 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs g) {
       const int row0 = panel * FR + wm * 32 + er;
       const int col0 = wn * 32 + eq * 4;                     // + t * 192 + (i >> 1) * 64 + (i & 1) * 16
       const float* b2l = (const float*)(smem + kB2Off) + col0;
+      f32x4 gbv = f32x4{0.f, 0.f, 0.f, 0.f};      // this thread's 16 bytes of the LayerNorm's gamma | beta (in flight under phases A .. C)
+      if (g.ln_out && lw && tid < 288) gbv = tid < 144 ? ((const f32x4*)lw)[tid] : ((const f32x4*)lb)[tid - 144];
       // phase A: the lane transposition, in place, three blocks at a time
 #pragma unroll
       for (int u = 0; u < 12; ++u) {
@@ -453,6 +455,11 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs g) {
         // waves exchange through LDS (the idle activation part of ring slot 2); two passes (mean, then centred squares) like
         // rowq_stats in rowops.hip.  Both waves add the same two partial sums: identical statistics in either.
         float* red = (float*)(smem + 2 * kSlot);          // [pass][wave][m][row] floats
+        // gamma / beta go through LDS (behind the same barriers): as global loads inside the normalise loop they would sit behind
+        // the loop's own stores in the wave's one in-order memory queue and wait for every store to drain (measured: 23 k cycles
+        // for the loop, store count and arithmetic notwithstanding)
+        float* gb = (float*)(smem + 2 * kSlot + 4096);    // [gamma 576 | beta 576], requested at the top of the epilogue
+        if (tid < 288) ((f32x4*)gb)[tid] = gbv;
         float mean[2], rstd[2];
 #pragma unroll
         for (int pass = 0; pass < 2; ++pass) {
@@ -491,7 +498,7 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs g) {
 #pragma unroll
           for (int i = 0; i < 6; ++i) {
             const int col = col0 + t * FC + (i >> 1) * 64 + (i & 1) * 16;
-            const f32x4 wv = *(const f32x4*)(lw + col), bv = *(const f32x4*)(lb + col);
+            const f32x4 wv = *(const f32x4*)(gb + col), bv = *(const f32x4*)(gb + kDim + col);
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
               const int row = row0 + m * 16;
