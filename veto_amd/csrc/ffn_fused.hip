@@ -46,6 +46,9 @@
 #ifndef FFN_PRIO
 #define FFN_PRIO 0          // 1: s_setprio 1 for waves 4..7 (the younger wave of every SIMD loses the issue arbitration otherwise)
 #endif
+#ifndef FFN_RESID_EARLY
+#define FFN_RESID_EARLY 1   // layer tail: request the first residual rows of the mid-panel epilogue during the last out-projection stages
+#endif
 #ifndef FFN_DMA_EARLY
 #define FFN_DMA_EARLY 1     // DMA instructions issued before the first MFMA group of a stage (the rest follow groups 0, 1, ...)
 #endif
@@ -370,8 +373,8 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs g) {
     // l >> 4; one ds_bpermute per value (lane 4 r + q takes lane 16 q + r) makes every quad of lanes cover 64 contiguous bytes
     // of one row (gemm_split_ps.hip).  Every residual read is issued before the first store (one in-order counter per wave).
   auto epilogue = [&](f32x4 (&acc2)[3][6][2], int panel, auto resid_tag, auto store_tag, auto back_tag, const float* bias_g, const float* lw,
-                      const float* lb) {
-    constexpr bool RESID = decltype(resid_tag)::value != 0;   // add the residual rows g.resid
+                      const float* lb, f32x4 (*pre)[6]) {
+    constexpr bool RESID = decltype(resid_tag)::value != 0;   // add the residual rows g.resid (pre: groups 0, 1 already requested)
     constexpr bool STORE = decltype(store_tag)::value != 0;   // store the fp32 rows to g.out
     constexpr bool BACK = decltype(back_tag)::value != 0;     // return the accumulators to the MFMA layout (the panel goes on)
     {
@@ -413,8 +416,13 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs g) {
         for (int i = 0; i < 6; ++i) r[i] = *(const f32x4*)(rp + (i >> 1) * 64 + (i & 1) * 16);
       };
       if constexpr (RESID) {
-        load_res(0, res[0]);
-        load_res(1, res[1]);
+        if (pre) {
+#pragma unroll
+          for (int i = 0; i < 6; ++i) { res[0][i] = pre[0][i]; res[1][i] = pre[1][i]; }
+        } else {
+          load_res(0, res[0]);
+          load_res(1, res[1]);
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -545,20 +553,25 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs g) {
 #pragma unroll
         for (int m = 0; m < 2; ++m) acc2[t][i][m] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    f32x4 res_pre[2][6];     // MODE 2: residual groups 0, 1 of the mid-panel epilogue, requested at the end of the out projection
+    (void)res_pre;
     if constexpr (MODE != 0) {
       // ---- out projection: 18 k-slices x 3 column thirds.  MODE 2: nothing is prefetched behind position 53 (the FeedForward
       // phase streams the LayerNorm2 rows the epilogue below has yet to write)
       const bool stream_ends = MODE == 2 || it == my_panels - 1;
       const char* a_next = panel_base(it + 1);          // (not dereferenced when the stream ends)
       i32x4 fa0[2], fa1[2];
+      constexpr bool EARLY = MODE == 2 && FFN_RESID_EARLY;   // the residual groups 0, 1 of the epilogue are requested behind stage 51
       static_for<0, 54>([&](auto p_tag) {
         constexpr int P = decltype(p_tag)::value, KS = P / 3, T = P % 3;
         STAMP(t0);
         if (skip > 0) --skip;
         else if (P == 53) {
-          if (stream_ends) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          if (EARLY) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");       // (the 12 residual loads are younger than stage 53)
+          else if (stream_ends) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-        } else if ((P + 1) % 3 == 0) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        } else if (EARLY && P == 52) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");   // stage 53 (3) + the residual loads (12)
+        else if ((P + 1) % 3 == 0) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
         STAMP(t1);
         wg_barrier();
@@ -570,6 +583,21 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs g) {
           else if (!stream_ends) issue_out(a_next, (P2 - 54) / 3, (P2 - 54) % 3, (P2 - 54) % 3, k);
         };
         stage(Tag<KS & 1>(), Tag<0>(), Tag<T * kSlot>(), acc2[T], MODE == 2 ? sco : sc2, dma, Tag<(T > 0)>(), fa0, fa1, [](int) {}, [](int) {});
+        if constexpr (EARLY && P == 51) {
+          // the phase's last DMA instruction is out: the first two residual groups of the epilogue (transposed-layout addresses,
+          // as load_res there) ride under the last two stages and the lane transposition
+          int lane_e = lane;
+          asm volatile("" : "+v"(lane_e));
+          const int er = lane_e >> 2, eq = lane_e & 3;
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            int row = panel * FR + wm * 32 + er;          // groups 0, 1: row group m = 0, column thirds 0, 1
+            if (row >= g.M) row = g.M - 1;
+            const float* rp = g.resid + (size_t)row * g.ldr + wn * 32 + eq * 4 + u * FC;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) res_pre[u][i] = *(const f32x4*)(rp + (i >> 1) * 64 + (i & 1) * 16);
+          }
+        }
         STAMP(t0);
         ACC(s_cmp, t0, t2);
       });
@@ -579,7 +607,7 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs g) {
       // of it); LayerNorm2(x1) goes to ln_out as mixed rows.  Those rows are re-read by this CU's DMA right away, through an L1
       // that may still hold lines of the attention-output rows they replace: stores drained, one L1 invalidate per workgroup.
       STAMP(t0);
-      epilogue(acc2, panel, Tag<1>(), Tag<0>(), Tag<1>(), g.bo, g.lnm_w, g.lnm_b);
+      epilogue(acc2, panel, Tag<1>(), Tag<0>(), Tag<1>(), g.bo, g.lnm_w, g.lnm_b, FFN_RESID_EARLY ? res_pre : nullptr);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       wg_barrier();
       if (w == 0) {
@@ -701,7 +729,7 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs g) {
     STAMP(t0);
     EP(0);
     if (!(FFN_ABLATE & 16)) {
-      epilogue(acc2, panel, Tag<(MODE == 2 ? 0 : 1)>(), Tag<1>(), Tag<0>(), nullptr, g.ln_w, g.ln_b);
+      epilogue(acc2, panel, Tag<(MODE == 2 ? 0 : 1)>(), Tag<1>(), Tag<0>(), nullptr, g.ln_w, g.ln_b, nullptr);
       skip = 2;   // stages 0 and 1 of the next panel landed before the drain inside
     } else {
       asm volatile("" ::"v"(acc2[0][0][0]), "v"(acc2[2][5][1]));
