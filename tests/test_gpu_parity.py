@@ -264,6 +264,45 @@ def test_fused_layer_tail(m):
     assert (xs[0] - xs[1]).abs().max().item() < 3e-4
 
 
+def test_fused_layer_tail_full_size_hand_off():
+    """The layer-tail kernel at the headline size (287 280 rows: nine panels per workgroup, every CU streaming): the LayerNorm2
+    rows a workgroup writes and re-reads within the launch must be the fresh ones in EVERY row (an L1 line of the rows they replace
+    would be a stale hit), launch after launch.  Checked word by word against the two panel launches (which pass the rows through
+    a kernel boundary), three times."""
+    from veto_amd import native
+    lib = native.load_library()
+    dev = _dev()
+    m = 287280
+    g = torch.Generator(device="cpu").manual_seed(99)
+    mk = lambda *shape, s=1.0: (torch.randn(*shape, generator=g) * s).to(dev)
+    a, x0 = mk(m, 576), mk(m, 576)
+    wo, bo = mk(576, 576, s=0.05), mk(576, s=0.1)
+    l2w, l2b = (1.0 + 0.3 * torch.randn(576, generator=g)).to(dev), mk(576, s=0.2)
+    w1, b1, w2, b2 = mk(1152, 576, s=0.04), mk(1152, s=0.1), mk(576, 1152, s=0.03), mk(576, s=0.1)
+    lw, lb = (1.0 + 0.3 * torch.randn(576, generator=g)).to(dev), mk(576, s=0.2)
+    ws = torch.empty(lib.veto_debug_layer_tail_workspace_bytes(m), dtype=torch.uint8, device=dev)
+
+    def run(mode):
+        x = x0.clone()
+        rows = torch.zeros(m, 4 * 576, dtype=torch.uint8, device=dev)
+        native.check(lib.veto_debug_layer_tail(None, a.data_ptr(), wo.data_ptr(), bo.data_ptr(), l2w.data_ptr(), l2b.data_ptr(), w1.data_ptr(),
+                                               b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), x.data_ptr(), m, mode, 1, None, ws.data_ptr(),
+                                               ws.numel(), lw.data_ptr(), lb.data_ptr(), rows.data_ptr()))
+        torch.cuda.synchronize()
+        return x, rows
+
+    ref_x, ref_rows = run(0)
+    first = None
+    for rep in range(3):
+        x, rows = run(1)
+        assert torch.isfinite(x).all()
+        assert (x - ref_x).abs().max().item() < 3e-4, rep          # a stale LayerNorm2 row would be off by O(1)
+        if first is None:
+            first = (x, rows)
+        else:
+            assert torch.equal(x, first[0]) and torch.equal(rows, first[1])     # and the launch is deterministic
+
+
 @pytest.mark.parametrize("n", [1, 2, 3, 10, 36, 50])
 def test_enumerate_pairs_bit_exact(n):
     from veto_amd.pairs import prepare_test_pairs
