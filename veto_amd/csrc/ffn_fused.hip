@@ -46,9 +46,6 @@
 #ifndef FFN_PRIO
 #define FFN_PRIO 0          // 1: s_setprio 1 for waves 4..7 (the younger wave of every SIMD loses the issue arbitration otherwise)
 #endif
-#ifndef FFN_RESID_EARLY
-#define FFN_RESID_EARLY 1   // layer tail: request the first residual rows of the mid-panel epilogue during the last out-projection stages
-#endif
 #ifndef FFN_DMA_EARLY
 #define FFN_DMA_EARLY 1     // DMA instructions issued before the first MFMA group of a stage (the rest follow groups 0, 1, ...)
 #endif
@@ -372,11 +369,8 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs g) {
     // ---- panel epilogue: out = acc + b2 + residual.  The MFMA leaves lane l with row l & 15, 4 consecutive columns of chunk
     // l >> 4; one ds_bpermute per value (lane 4 r + q takes lane 16 q + r) makes every quad of lanes cover 64 contiguous bytes
     // of one row (gemm_split_ps.hip).  Every residual read is issued before the first store (one in-order counter per wave).
-  auto epilogue = [&](f32x4 (&acc2)[3][6][2], int panel, auto resid_tag, auto store_tag, auto back_tag, const float* bias_g, const float* lw,
-                      const float* lb, f32x4 (*pre)[6]) {
-    constexpr bool RESID = decltype(resid_tag)::value != 0;   // add the residual rows g.resid (pre: groups 0, 1 already requested)
-    constexpr bool STORE = decltype(store_tag)::value != 0;   // store the fp32 rows to g.out
-    constexpr bool BACK = decltype(back_tag)::value != 0;     // return the accumulators to the MFMA layout (the panel goes on)
+  auto epilogue = [&](f32x4 (&acc2)[3][6][2], int panel, auto resid_tag, const float* lw, const float* lb) {
+    constexpr bool RESID = decltype(resid_tag)::value != 0;   // add the residual rows g.resid
     {
       int lane_e = lane;
       asm volatile("" : "+v"(lane_e));
@@ -416,13 +410,8 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs g) {
         for (int i = 0; i < 6; ++i) r[i] = *(const f32x4*)(rp + (i >> 1) * 64 + (i & 1) * 16);
       };
       if constexpr (RESID) {
-        if (pre) {
-#pragma unroll
-          for (int i = 0; i < 6; ++i) { res[0][i] = pre[0][i]; res[1][i] = pre[1][i]; }
-        } else {
-          load_res(0, res[0]);
-          load_res(1, res[1]);
-        }
+        load_res(0, res[0]);
+        load_res(1, res[1]);
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -432,8 +421,7 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs g) {
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
-          const f32x4 bias4 = bias_g ? *(const f32x4*)(bias_g + col0 + t * FC + (i >> 1) * 64 + (i & 1) * 16)
-                                     : *(const f32x4*)(b2l + t * FC + (i >> 1) * 64 + (i & 1) * 16);
+          const f32x4 bias4 = *(const f32x4*)(b2l + t * FC + (i >> 1) * 64 + (i & 1) * 16);
           if constexpr (RESID) acc2[t][i][m] = acc2[t][i][m] + res[u % 3][i] + bias4;
           else acc2[t][i][m] = acc2[t][i][m] + bias4;
           asm volatile("" : "+v"(acc2[t][i][m]));
@@ -443,7 +431,6 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs g) {
       EP(2);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the reads are consumed; the two prefetched stages have landed too)
       EP(3);
-      if constexpr (STORE)
 #pragma unroll
       for (int m = 0; m < 2; ++m) {
         const int row = row0 + m * 16;
@@ -520,25 +507,83 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs g) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         EP(8);
       }
-      if constexpr (BACK) {
-        // back to the MFMA layout (lane 16 q + r takes lane 4 r + q): the panel's FeedForward phase accumulates on these rows
-        const int perm_inv = (((lane_e & 15) << 2) + (lane_e >> 4)) << 2;
+    }
+  };
+
+  // ---- MODE 2, middle of a panel.  The accumulators hold x + a Wo^T in the MFMA layout (they started as the residual rows); this
+  // adds the bias (x1 stays in the registers: fc2 accumulates on top of it), computes LayerNorm2 of the rows and writes them as
+  // mixed rows to ln_out, all in the MFMA layout: a row's 576 columns sit in lanes r, r + 16, r + 32, r + 48 of the two waves of
+  // its row group.  Statistics as in the panel epilogue above (two passes, the same two partial sums added in either wave).
+  auto mid_epilogue = [&](f32x4 (&acc2)[3][6][2], int panel, f32x4 gbv) {
+    int lane_e = lane;
+    asm volatile("" : "+v"(lane_e));
+    const int r = lane_e & 15, q = lane_e >> 4;
+    const int col0 = wn * 32 + q * 4;                    // + t * 192 + (i >> 1) * 64 + (i & 1) * 16
+    const int row0 = panel * FR + wm * 32 + r;           // + m * 16
+    float* red = (float*)(smem + 2 * kSlot);             // [pass][wave][m][row] floats (ring slot 2: stage 53 lived there)
+    float* gb = (float*)(smem + 2 * kSlot + 4096);       // [gamma 576 | beta 576 | bias 576]
+    wg_barrier();                                         // every wave has read stage 53
+    if (tid < 432) ((f32x4*)gb)[tid] = gbv;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    wg_barrier();
 #pragma unroll
-        for (int u = 0; u < 12; ++u) {
-          const int m = u / 6, t = (u % 6) >> 1, i0 = (u & 1) * 3;
+    for (int u = 0; u < 12; ++u) {
+      const int m = u / 6, t = (u % 6) >> 1, i0 = (u & 1) * 3;
+      mfma_drain3(acc2[t][i0][m], acc2[t][i0 + 1][m], acc2[t][i0 + 2][m]);
 #pragma unroll
-          for (int i = i0; i < i0 + 3; ++i) {
-            f32x4 tv;
+      for (int i = i0; i < i0 + 3; ++i) {
+        acc2[t][i][m] = acc2[t][i][m] + *(const f32x4*)(gb + 2 * kDim + col0 + t * FC + (i >> 1) * 64 + (i & 1) * 16);
+        asm volatile("" : "+v"(acc2[t][i][m]));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    float mean[2], rstd[2];
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-              tv[e] = __int_as_float(__builtin_amdgcn_ds_bpermute(perm_inv, __float_as_int(acc2[t][i][m][e])));
-            acc2[t][i][m] = tv;
-            asm volatile("" : "+v"(acc2[t][i][m]));
+    for (int pass = 0; pass < 2; ++pass) {
+      float part[2];
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        float p = 0.f;
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+          for (int i = 0; i < 6; ++i) {
+            if (pass == 0) {
+              p += (acc2[t][i][m][0] + acc2[t][i][m][1]) + (acc2[t][i][m][2] + acc2[t][i][m][3]);
+            } else {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) { const float d = acc2[t][i][m][e] - mean[m]; p += d * d; }
+            }
           }
-          __builtin_amdgcn_sched_barrier(0);
-        }
+        p += __shfl_xor(p, 16, 64);
+        p += __shfl_xor(p, 32, 64);
+        part[m] = p;
+        if (q == 0) red[((pass * 8 + w) * 2 + m) * 16 + r] = p;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      wg_barrier();
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        const float tot = part[m] + red[((pass * 8 + (w ^ 1)) * 2 + m) * 16 + r];
+        if (pass == 0) mean[m] = tot * (1.f / kDim);
+        else rstd[m] = 1.f / sqrtf(tot * (1.f / kDim) + 1e-5f);
       }
     }
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        const int col = col0 + t * FC + (i >> 1) * 64 + (i & 1) * 16;
+        const f32x4 wv = *(const f32x4*)(gb + col), bv = *(const f32x4*)(gb + kDim + col);
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+          const int row = row0 + m * 16;
+          f32x4 y;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) y[e] = (acc2[t][i][m][e] - mean[m]) * rstd[m] * wv[e] + bv[e];
+          if (row < g.M) store_act4<FMT_MIXED>((__bf16*)(g.ln_out + (size_t)row * kRow1), col, y);
+        }
+      }
   };
 
   for (int it = 0; it < my_panels; ++it) {
@@ -546,32 +591,53 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs g) {
     const int panel = b + it * G;
     const char* a_panel = panel_base(it);
     f32x4 acc2[3][6][2];     // [column third t][block i][row group m]
+    if constexpr (MODE == 2) {
+      // The layer tail's accumulators START as the panel's residual rows, read straight into the MFMA layout (lane 16 q + r holds
+      // row r of its 16-row group, 4 columns at 4 q of every 16-column block): the out projection accumulates on top of x, so
+      // x1 is complete in registers when its last stage ends -- no residual buffers, no lane transposition, and the rows arrive
+      // under the first stages (the compiler sees these loads and waits for each one in front of its first MFMA; the DMA
+      // instructions it does not see are all younger or already drained, which only makes its counts conservative).
+      int lane_r = lane;
+      asm volatile("" : "+v"(lane_r));
+      const int r = lane_r & 15, q = lane_r >> 4;
 #pragma unroll
-    for (int t = 0; t < 3; ++t)
+      for (int t = 0; t < 3; ++t)
 #pragma unroll
-      for (int i = 0; i < 6; ++i)
+        for (int i = 0; i < 6; ++i)
 #pragma unroll
-        for (int m = 0; m < 2; ++m) acc2[t][i][m] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    f32x4 res_pre[2][6];     // MODE 2: residual groups 0, 1 of the mid-panel epilogue, requested at the end of the out projection
-    (void)res_pre;
+          for (int m = 0; m < 2; ++m) {
+            int row = panel * FR + wm * 32 + m * 16 + r;
+            if (row >= g.M) row = g.M - 1;          // clamp: rows past the end are never stored
+            acc2[t][i][m] = *(const f32x4*)(g.resid + (size_t)row * g.ldr + wn * 32 + q * 4 + t * FC + (i >> 1) * 64 + (i & 1) * 16);
+          }
+      if (it == 0) {
+        asm volatile("s_waitcnt vmcnt(36)" ::: "memory");   // the prologue's stages 0 and 1 have landed (they are older than the 36 loads)
+        skip = 2;
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+          for (int m = 0; m < 2; ++m) acc2[t][i][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    f32x4 gbv = f32x4{0.f, 0.f, 0.f, 0.f};   // MODE 2: this thread's 16 bytes of LayerNorm2's gamma | beta | the out-projection bias
+    (void)gbv;
     if constexpr (MODE != 0) {
       // ---- out projection: 18 k-slices x 3 column thirds.  MODE 2: nothing is prefetched behind position 53 (the FeedForward
       // phase streams the LayerNorm2 rows the epilogue below has yet to write)
       const bool stream_ends = MODE == 2 || it == my_panels - 1;
       const char* a_next = panel_base(it + 1);          // (not dereferenced when the stream ends)
       i32x4 fa0[2], fa1[2];
-      constexpr bool EARLY = MODE == 2 && FFN_RESID_EARLY;   // the residual groups 0, 1 of the epilogue are requested behind stage 51
       static_for<0, 54>([&](auto p_tag) {
         constexpr int P = decltype(p_tag)::value, KS = P / 3, T = P % 3;
         STAMP(t0);
         if (skip > 0) --skip;
         else if (P == 53) {
-          if (EARLY) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");       // (the 12 residual loads are younger than stage 53)
-          else if (stream_ends) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          if (stream_ends) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-        } else if (EARLY && P == 52) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");   // stage 53 (3) + the residual loads (12)
-        else if ((P + 1) % 3 == 0) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        } else if ((P + 1) % 3 == 0) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
         STAMP(t1);
         wg_barrier();
@@ -583,20 +649,10 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs g) {
           else if (!stream_ends) issue_out(a_next, (P2 - 54) / 3, (P2 - 54) % 3, (P2 - 54) % 3, k);
         };
         stage(Tag<KS & 1>(), Tag<0>(), Tag<T * kSlot>(), acc2[T], MODE == 2 ? sco : sc2, dma, Tag<(T > 0)>(), fa0, fa1, [](int) {}, [](int) {});
-        if constexpr (EARLY && P == 51) {
-          // the phase's last DMA instruction is out: the first two residual groups of the epilogue (transposed-layout addresses,
-          // as load_res there) ride under the last two stages and the lane transposition
-          int lane_e = lane;
-          asm volatile("" : "+v"(lane_e));
-          const int er = lane_e >> 2, eq = lane_e & 3;
-#pragma unroll
-          for (int u = 0; u < 2; ++u) {
-            int row = panel * FR + wm * 32 + er;          // groups 0, 1: row group m = 0, column thirds 0, 1
-            if (row >= g.M) row = g.M - 1;
-            const float* rp = g.resid + (size_t)row * g.ldr + wn * 32 + eq * 4 + u * FC;
-#pragma unroll
-            for (int i = 0; i < 6; ++i) res_pre[u][i] = *(const f32x4*)(rp + (i >> 1) * 64 + (i & 1) * 16);
-          }
+        if constexpr (MODE == 2 && P == 52) {
+          // the phase's last DMA instruction is long out: the parameters of the mid-panel epilogue are requested here and drained by
+          // the wait of position 53
+          if (tid < 432) gbv = tid < 144 ? ((const f32x4*)g.lnm_w)[tid] : tid < 288 ? ((const f32x4*)g.lnm_b)[tid - 144] : ((const f32x4*)g.bo)[tid - 288];
         }
         STAMP(t0);
         ACC(s_cmp, t0, t2);
@@ -607,7 +663,7 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs g) {
       // of it); LayerNorm2(x1) goes to ln_out as mixed rows.  Those rows are re-read by this CU's DMA right away, through an L1
       // that may still hold lines of the attention-output rows they replace: stores drained, one L1 invalidate per workgroup.
       STAMP(t0);
-      epilogue(acc2, panel, Tag<1>(), Tag<0>(), Tag<1>(), g.bo, g.lnm_w, g.lnm_b, FFN_RESID_EARLY ? res_pre : nullptr);
+      mid_epilogue(acc2, panel, gbv);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       wg_barrier();
       if (w == 0) {
@@ -729,7 +785,7 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs g) {
     STAMP(t0);
     EP(0);
     if (!(FFN_ABLATE & 16)) {
-      epilogue(acc2, panel, Tag<(MODE == 2 ? 0 : 1)>(), Tag<1>(), Tag<0>(), nullptr, g.ln_w, g.ln_b, nullptr);
+      epilogue(acc2, panel, Tag<(MODE == 2 ? 0 : 1)>(), g.ln_w, g.ln_b);
       skip = 2;   // stages 0 and 1 of the next panel landed before the drain inside
     } else {
       asm volatile("" ::"v"(acc2[0][0][0]), "v"(acc2[2][5][1]));
