@@ -216,7 +216,9 @@ def test_fused_out_projection_residual_layernorm(m):
         assert ((hx - lnref).abs() / lnref.abs().clamp_min(0.05)).max().item() < 2.0 ** -14, mode
         xs.append(x)
         planes.append(hx)
-    assert torch.equal(xs[0], xs[1])        # same operands, same summation order, same epilogue arithmetic
+    # same operands and k order; the panel kernel starts its accumulators at the residual row where the GEMM launch adds it last:
+    # the two differ by fp32 roundings of the sum
+    assert ((xs[0] - xs[1]).abs() / (xs[0].abs() + scale.float())).max().item() < 2e-6
     assert (planes[0] - planes[1]).abs().max().item() < 2e-4
 
 

@@ -137,6 +137,13 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs g) {
   __shared__ __attribute__((aligned(16))) char smem[kLds];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
+  // the lane id, recomputed where a late phase needs it (two instructions) instead of a register that lives through the whole
+  // kernel: with 192 accumulators the allocator spills such a register and its reload costs a full drain of the wave's DMA queue
+  auto lane_now = []() {
+    int l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+  };
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = w >> 1, wn = w & 1;          // 4 x 2 waves: rows 32 wm .., of every 64 weight rows of a stage the 32 at 32 wn
   const int G = gridDim.x, b = blockIdx.x;
@@ -306,8 +313,7 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs g) {
   // bias + GELU + mixed-row conversion of hidden block J of chunk c (this wave's 32 columns x 32 rows) into the hidden images
   auto hidden_write = [&](auto j_tag, int c, f32x4 (&acc1)[6][2]) {
     constexpr int J = decltype(j_tag)::value;
-    int lane_h = lane;
-    asm volatile("" : "+v"(lane_h));                                    // recompute the lane offsets here: nothing to keep live
+    const int lane_h = lane_now();
     const int hr = lane_h & 15, hq = lane_h >> 4;
     // every value is converted first, the eight LDS stores follow in one run behind a scheduling fence: the compiler merges the
     // two row groups of a block into one ds_write2st64_b64 and, left alone, overwrites its last data register in the very next
@@ -366,71 +372,60 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs g) {
   int skip = 0;                       // intervals whose stage is known to have landed (behind a full drain)
 
   int cur_it = 0; (void)cur_it;
-    // ---- panel epilogue: out = acc + b2 + residual.  The MFMA leaves lane l with row l & 15, 4 consecutive columns of chunk
-    // l >> 4; one ds_bpermute per value (lane 4 r + q takes lane 16 q + r) makes every quad of lanes cover 64 contiguous bytes
-    // of one row (gemm_split_ps.hip).  Every residual read is issued before the first store (one in-order counter per wave).
-  auto epilogue = [&](f32x4 (&acc2)[3][6][2], int panel, auto resid_tag, const float* lw, const float* lb) {
-    constexpr bool RESID = decltype(resid_tag)::value != 0;   // add the residual rows g.resid
-    {
-      int lane_e = lane;
-      asm volatile("" : "+v"(lane_e));
-      const int er = lane_e >> 2, eq = lane_e & 3;
-      const int perm_addr = ((eq << 4) + er) << 2;
-      const int row0 = panel * FR + wm * 32 + er;
-      const int col0 = wn * 32 + eq * 4;                     // + t * 192 + (i >> 1) * 64 + (i & 1) * 16
-      const float* b2l = (const float*)(smem + kB2Off) + col0;
-      f32x4 gbv = f32x4{0.f, 0.f, 0.f, 0.f};      // this thread's 16 bytes of the LayerNorm's gamma | beta (in flight under phases A .. C)
-      if (g.ln_out && lw && tid < 288) gbv = tid < 144 ? ((const f32x4*)lw)[tid] : ((const f32x4*)lb)[tid - 144];
-      // phase A: the lane transposition, in place, three blocks at a time
+  // ---- panel epilogue.  MFMA layout: lane 16 q + r holds row r of its 16-row group and 4 consecutive columns at 4 q of every
+  // 16-column block, so a row's 576 columns sit in lanes r, r + 16, r + 32, r + 48 of the two waves of its row group.  The
+  // accumulators started as the residual rows (panel loop below): acc + bias IS the new residual stream.
+  //   MID (the layer tail's mid-panel point): bias = the out projection's, staged with LayerNorm2's gamma | beta (gbv, requested at
+  //        position 52); x1 stays in the registers -- fc2 accumulates on top of it -- and LayerNorm2(x1) goes to ln_out;
+  //   otherwise: bias = b2 (resident in LDS), the rows are stored to g.out, and with ln_w the LayerNorm of the finished rows
+  //        (model_veto.py:125-132 of the NEXT layer's attention PreNorm) is written as mixed rows to ln_out: the standalone
+  //        LayerNorm launch (0.66 GB read + 0.66 GB written) disappears.
+  // LayerNorm statistics: two passes (mean, then centred squares) like rowq_stats in rowops.hip; the four lanes of a row are
+  // summed by lane exchange, the two waves exchange through LDS (the activation part of ring slot 2, idle in every phase that
+  // ends in an epilogue); both waves add the same two partial sums: identical statistics in either.  gamma / beta are read from
+  // LDS: as global loads inside the normalise loop they would sit behind the loop's own stores in the wave's one in-order memory
+  // queue (measured: 23 k cycles for the loop, store count and arithmetic notwithstanding).
+  auto epilogue = [&](f32x4 (&acc2)[3][6][2], int panel, auto mid_tag, f32x4 gbv) {
+    constexpr bool MID = decltype(mid_tag)::value != 0;
+    const int lane_e = lane_now();
+    // MID: the MFMA layout as it is.  Otherwise the rows leave through 16-byte stores, and those want every quad of lanes on 64
+    // contiguous bytes of one row (four rows per quad cost the final epilogue ~20 % more time, measured): one ds_bpermute per value
+    // (lane 4 r + q takes lane 16 q + r, gemm_split_ps.hip) puts row r, columns 4 q.. into lane 4 r + q first.
+    const int r = MID ? (lane_e & 15) : (lane_e >> 2), q = MID ? (lane_e >> 4) : (lane_e & 3);
+    const int perm_addr = ((q << 4) + r) << 2;
+    const int col0 = wn * 32 + q * 4;                    // + t * 192 + (i >> 1) * 64 + (i & 1) * 16
+    const int row0 = panel * FR + wm * 32 + r;           // + m * 16
+    float* red = (float*)(smem + 2 * kSlot);             // [pass][wave][m][row] floats
+    float* gb = (float*)(smem + 2 * kSlot + 4096);       // [gamma 576 | beta 576 | MID: bias 576]
+    const bool ln = MID || (g.ln_out && g.ln_w);
+    const float* bias = (const float*)(smem + kB2Off);
+    const int tl = w * 64 + lane_e;                      // (the thread id, re-derived: see lane_now)
+    if constexpr (MID) {
+      if (tl < 432) ((f32x4*)gb)[tl] = gbv;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      wg_barrier();
+      bias = gb + 2 * kDim;
+    } else {
+      if (ln && tl < 288) gbv = tl < 144 ? ((const f32x4*)g.ln_w)[tl] : ((const f32x4*)g.ln_b)[tl - 144];   // in flight under the row stores
+    }
 #pragma unroll
-      for (int u = 0; u < 12; ++u) {
-        const int m = u / 6, t = (u % 6) >> 1, i0 = (u & 1) * 3;
-        mfma_drain3(acc2[t][i0][m], acc2[t][i0 + 1][m], acc2[t][i0 + 2][m]);
+    for (int u = 0; u < 12; ++u) {
+      const int m = u / 6, t = (u % 6) >> 1, i0 = (u & 1) * 3;
+      mfma_drain3(acc2[t][i0][m], acc2[t][i0 + 1][m], acc2[t][i0 + 2][m]);
 #pragma unroll
-        for (int i = i0; i < i0 + 3; ++i) {
-          f32x4 tv;
+      for (int i = i0; i < i0 + 3; ++i) {
+        f32x4 tv = acc2[t][i][m];
+        if constexpr (!MID) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e)
-            tv[e] = __int_as_float(__builtin_amdgcn_ds_bpermute(perm_addr, __float_as_int(acc2[t][i][m][e])));
-          acc2[t][i][m] = tv;
-          asm volatile("" : "+v"(acc2[t][i][m]));    // pins the group here: register-only instructions are not ordered by
-        }                                            // sched_barrier before instruction selection (they carry no chain)
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      EP(1);
-      // phase B: six groups (row group m, column third t) of six blocks; the residuals of groups u + 1 and u + 2 are in flight
-      // while group u is combined (three buffers of 24 registers: the fc1 accumulators and the fragments are dead here: every
-      // round trip to HBM is ~2 us with all 256 CUs in their epilogues at once); sched_barrier keeps the groups apart
-      f32x4 res[3][6];
-      auto load_res = [&](int u, f32x4 (&r)[6]) {
-        int row = row0 + (u / 3) * 16;
-        if (row >= g.M) row = g.M - 1;          // clamp: the value is never stored
-        const float* rp = g.resid + (size_t)row * g.ldr + col0 + (u % 3) * FC;
-#pragma unroll
-        for (int i = 0; i < 6; ++i) r[i] = *(const f32x4*)(rp + (i >> 1) * 64 + (i & 1) * 16);
-      };
-      if constexpr (RESID) {
-        load_res(0, res[0]);
-        load_res(1, res[1]);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int u = 0; u < 6; ++u) {
-        const int m = u / 3, t = u % 3;
-        if (RESID && u < 4) load_res(u + 2, res[(u + 2) % 3]);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-          const f32x4 bias4 = *(const f32x4*)(b2l + t * FC + (i >> 1) * 64 + (i & 1) * 16);
-          if constexpr (RESID) acc2[t][i][m] = acc2[t][i][m] + res[u % 3][i] + bias4;
-          else acc2[t][i][m] = acc2[t][i][m] + bias4;
-          asm volatile("" : "+v"(acc2[t][i][m]));
+          for (int e = 0; e < 4; ++e) tv[e] = __int_as_float(__builtin_amdgcn_ds_bpermute(perm_addr, __float_as_int(acc2[t][i][m][e])));
         }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      EP(2);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the reads are consumed; the two prefetched stages have landed too)
-      EP(3);
+        acc2[t][i][m] = tv + *(const f32x4*)(bias + col0 + t * FC + (i >> 1) * 64 + (i & 1) * 16);
+        asm volatile("" : "+v"(acc2[t][i][m]));          // pins the group here: register-only instructions carry no order of
+      }                                                  // their own before instruction selection
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    EP(1);
+    if constexpr (!MID) {
 #pragma unroll
       for (int m = 0; m < 2; ++m) {
         const int row = row0 + m * 16;
@@ -442,148 +437,62 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs g) {
             for (int i = 0; i < 6; ++i) *(f32x4*)(op + t * FC + (i >> 1) * 64 + (i & 1) * 16) = acc2[t][i][m];
         }
       }
-      EP(4);
-      if (g.ln_out && lw) {
-        // ---- LayerNorm of the finished rows (model_veto.py:125-132 of the NEXT layer's attention PreNorm) as mixed rows: the
-        // workgroup holds complete rows, so the standalone LayerNorm launch (0.66 GB read + 0.66 GB written) disappears.  A row's
-        // 576 columns sit in the two waves of its row group (wn = 0, 1), 4 lanes x 72 values each: quad reduction by DPP, the two
-        // waves exchange through LDS (the idle activation part of ring slot 2); two passes (mean, then centred squares) like
-        // rowq_stats in rowops.hip.  Both waves add the same two partial sums: identical statistics in either.
-        float* red = (float*)(smem + 2 * kSlot);          // [pass][wave][m][row] floats
-        // gamma / beta go through LDS (behind the same barriers): as global loads inside the normalise loop they would sit behind
-        // the loop's own stores in the wave's one in-order memory queue and wait for every store to drain (measured: 23 k cycles
-        // for the loop, store count and arithmetic notwithstanding)
-        float* gb = (float*)(smem + 2 * kSlot + 4096);    // [gamma 576 | beta 576], requested at the top of the epilogue
-        if (tid < 288) ((f32x4*)gb)[tid] = gbv;
-        float mean[2], rstd[2];
-#pragma unroll
-        for (int pass = 0; pass < 2; ++pass) {
-          float part[2];
-#pragma unroll
-          for (int m = 0; m < 2; ++m) {
-            float p = 0.f;
-#pragma unroll
-            for (int t = 0; t < 3; ++t)
-#pragma unroll
-              for (int i = 0; i < 6; ++i) {
-                if (pass == 0) {
-                  p += (acc2[t][i][m][0] + acc2[t][i][m][1]) + (acc2[t][i][m][2] + acc2[t][i][m][3]);
-                } else {
-#pragma unroll
-                  for (int e = 0; e < 4; ++e) { const float d = acc2[t][i][m][e] - mean[m]; p += d * d; }
-                }
-              }
-            p += __shfl_xor(p, 1, 64);
-            p += __shfl_xor(p, 2, 64);
-            part[m] = p;
-            if (eq == 0) red[((pass * 8 + w) * 2 + m) * 16 + er] = p;
-          }
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          wg_barrier();
-#pragma unroll
-          for (int m = 0; m < 2; ++m) {
-            const float tot = part[m] + red[((pass * 8 + (w ^ 1)) * 2 + m) * 16 + er];
-            if (pass == 0) mean[m] = tot * (1.f / kDim);
-            else rstd[m] = 1.f / sqrtf(tot * (1.f / kDim) + 1e-5f);
-          }
-          EP(5 + pass);
-        }
-#pragma unroll
-        for (int t = 0; t < 3; ++t)
-#pragma unroll
-          for (int i = 0; i < 6; ++i) {
-            const int col = col0 + t * FC + (i >> 1) * 64 + (i & 1) * 16;
-            const f32x4 wv = *(const f32x4*)(gb + col), bv = *(const f32x4*)(gb + kDim + col);
-#pragma unroll
-            for (int m = 0; m < 2; ++m) {
-              const int row = row0 + m * 16;
-              f32x4 y;
-#pragma unroll
-              for (int e = 0; e < 4; ++e) y[e] = (acc2[t][i][m][e] - mean[m]) * rstd[m] * wv[e] + bv[e];
-              if (row < g.M) store_act4<FMT_MIXED>((__bf16*)(g.ln_out + (size_t)row * kRow1), col, y);
-            }
-          }
-        EP(7);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        EP(8);
-      }
     }
-  };
-
-  // ---- MODE 2, middle of a panel.  The accumulators hold x + a Wo^T in the MFMA layout (they started as the residual rows); this
-  // adds the bias (x1 stays in the registers: fc2 accumulates on top of it), computes LayerNorm2 of the rows and writes them as
-  // mixed rows to ln_out, all in the MFMA layout: a row's 576 columns sit in lanes r, r + 16, r + 32, r + 48 of the two waves of
-  // its row group.  Statistics as in the panel epilogue above (two passes, the same two partial sums added in either wave).
-  auto mid_epilogue = [&](f32x4 (&acc2)[3][6][2], int panel, f32x4 gbv) {
-    int lane_e = lane;
-    asm volatile("" : "+v"(lane_e));
-    const int r = lane_e & 15, q = lane_e >> 4;
-    const int col0 = wn * 32 + q * 4;                    // + t * 192 + (i >> 1) * 64 + (i & 1) * 16
-    const int row0 = panel * FR + wm * 32 + r;           // + m * 16
-    float* red = (float*)(smem + 2 * kSlot);             // [pass][wave][m][row] floats (ring slot 2: stage 53 lived there)
-    float* gb = (float*)(smem + 2 * kSlot + 4096);       // [gamma 576 | beta 576 | bias 576]
-    wg_barrier();                                         // every wave has read stage 53
-    if (tid < 432) ((f32x4*)gb)[tid] = gbv;
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    wg_barrier();
+    EP(2);
+    if (ln) {
+      if (!MID && tl < 288) ((f32x4*)gb)[tl] = gbv;    // (published by the barrier of pass 0)
+      float mean[2], rstd[2];
 #pragma unroll
-    for (int u = 0; u < 12; ++u) {
-      const int m = u / 6, t = (u % 6) >> 1, i0 = (u & 1) * 3;
-      mfma_drain3(acc2[t][i0][m], acc2[t][i0 + 1][m], acc2[t][i0 + 2][m]);
-#pragma unroll
-      for (int i = i0; i < i0 + 3; ++i) {
-        acc2[t][i][m] = acc2[t][i][m] + *(const f32x4*)(gb + 2 * kDim + col0 + t * FC + (i >> 1) * 64 + (i & 1) * 16);
-        asm volatile("" : "+v"(acc2[t][i][m]));
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    float mean[2], rstd[2];
-#pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
-      float part[2];
-#pragma unroll
-      for (int m = 0; m < 2; ++m) {
-        float p = 0.f;
-#pragma unroll
-        for (int t = 0; t < 3; ++t)
-#pragma unroll
-          for (int i = 0; i < 6; ++i) {
-            if (pass == 0) {
-              p += (acc2[t][i][m][0] + acc2[t][i][m][1]) + (acc2[t][i][m][2] + acc2[t][i][m][3]);
-            } else {
-#pragma unroll
-              for (int e = 0; e < 4; ++e) { const float d = acc2[t][i][m][e] - mean[m]; p += d * d; }
-            }
-          }
-        p += __shfl_xor(p, 16, 64);
-        p += __shfl_xor(p, 32, 64);
-        part[m] = p;
-        if (q == 0) red[((pass * 8 + w) * 2 + m) * 16 + r] = p;
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      wg_barrier();
-#pragma unroll
-      for (int m = 0; m < 2; ++m) {
-        const float tot = part[m] + red[((pass * 8 + (w ^ 1)) * 2 + m) * 16 + r];
-        if (pass == 0) mean[m] = tot * (1.f / kDim);
-        else rstd[m] = 1.f / sqrtf(tot * (1.f / kDim) + 1e-5f);
-      }
-    }
-#pragma unroll
-    for (int t = 0; t < 3; ++t)
-#pragma unroll
-      for (int i = 0; i < 6; ++i) {
-        const int col = col0 + t * FC + (i >> 1) * 64 + (i & 1) * 16;
-        const f32x4 wv = *(const f32x4*)(gb + col), bv = *(const f32x4*)(gb + kDim + col);
+      for (int pass = 0; pass < 2; ++pass) {
+        float part[2];
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
-          const int row = row0 + m * 16;
-          f32x4 y;
+          float p = 0.f;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) y[e] = (acc2[t][i][m][e] - mean[m]) * rstd[m] * wv[e] + bv[e];
-          if (row < g.M) store_act4<FMT_MIXED>((__bf16*)(g.ln_out + (size_t)row * kRow1), col, y);
+          for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+              if (pass == 0) {
+                p += (acc2[t][i][m][0] + acc2[t][i][m][1]) + (acc2[t][i][m][2] + acc2[t][i][m][3]);
+              } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const float d = acc2[t][i][m][e] - mean[m]; p += d * d; }
+              }
+            }
+          p += __shfl_xor(p, MID ? 16 : 1, 64);
+          p += __shfl_xor(p, MID ? 32 : 2, 64);
+          part[m] = p;
+          if (q == 0) red[((pass * 8 + w) * 2 + m) * 16 + r] = p;
         }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        wg_barrier();
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+          const float tot = part[m] + red[((pass * 8 + (w ^ 1)) * 2 + m) * 16 + r];
+          if (pass == 0) mean[m] = tot * (1.f / kDim);
+          else rstd[m] = 1.f / sqrtf(tot * (1.f / kDim) + 1e-5f);
+        }
+        EP(3 + pass);
       }
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+          const int col = col0 + t * FC + (i >> 1) * 64 + (i & 1) * 16;
+          const f32x4 wv = *(const f32x4*)(gb + col), bv = *(const f32x4*)(gb + kDim + col);
+#pragma unroll
+          for (int m = 0; m < 2; ++m) {
+            const int row = row0 + m * 16;
+            f32x4 y;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[e] = (acc2[t][i][m][e] - mean[m]) * rstd[m] * wv[e] + bv[e];
+            if (row < g.M) store_act4<FMT_MIXED>((__bf16*)(g.ln_out + (size_t)row * kRow1), col, y);
+          }
+        }
+      EP(5);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (the two prefetched stages of the next panel have landed too)
+    EP(6);
   };
 
   for (int it = 0; it < my_panels; ++it) {
@@ -591,14 +500,12 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs g) {
     const int panel = b + it * G;
     const char* a_panel = panel_base(it);
     f32x4 acc2[3][6][2];     // [column third t][block i][row group m]
-    if constexpr (MODE == 2) {
-      // The layer tail's accumulators START as the panel's residual rows, read straight into the MFMA layout (lane 16 q + r holds
-      // row r of its 16-row group, 4 columns at 4 q of every 16-column block): the out projection accumulates on top of x, so
-      // x1 is complete in registers when its last stage ends -- no residual buffers, no lane transposition, and the rows arrive
-      // under the first stages (the compiler sees these loads and waits for each one in front of its first MFMA; the DMA
-      // instructions it does not see are all younger or already drained, which only makes its counts conservative).
-      int lane_r = lane;
-      asm volatile("" : "+v"(lane_r));
+    {
+      // The accumulators START as the panel's residual rows, read straight into the MFMA layout: the GEMMs accumulate on top of x, so
+      // the new residual stream is complete in registers when the last stage ends -- no residual buffers, no lane transposition,
+      // and the rows arrive under the first stages (the compiler sees these loads and waits for each one in front of its first
+      // MFMA; the DMA instructions it does not see are all younger or already drained, which only makes its counts conservative).
+      const int lane_r = lane_now();
       const int r = lane_r & 15, q = lane_r >> 4;
 #pragma unroll
       for (int t = 0; t < 3; ++t)
@@ -614,13 +521,6 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs g) {
         asm volatile("s_waitcnt vmcnt(36)" ::: "memory");   // the prologue's stages 0 and 1 have landed (they are older than the 36 loads)
         skip = 2;
       }
-    } else {
-#pragma unroll
-      for (int t = 0; t < 3; ++t)
-#pragma unroll
-        for (int i = 0; i < 6; ++i)
-#pragma unroll
-          for (int m = 0; m < 2; ++m) acc2[t][i][m] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     f32x4 gbv = f32x4{0.f, 0.f, 0.f, 0.f};   // MODE 2: this thread's 16 bytes of LayerNorm2's gamma | beta | the out-projection bias
     (void)gbv;
@@ -652,7 +552,8 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs g) {
         if constexpr (MODE == 2 && P == 52) {
           // the phase's last DMA instruction is long out: the parameters of the mid-panel epilogue are requested here and drained by
           // the wait of position 53
-          if (tid < 432) gbv = tid < 144 ? ((const f32x4*)g.lnm_w)[tid] : tid < 288 ? ((const f32x4*)g.lnm_b)[tid - 144] : ((const f32x4*)g.bo)[tid - 288];
+          const int tl = w * 64 + lane_now();
+          if (tl < 432) gbv = tl < 144 ? ((const f32x4*)g.lnm_w)[tl] : tl < 288 ? ((const f32x4*)g.lnm_b)[tl - 144] : ((const f32x4*)g.bo)[tl - 288];
         }
         STAMP(t0);
         ACC(s_cmp, t0, t2);
@@ -663,7 +564,7 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs g) {
       // of it); LayerNorm2(x1) goes to ln_out as mixed rows.  Those rows are re-read by this CU's DMA right away, through an L1
       // that may still hold lines of the attention-output rows they replace: stores drained, one L1 invalidate per workgroup.
       STAMP(t0);
-      mid_epilogue(acc2, panel, gbv);
+      epilogue(acc2, panel, Tag<1>(), gbv);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       wg_barrier();
       if (w == 0) {
@@ -748,8 +649,7 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs g) {
           auto valu = [&](int i) {
             if constexpr (CONV) {
               if (i == 0) {
-                int lane_h = lane;
-                asm volatile("" : "+v"(lane_h));
+                const int lane_h = lane_now();
                 const int hr = lane_h & 15, hq = lane_h >> 4;
                 const int ls = wn * 4 + IB * 2 + (hq >> 1);
                 ho = (wm * 32 + MM * 16 + hr) * 128 + ((ls ^ ((hr >> 1) & 7)) << 4) + (hq & 1) * 8;
@@ -785,7 +685,7 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs g) {
     STAMP(t0);
     EP(0);
     if (!(FFN_ABLATE & 16)) {
-      epilogue(acc2, panel, Tag<(MODE == 2 ? 0 : 1)>(), g.ln_w, g.ln_b);
+      epilogue(acc2, panel, Tag<0>(), f32x4{0.f, 0.f, 0.f, 0.f});
       skip = 2;   // stages 0 and 1 of the next panel landed before the drain inside
     } else {
       asm volatile("" ::"v"(acc2[0][0][0]), "v"(acc2[2][5][1]));
@@ -840,8 +740,8 @@ hipError_t launch_panel(FfnArgs g, int mode, hipStream_t s) {
       hipMemcpyFromSymbol(ep, HIP_SYMBOL(g_ffn_epi), sizeof(ep));
       for (int wv = 0; wv < 2; ++wv) {
         fprintf(stderr, "[ffn epilogue] wave %d:", wv * 4);
-        for (int k = 1; k < 9; ++k) fprintf(stderr, " %6lld", (long long)(ep[wv * 12 + k] - ep[wv * 12 + k - 1]));
-        fprintf(stderr, "  (transpose | resid loads+adds | drain | x stores | LN pass 1 | pass 2 | normalise+stores | their drain)\n");
+        for (int k = 1; k < 7; ++k) fprintf(stderr, " %6lld", (long long)(ep[wv * 12 + k] - ep[wv * 12 + k - 1]));
+        fprintf(stderr, "  (bias adds | x stores | LN pass 1 | pass 2 | normalise+stores | drain)\n");
       }
     }
     if (!printed++) {
