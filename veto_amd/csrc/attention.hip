@@ -101,8 +101,10 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 // TAB: layer 0 in the per-object form -- q / k / v of the 16 patch tokens never exist in memory: their chunks are formed on load
 // from the two per-object table rows (L2 / Infinity Cache), the row's rstd and c2 (AttnArgs::sw ...).  (Giving each XCD a
 // contiguous eighth of the items, so that an image's table rows meet in one L2, measured neutral.)
-template <int DH, bool TAB = false>
+// F24: q / k / v arrive as 3-byte floats (common.h): a chunk of 8 values is 24 bytes, and hi + lo of such a value is exact.
+template <int DH, bool TAB = false, bool F24 = false>
 __global__ __launch_bounds__(128) void attention_mfma_kernel(AttnArgs a) {
+  static_assert(!(TAB && F24), "the per-object form reads fp32 tables");
   saturating_conversions_on();   // (the mixed-row output path converts without clamps, common.h)
   constexpr int DHP = (DH + 15) / 16 * 16;  // contraction extent of QK^T (zero padded)
   constexpr int RB = DHP * 2;               // bytes per row of the Q / K images (bf16)
@@ -154,6 +156,12 @@ __global__ __launch_bounds__(128) void attention_mfma_kernel(AttnArgs a) {
       ldb[TAB ? r : 0][0] = *(const f32x4*)(tab_o + off);
       ldb[TAB ? r : 0][1] = *(const f32x4*)(tab_o + off + 4);
       rs[TAB ? r : 0] = a.stats[((size_t)pair * kTokens + i) * 2 + 1];
+    } else if (F24 && need) {
+      // (the six dwords are kept packed in ld[r][0] / the first half of ld[r][1] until the conversion below)
+      const char* src = (const char*)a.qkv + (((size_t)pair * kTokens + i) * (3 * kDim) + mat * kDim + head * DH + c * 8) * 3;
+      const u32x2 d0 = *(const u32x2*)src, d1 = *(const u32x2*)(src + 8), d2 = *(const u32x2*)(src + 16);
+      ld[r][0] = f32x4{__uint_as_float(d0[0]), __uint_as_float(d0[1]), __uint_as_float(d1[0]), __uint_as_float(d1[1])};
+      ld[r][1] = f32x4{__uint_as_float(d2[0]), __uint_as_float(d2[1]), 0.f, 0.f};
     } else if (need) {
       const float* src = TAB && i == 0 ? a.vec + 2 * (3 * kDim) + head * DH + mat * kDim + c * 8
                                        : src0 + (size_t)i * (3 * kDim) + mat * kDim + c * 8;
@@ -174,6 +182,11 @@ __global__ __launch_bounds__(128) void attention_mfma_kernel(AttnArgs a) {
       const f32x4 c20 = *(const f32x4*)c2, c21 = *(const f32x4*)(c2 + 4);
       ld[r][0] = rs[TAB ? r : 0] * (ld[r][0] + ldb[TAB ? r : 0][0]) + c20;
       ld[r][1] = rs[TAB ? r : 0] * (ld[r][1] + ldb[TAB ? r : 0][1]) + c21;
+    }
+    if constexpr (F24) {      // (rows that were not read hold zeros, which unpack to zeros)
+      const f32x4 p0 = ld[r][0], p1 = ld[r][1];
+      ld[r][0] = unpack_f24x4(__float_as_uint(p0[0]), __float_as_uint(p0[1]), __float_as_uint(p0[2]));
+      ld[r][1] = unpack_f24x4(__float_as_uint(p0[3]), __float_as_uint(p1[0]), __float_as_uint(p1[1]));
     }
     bf16x8 hi, lo;
 #pragma unroll
@@ -497,11 +510,14 @@ hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
       if (!a.ow || !a.stats || !a.vec || !a.subj || !a.obj || a.cls_only) return hipErrorInvalidValue;
       if (dh == 72) VETO_LAUNCH((attention_mfma_kernel<72, true>), dim3(blocks), dim3(128), 0, s, a);
       else VETO_LAUNCH((attention_mfma_kernel<96, true>), dim3(blocks), dim3(128), 0, s, a);
+    } else if (a.qkv_f24) {
+      if (dh == 72) VETO_LAUNCH((attention_mfma_kernel<72, false, true>), dim3(blocks), dim3(128), 0, s, a);
+      else VETO_LAUNCH((attention_mfma_kernel<96, false, true>), dim3(blocks), dim3(128), 0, s, a);
     } else if (dh == 72) VETO_LAUNCH(attention_mfma_kernel<72>, dim3(blocks), dim3(128), 0, s, a);
     else VETO_LAUNCH(attention_mfma_kernel<96>, dim3(blocks), dim3(128), 0, s, a);
     return hipGetLastError();
   }
-  if (a.sw) return hipErrorInvalidValue;
+  if (a.sw || a.qkv_f24) return hipErrorInvalidValue;
   if (dh % 4 != 0) return hipErrorInvalidValue;
   const int ldh = dh + 4;
   const size_t lds = (size_t)kWavesPerBlock * (3 * kTokens * ldh + kTokens * 20) * sizeof(float);

@@ -152,6 +152,29 @@ __device__ __forceinline__ void store_act4(__bf16* row, int col, f32x4 v) {
   }
 }
 
+// ---- 3-byte floats ("f24": sign, 8 exponent bits, 15 mantissa bits = the top three bytes of the fp32 rounded to nearest even).
+// q / k / v between the QKV projection and the attention kernel: the attention products split every operand into bf16 hi + bf16 lo
+// (a 16-bit significand), so a 16-bit significand in memory loses nothing the kernel keeps -- hi + lo of an f24 value is exact --
+// and the 2 GB matrix a layer writes and reads back becomes 1.5 GB.  Four values = three dwords.
+typedef __attribute__((ext_vector_type(3))) uint32_t u32x3;
+__device__ __forceinline__ u32x3 pack_f24x4(f32x4 v) {
+  uint32_t u[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const uint32_t b = __float_as_uint(v[e]);
+    u[e] = b + 0x7fu + ((b >> 8) & 1u);            // round to nearest even at bit 8 (the low byte is dropped below)
+  }
+  // bytes, low address first: u0.b1 u0.b2 u0.b3 | u1.b1 u1.b2 u1.b3 | u2.b1 .. | u3.b1 u3.b2 u3.b3   (v_perm_b32: selector byte
+  // values 0..3 pick bytes of the SECOND operand, 4..7 of the first)
+  return u32x3{__builtin_amdgcn_perm(u[1], u[0], 0x05030201u), __builtin_amdgcn_perm(u[2], u[1], 0x06050302u),
+               __builtin_amdgcn_perm(u[3], u[2], 0x07060503u)};
+}
+__device__ __forceinline__ f32x4 unpack_f24x4(uint32_t d0, uint32_t d1, uint32_t d2) {
+  // value e occupies bytes 3e .. 3e+2 of the 12; 0x0c selects a zero byte
+  return f32x4{__uint_as_float(d0 << 8), __uint_as_float(__builtin_amdgcn_perm(d1, d0, 0x0504030cu)),
+               __uint_as_float(__builtin_amdgcn_perm(d2, d1, 0x0403020cu)), __uint_as_float(d2 & 0xffffff00u)};
+}
+
 // 8 consecutive columns (col % 8 == 0) of a mixed activation row: two 16-byte stores
 __device__ __forceinline__ void store_act8_mixed(__bf16* row, int col, f32x4 v0, f32x4 v1) {
   typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;

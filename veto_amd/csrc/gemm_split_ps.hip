@@ -513,6 +513,8 @@ __global__ __launch_bounds__(64 * (NCONS + NLOAD), 3) void gemm_split_ps_kernel(
             for (int e = 0; e < 4; ++e) unsafeAtomicAdd(dstc + e, v[e]);
           } else if (EPI == EPI_RESID) {
             acc[n][m] = v;    // (training, dropout form) stored below, after the last residual load
+          } else if (EPI == EPI_F24) {
+            *(u32x3*)((char*)g.c + ((size_t)row * g.ldc + col) * 3) = pack_f24x4(v);
           } else {
             *(f32x4*)(g.c + (size_t)row * g.ldc + col) = v;
           }
@@ -554,6 +556,7 @@ hipError_t launch_ps_terms(GemmArgs g, int epi, int nblocks, hipStream_t s) {
   if constexpr (NTERMS == 2) {   // inference forms only
     switch (epi) {
       case EPI_F32: VETO_LAUNCH((gemm_split_ps_kernel<2, EPI_F32>), grid, block, 0, s, g); break;
+      case EPI_F24: VETO_LAUNCH((gemm_split_ps_kernel<2, EPI_F24>), grid, block, 0, s, g); break;
       case EPI_RESID: VETO_LAUNCH((gemm_split_ps_kernel<2, EPI_RESID>), grid, block, 0, s, g); break;
       case EPI_GELU_SPLIT: VETO_LAUNCH((gemm_split_ps_kernel<2, EPI_GELU_SPLIT>), grid, block, 0, s, g); break;
       default: return hipErrorInvalidValue;

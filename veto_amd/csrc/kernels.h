@@ -4,7 +4,7 @@
 
 namespace veto {
 
-enum Epi { EPI_F32 = 0, EPI_RESID = 1, EPI_GELU_SPLIT = 2, EPI_ATOMIC = 3, EPI_RESID_DROP = 4 };
+enum Epi { EPI_F32 = 0, EPI_RESID = 1, EPI_GELU_SPLIT = 2, EPI_ATOMIC = 3, EPI_RESID_DROP = 4, EPI_F24 = 5 };   // EPI_F24: EPI_F32 written as 3-byte floats (common.h)
 
 // C[M,N] = A[M,K] . W[N,K]^T with A and W in the split-row format (common.h): rows of 2K bf16.
 struct GemmArgs {
@@ -12,7 +12,7 @@ struct GemmArgs {
   const __bf16* w;     // [N, 2K]
   const float* bias;   // [N] or nullptr
   const float* resid;  // EPI_RESID: row r at resid + r*ldr
-  float* c;            // EPI_F32 / EPI_RESID: row r at c + r*ldc
+  float* c;            // EPI_F32 / EPI_RESID: row r at c + r*ldc; EPI_F24: row r at (char*)c + 3*r*ldc, 3 bytes per element
   __bf16* c_split;     // EPI_GELU_SPLIT: split-row output, row r at c_split + r*ldc (ldc = 2N)
   int M, N, K;
   long lda;            // A row stride in bf16 elements (0 = 2K)
@@ -172,9 +172,10 @@ hipError_t launch_layernorm(const float* x, long ldx, const float* w, const floa
                             hipStream_t s, int fmt = FMT_SPLIT, long ldd = 0);
 
 struct AttnArgs {
-  const float* qkv;        // [n_pair*19, 1728]
+  const float* qkv;        // [n_pair*19, 1728]; qkv_f24: the same matrix as 3-byte floats (rows of 5184 bytes)
   __bf16* o;               // split rows [rows, 2*576]; rows = n_pair*19, or n_pair when cls_only
   int n_pair, heads, cls_only;
+  int qkv_f24 = 0;         // MFMA head widths, not the per-object form
   int o_fmt = FMT_SPLIT;   // operand format of o (MFMA head widths; the generic kernel writes split rows only)
   // layer 0, per-object form (rowops.hip): when sw != nullptr the rows of tokens 1..16 are formed on load as
   // rstd * (sw[subj*16 + t-1] + ow[obj*16 + t-1]) + c2, token 0 is the constant row vec + 2*1728, and only the rows of tokens

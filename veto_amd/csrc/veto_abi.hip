@@ -515,6 +515,7 @@ int veto_forward(veto_handle_t h, void* stream, const veto_inputs_t* in, void* w
   static const bool tail_off = getenv("VETO_TAIL_FUSED") && !strcmp(getenv("VETO_TAIL_FUSED"), "0");        // A/B knob
   const bool tail_fused = !tail_off;   // ... and both of them as ONE launch per layer
   static const bool ffn_ln_off = getenv("VETO_FFN_LN") && !strcmp(getenv("VETO_FFN_LN"), "0");              // A/B knob
+  static const bool qkv_f24_off = getenv("VETO_QKV_F24") && !strcmp(getenv("VETO_QKV_F24"), "0");           // A/B knob
   if (qkv0_tables) {
     const int R = n_obj * 16;
     HIP_TRY(launch_centre_split(ws.patch_tab, ws.ptab_split, R, s));
@@ -550,6 +551,7 @@ int veto_forward(veto_handle_t h, void* stream, const veto_inputs_t* in, void* w
       const LayerW& w = h->layers[l];
       const bool last = (l == L - 1);
       int rc;
+      bool qkv_f24 = false;
       const bool fold = last && fold_last;
       if (fold) {
         // last layer, folded (attention.hip): u = a_0 . Mcat on the CLS rows, per-pair scores / softmax / weighted token means,
@@ -581,8 +583,10 @@ int veto_forward(veto_handle_t h, void* stream, const veto_inputs_t* in, void* w
         }
       } else if (!last) {
         const bool mq = mixed && l > 0;   // layer 0's LayerNorm'ed rows come from token assembly (split rows)
-        rc = run_gemm(h, s, "gemm_qkv", ws.a, mq ? w.qkv_m : w.qkv, nullptr, nullptr, 0, qkv, nullptr, 3 * kDim, M, 3 * kDim, kDim, EPI_F32,
-                      0, 0, DropSite(), mq ? w.exp_m + 0 : nullptr);
+        // q / k / v as 3-byte floats between this GEMM and the attention kernel (common.h; VETO_QKV_F24=0: fp32)
+        qkv_f24 = mq && !qkv_f24_off && attention_reads_tables(H);
+        rc = run_gemm(h, s, "gemm_qkv", ws.a, mq ? w.qkv_m : w.qkv, nullptr, nullptr, 0, qkv, nullptr, 3 * kDim, M, 3 * kDim, kDim,
+                      qkv_f24 ? EPI_F24 : EPI_F32, 0, 0, DropSite(), mq ? w.exp_m + 0 : nullptr);
         if (rc) return rc;
       } else {
         // last layer: keys/values for all 19 tokens, the query for the CLS row of each pair only
@@ -596,6 +600,7 @@ int veto_forward(veto_handle_t h, void* stream, const veto_inputs_t* in, void* w
       if (!fold) {
         AttnArgs a{};
         a.qkv = qkv; a.n_pair = np; a.heads = H; a.cls_only = last ? 1 : 0;
+        a.qkv_f24 = qkv_f24 ? 1 : 0;
         a.o = last ? ws.ac : ws.a;
         a.o_fmt = (!last && mixed_out) ? FMT_MIXED : FMT_SPLIT;
         if (l == 0 && qkv0_tables && attention_reads_tables(H)) {   // q / k / v of the patch tokens are formed on load
