@@ -103,7 +103,7 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 // contiguous eighth of the items, so that an image's table rows meet in one L2, measured neutral.)
 // F24: q / k / v arrive as 3-byte floats (common.h): a chunk of 8 values is 24 bytes, and hi + lo of such a value is exact.
 template <int DH, bool TAB = false, bool F24 = false>
-__global__ __launch_bounds__(128) void attention_mfma_kernel(AttnArgs a) {
+__global__ __launch_bounds__(128, 2) void attention_mfma_kernel(AttnArgs a) {
   static_assert(!(TAB && F24), "the per-object form reads fp32 tables");
   saturating_conversions_on();   // (the mixed-row output path converts without clamps, common.h)
   constexpr int DHP = (DH + 15) / 16 * 16;  // contraction extent of QK^T (zero padded)
@@ -119,12 +119,15 @@ __global__ __launch_bounds__(128) void attention_mfma_kernel(AttnArgs a) {
   static_assert(DH % 8 == 0 && QK_PLANE % 16 == 0 && kTokens * DH * 4 <= 4 * QK_PLANE, "layout");
   __shared__ __attribute__((aligned(16))) char smem[2 * WAVE_LDS];
 
+  // A wave works on its own LDS region: no workgroup barrier anywhere (LDS operations of one wave complete in order; the two
+  // barriers of the first version cost 3 % of the launch).  The launcher normally gives every wave ONE item; with fewer
+  // workgroups than items (VETO_ATTN_BLOCKS_PER_CU, an A/B knob) a wave walks items gw, gw + (waves of the grid), ... and requests
+  // the operands of its next item as soon as the registers of the current one have been converted into the LDS images.
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const long gw = (long)blockIdx.x * 2 + w;
   const long total = (long)a.n_pair * a.heads;
-  const bool active = gw < total;
-  const long item = active ? gw : total - 1;
-  const int pair = (int)(item / a.heads), head = (int)(item % a.heads);
+  const long stride = (long)gridDim.x * 2;
+  if (gw >= total) return;
   char* base = smem + w * WAVE_LDS;
   char* q_hi = base;
   char* q_lo = base + QK_PLANE;
@@ -132,12 +135,14 @@ __global__ __launch_bounds__(128) void attention_mfma_kernel(AttnArgs a) {
   char* k_lo = base + 3 * QK_PLANE;
   char* vt_hi = base + 4 * QK_PLANE;
   char* vt_lo = vt_hi + VT_PLANE;
-  const float* src0 = a.qkv + (size_t)pair * kTokens * (3 * kDim) + head * DH;
 
   // ---- global -> registers (all loads in flight), then -> bf16 hi/lo LDS images ----------------
   f32x4 ld[ROUNDS][2];
   f32x4 ldb[TAB ? ROUNDS : 1][2];     // TAB: the object-side table row of a patch token
   float rs[TAB ? ROUNDS : 1];         // TAB: rstd of the token row
+  auto request = [&](long item) {
+  const int pair = (int)(item / a.heads), head = (int)(item % a.heads);
+  const float* src0 = a.qkv + (size_t)pair * kTokens * (3 * kDim) + head * DH;
   const float* tab_s = nullptr;
   const float* tab_o = nullptr;
   if constexpr (TAB) {
@@ -172,6 +177,10 @@ __global__ __launch_bounds__(128) void attention_mfma_kernel(AttnArgs a) {
       ld[r][1] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
   }
+  };
+  request(gw);
+  for (long item = gw; item < total; item += stride) {
+  const int pair = (int)(item / a.heads), head = (int)(item % a.heads);
 #pragma unroll
   for (int r = 0; r < ROUNDS; ++r) {
     const int e = lane + 64 * r;
@@ -219,7 +228,7 @@ __global__ __launch_bounds__(128) void attention_mfma_kernel(AttnArgs a) {
     *(uint16_t*)(vt_hi + d * VROW + 38) = 0;
     *(uint16_t*)(vt_lo + d * VROW + 38) = 0;
   }
-  __syncthreads();
+  if (!TAB && item + stride < total) request(item + stride);
 
   // ---- S^T = K Q^T: row = key j, column = query i ----------------------------------------------
   const int r = lane & 31, h = lane >> 5;
@@ -303,10 +312,11 @@ __global__ __launch_bounds__(128) void attention_mfma_kernel(AttnArgs a) {
       }
     }
   }
-  __syncthreads();
-  if (!active) return;
   const int nq = a.cls_only ? 1 : kTokens;
-  for (int e = lane; e < nq * CH; e += 64) {
+#pragma unroll
+  for (int e0 = 0; e0 < (kTokens * CH + 63) / 64 * 64; e0 += 64) {     // (a fixed trip count: the compiler can then count the stores
+    const int e = e0 + lane;                                            // that are younger than the prefetched loads)
+    if (e >= nq * CH) continue;
     const int i = e / CH, c = e % CH;
     const f32x4 v0 = *(const f32x4*)(o_lds + i * DH + c * 8);
     const f32x4 v1 = *(const f32x4*)(o_lds + i * DH + c * 8 + 4);
@@ -330,6 +340,8 @@ __global__ __launch_bounds__(128) void attention_mfma_kernel(AttnArgs a) {
     *(bf16x8*)dst = hi;
     *(bf16x8*)(dst + 32) = lo;
   }
+  if constexpr (TAB) break;   // (one item per wave: no loop-carried registers for the compiler to keep)
+  }   // items
 }
 
 
@@ -505,7 +517,20 @@ hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
   const bool force_valu = attn_force_valu();
   if (!force_valu && (dh == 72 || dh == 96)) {
     const long items = (long)a.n_pair * a.heads;
-    const unsigned blocks = (unsigned)((items + 1) / 2);
+    unsigned blocks = (unsigned)((items + 1) / 2);
+    static int num_cu = 0;
+    if (num_cu == 0) {
+      int dev = 0;
+      hipDeviceProp_t prop;
+      if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorInvalidDevice;
+      num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 1;
+    }
+    // VETO_ATTN_BLOCKS_PER_CU=n: persistent waves (n workgroups per CU; four fit the LDS), each prefetching its next item.  Measured
+    // SLOWER than one item per wave (0.94-0.96 vs 0.83-0.86 ms for the two middle-layer launches at n = 4, 1.02 at n = 3): the
+    // hardware dispatcher's refill of finished workgroups spreads the memory phases better than waves that march in step.  Default
+    // 0 = one item per wave (the loop below then runs once).
+    static const int per_cu = getenv("VETO_ATTN_BLOCKS_PER_CU") ? atoi(getenv("VETO_ATTN_BLOCKS_PER_CU")) : 0;
+    if (!a.sw && per_cu > 0 && blocks > (unsigned)(num_cu * per_cu)) blocks = (unsigned)(num_cu * per_cu);
     if (a.sw) {
       if (!a.ow || !a.stats || !a.vec || !a.subj || !a.obj || a.cls_only) return hipErrorInvalidValue;
       if (dh == 72) VETO_LAUNCH((attention_mfma_kernel<72, true>), dim3(blocks), dim3(128), 0, s, a);
