@@ -76,6 +76,7 @@ struct FfnArgs {
   const float* lnm_b;
   int n_panels;          // filled by the launcher
   int stagger;           // filled by the launcher (speed only): start delay of workgroup b = (b & 7) * stagger * s_sleep(32) (~1 us): one phase per XCD
+  int late;              // filled by the launcher (speed only): start delay (~us) of the workgroups that have one panel fewer than the others
 };
 int ffn_panel_rows();
 hipError_t launch_ffn_fused(FfnArgs g, hipStream_t s);
