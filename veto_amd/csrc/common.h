@@ -105,7 +105,9 @@ template <int EXP>
 __device__ __forceinline__ uint32_t pack_e4m3x4_scaled(float a, float b, float c, float d) {
   typedef short v2s __attribute__((ext_vector_type(2)));
   constexpr float lim = 448.f / (float)(1 << EXP), inv = 1.f / (float)(1 << EXP);
-  v2s r = {0, 0};
+  int any;                                  // (both halves are written below: no instruction to initialise the register)
+  asm("" : "=v"(any));
+  v2s r = __builtin_bit_cast(v2s, any);
 #if VETO_FP16_OVFL
   (void)lim;
   r = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(r, a, b, inv, false);
@@ -121,6 +123,22 @@ __host__ __device__ __forceinline__ int mixed_h_offset(int k) { return ((k >> 6)
 __host__ __device__ __forceinline__ int mixed_x_offset(int k) { return ((k >> 6) << 8) + 128 + (((k & 63) >> 2) << 3) + (k & 3); }
 typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+
+// The mixed-row image of 4 consecutive activation values: h = their fp16 (two dwords), xy = {e4m3 X of the fp16 residual, e4m3 Y
+// of the value}.  The residual v - float(h) comes from v_fma_mix_f32 (fp16 operand read in place, exact result) instead of a
+// conversion back and a subtraction: 12 instructions per 4 values instead of 16 -- the producers of mixed rows are VALU-bound.
+__device__ __forceinline__ void mixed_pack4(f32x4 v, u32x2& h, u32x2& xy) {
+  float l[4];
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    uint32_t hp;
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hp) : "v"(v[2 * p]), "v"(v[2 * p + 1]));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l[2 * p]) : "v"(hp), "v"(v[2 * p]));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(l[2 * p + 1]) : "v"(hp), "v"(v[2 * p + 1]));
+    h[p] = hp;
+  }
+  xy = u32x2{pack_e4m3x4_scaled<kMixActExp>(l[0], l[1], l[2], l[3]), pack_e4m3x4_scaled<kMixActHiExp>(v[0], v[1], v[2], v[3])};
+}
 
 // 4 consecutive columns (col % 4 == 0) of an ACTIVATION row in either operand format; `row` = first byte of the row
 template <int FMT>
@@ -139,16 +157,10 @@ __device__ __forceinline__ void store_act4(__bf16* row, int col, f32x4 v) {
     *(bf16x4*)(d + 32) = lo;
   } else {
     char* base = (char*)row;
-    f16x4 h;
-    float l[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      h[e] = (_Float16)v[e];
-      l[e] = v[e] - (float)h[e];
-    }
-    *(f16x4*)(base + mixed_h_offset(col)) = h;
-    *(u32x2*)(base + mixed_x_offset(col)) = u32x2{pack_e4m3x4_scaled<kMixActExp>(l[0], l[1], l[2], l[3]),
-                                                  pack_e4m3x4_scaled<kMixActHiExp>(v[0], v[1], v[2], v[3])};
+    u32x2 h, xy;
+    mixed_pack4(v, h, xy);
+    *(u32x2*)(base + mixed_h_offset(col)) = h;
+    *(u32x2*)(base + mixed_x_offset(col)) = xy;
   }
 }
 
@@ -177,20 +189,12 @@ __device__ __forceinline__ f32x4 unpack_f24x4(uint32_t d0, uint32_t d1, uint32_t
 
 // 8 consecutive columns (col % 8 == 0) of a mixed activation row: two 16-byte stores
 __device__ __forceinline__ void store_act8_mixed(__bf16* row, int col, f32x4 v0, f32x4 v1) {
-  typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
   char* base = (char*)row;
-  f16x8_t h;
-  float l[8], y[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const float x = e < 4 ? v0[e] : v1[e - 4];
-    h[e] = (_Float16)x;
-    l[e] = x - (float)h[e];
-    y[e] = x;
-  }
-  *(f16x8_t*)(base + mixed_h_offset(col)) = h;
-  *(u32x4*)(base + mixed_x_offset(col)) = u32x4{pack_e4m3x4_scaled<kMixActExp>(l[0], l[1], l[2], l[3]), pack_e4m3x4_scaled<kMixActHiExp>(y[0], y[1], y[2], y[3]),
-                                                pack_e4m3x4_scaled<kMixActExp>(l[4], l[5], l[6], l[7]), pack_e4m3x4_scaled<kMixActHiExp>(y[4], y[5], y[6], y[7])};
+  u32x2 h0, h1, xy0, xy1;
+  mixed_pack4(v0, h0, xy0);
+  mixed_pack4(v1, h1, xy1);
+  *(u32x4*)(base + mixed_h_offset(col)) = u32x4{h0[0], h0[1], h1[0], h1[1]};
+  *(u32x4*)(base + mixed_x_offset(col)) = u32x4{xy0[0], xy0[1], xy1[0], xy1[1]};
 }
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -225,6 +229,24 @@ __device__ __forceinline__ float gelu_sigmoid(float x) {
   p = fmaf(p, x2, -2.3021585941314697f);
   const float e = __builtin_amdgcn_exp2f(p * xc);             // exp(-g(x)), <= 2^23
   return x * __builtin_amdgcn_rcpf(1.0f + e);
+}
+
+// Two values at a time on the packed fp32 instructions (v_pk_mul / v_pk_fma / v_pk_add: two lanes' worth of work per issue slot);
+// same operations in the same order as gelu_sigmoid, so the results are bit-identical.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 gelu_sigmoid2(f32x2 x) {
+  const f32x2 xc = {__builtin_amdgcn_fmed3f(x[0], -6.f, 6.f), __builtin_amdgcn_fmed3f(x[1], -6.f, 6.f)};
+  const f32x2 x2 = xc * xc;
+  auto both = [](float c) { return f32x2{c, c}; };
+  f32x2 p = both(1.3906235096783348e-07f);
+  p = __builtin_elementwise_fma(p, x2, both(-7.393736268568318e-06f));
+  p = __builtin_elementwise_fma(p, x2, both(0.000129951280541718f));
+  p = __builtin_elementwise_fma(p, x2, both(0.00019161769887432456f));
+  p = __builtin_elementwise_fma(p, x2, both(-0.10496557503938675f));
+  p = __builtin_elementwise_fma(p, x2, both(-2.3021585941314697f));
+  const f32x2 t = p * xc;
+  const f32x2 d = both(1.0f) + f32x2{__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+  return x * f32x2{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
 }
 
 // Counter-based dropout mask (training path): element `idx` of dropout site `seed` is kept iff the top 24 bits of a

@@ -46,6 +46,9 @@
 #ifndef FFN_PRIO
 #define FFN_PRIO 0          // 1: s_setprio 1 for waves 4..7 (the younger wave of every SIMD loses the issue arbitration otherwise)
 #endif
+#ifndef FFN_CONV_G0
+#define FFN_CONV_G0 0       // first of the three MFMA groups of a sub-stage that carry a piece of the hidden conversion (0..3)
+#endif
 #ifndef FFN_DMA_EARLY
 #define FFN_DMA_EARLY 1     // DMA instructions issued before the first MFMA group of a stage (the rest follow groups 0, 1, ...)
 #endif
@@ -323,22 +326,16 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs g) {
     // every value is converted first, the eight LDS stores follow in one run behind a scheduling fence: the compiler merges the
     // two row groups of a block into one ds_write2st64_b64 and, left alone, overwrites its last data register in the very next
     // instruction (measured: exactly those two fp16 values of row group 1 reached the LDS corrupted)
-    f16x4 hh[2][2];
+    u32x2 hh[2][2];
     u32x2 xy[2][2];
 #pragma unroll
     for (int ib = 0; ib < 2; ++ib) {
       const f32x4 bias = *(const f32x4*)(smem + kB1Off + (c * FC + J * 64 + wn * 32 + ib * 16 + hq * 4) * 4);
 #pragma unroll
       for (int m = 0; m < 2; ++m) {
-        f32x4 v = acc1[2 * J + ib][m] + bias;
-        float l[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          v[e] = gelu_sigmoid(v[e]);
-          hh[ib][m][e] = (_Float16)v[e];
-          l[e] = v[e] - (float)hh[ib][m][e];
-        }
-        xy[ib][m] = u32x2{pack_e4m3x4_scaled<kMixActExp>(l[0], l[1], l[2], l[3]), pack_e4m3x4_scaled<kMixActHiExp>(v[0], v[1], v[2], v[3])};
+        const f32x4 v = acc1[2 * J + ib][m] + bias;
+        const f32x2 g0 = gelu_sigmoid2(f32x2{v[0], v[1]}), g1 = gelu_sigmoid2(f32x2{v[2], v[3]});
+        mixed_pack4(f32x4{g0[0], g0[1], g1[0], g1[1]}, hh[ib][m], xy[ib][m]);
       }
     }
 #pragma unroll
@@ -352,7 +349,7 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs g) {
       const int ho = (wm * 32 + hr) * 128 + ((ls ^ ((hr >> 1) & 7)) << 4) + (hq & 1) * 8;
 #pragma unroll
       for (int m = 0; m < 2; ++m) {
-        *(f16x4*)(smem + hid_f16(J) + ho + m * 2048) = hh[ib][m];
+        *(u32x2*)(smem + hid_f16(J) + ho + m * 2048) = hh[ib][m];
         *(u32x2*)(smem + hid_e4m3(J) + ho + m * 2048) = xy[ib][m];
       }
     }
@@ -479,19 +476,41 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs g) {
         }
         EP(3 + pass);
       }
+      // (one 64-bit row pointer per row group, computed here: inside the loop the compiler re-derived it per store from a 64-bit
+      // multiply; every column offset below is a compile-time constant that folds into the store's immediate)
+      typedef __attribute__((address_space(1))) char gchar_t;          // (explicitly global: a pointer that went through an asm is generic)
+      typedef __attribute__((address_space(1))) u32x2 gu32x2_t;
+      gchar_t* lrow[2];
+      f32x2 nmean[2], rstd2[2];
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        nmean[m] = f32x2{-mean[m], -mean[m]};      // both statistics as register PAIRS: operands of the packed instructions as they are
+        rstd2[m] = f32x2{rstd[m], rstd[m]};
+        asm volatile("" : "+v"(nmean[m]), "+v"(rstd2[m]));   // (also keeps the compiler from carrying the 144 differences x - mean of
+                                                             // pass 2 into the loop below: it did, and spilled them)
+        const int row = row0 + m * 16;
+        lrow[m] = (gchar_t*)(g.ln_out + (size_t)(row < g.M ? row : g.M - 1) * kRow1 + mixed_h_offset(col0));
+        asm volatile("" : "+v"(lrow[m]));
+      }
 #pragma unroll
       for (int t = 0; t < 3; ++t)
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
-          const int col = col0 + t * FC + (i >> 1) * 64 + (i & 1) * 16;
+          const int cofs = t * FC + (i >> 1) * 64 + (i & 1) * 16;         // column offset: a multiple of 16, so inside a 64-column block
+          const int col = col0 + cofs;
           const f32x4 wv = *(const f32x4*)(gb + col), bv = *(const f32x4*)(gb + kDim + col);
 #pragma unroll
           for (int m = 0; m < 2; ++m) {
-            const int row = row0 + m * 16;
-            f32x4 y;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) y[e] = (acc2[t][i][m][e] - mean[m]) * rstd[m] * wv[e] + bv[e];
-            if (row < g.M) store_act4<FMT_MIXED>((__bf16*)(g.ln_out + (size_t)row * kRow1), col, y);
+            const f32x4 xv = acc2[t][i][m];                                     // (packed fp32 instructions; same operations per element as before)
+            const f32x2 ylo = (f32x2{xv[0], xv[1]} + nmean[m]) * rstd2[m] * f32x2{wv[0], wv[1]} + f32x2{bv[0], bv[1]};
+            const f32x2 yhi = (f32x2{xv[2], xv[3]} + nmean[m]) * rstd2[m] * f32x2{wv[2], wv[3]} + f32x2{bv[2], bv[3]};
+            const f32x4 y = {ylo[0], ylo[1], yhi[0], yhi[1]};
+            u32x2 h, xy;
+            mixed_pack4(y, h, xy);
+            if (row0 + m * 16 < g.M) {
+              *(gu32x2_t*)(lrow[m] + mixed_h_offset(cofs)) = h;       // (col0 < 48 is a multiple of 4 and cofs % 64 is 0 or 16: both byte
+              *(gu32x2_t*)(lrow[m] + mixed_x_offset(cofs)) = xy;      // offsets of column col0 + cofs are those of cofs plus 2 col0)
+            }
           }
         }
       EP(5);
@@ -660,21 +679,18 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs g) {
                 ho = (wm * 32 + MM * 16 + hr) * 128 + ((ls ^ ((hr >> 1) & 7)) << 4) + (hq & 1) * 8;
                 pre = acc1[2 * (J + 1) + IB][MM] + *(const f32x4*)(smem + kB1Off + (c * FC + (J + 1) * 64 + wn * 32 + IB * 16 + hq * 4) * 4);
               }
-              if (i < 4) {
-                gv[i] = gelu_sigmoid(pre[i]);
-                asm volatile("" : "+v"(gv[i]));      // pins the piece in its group (register-only code carries no order of its own)
+              if (i == FFN_CONV_G0 || i == FFN_CONV_G0 + 1) {          // two values per group on the packed fp32 instructions
+                const int k = 2 * (i - FFN_CONV_G0);
+                const f32x2 g2 = gelu_sigmoid2(f32x2{pre[k], pre[k + 1]});
+                gv[k] = g2[0];
+                gv[k + 1] = g2[1];
+                asm volatile("" : "+v"(gv[k]), "+v"(gv[k + 1]));   // pins the piece in its group (register-only code carries no order of its own)
               }
-              if (i == 4) {
-                f16x4 h;
-                float l[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                  h[e] = (_Float16)gv[e];
-                  l[e] = gv[e] - (float)h[e];
-                }
-                u32x2 xy = u32x2{pack_e4m3x4_scaled<kMixActExp>(l[0], l[1], l[2], l[3]), pack_e4m3x4_scaled<kMixActHiExp>(gv[0], gv[1], gv[2], gv[3])};
+              if (i == FFN_CONV_G0 + 2) {
+                u32x2 h, xy;
+                mixed_pack4(gv, h, xy);
                 asm volatile("" : "+v"(h), "+v"(xy));
-                *(f16x4*)(smem + hid_f16(J + 1) + ho) = h;
+                *(u32x2*)(smem + hid_f16(J + 1) + ho) = h;
                 *(u32x2*)(smem + hid_e4m3(J + 1) + ho) = xy;
               }
             }
