@@ -1,12 +1,20 @@
-// Fused FeedForward of the VETO relation transformer (model_veto.py:137-143 with the residual of :21):
+// The 128-row panel kernel of the VETO relation transformer: everything of a layer behind its attention on full rows.
 //
-//   x <- x + W2 . gelu(W1 . a + b1) + b2        a = LayerNorm2(x) as mixed rows (common.h), W1 [1152, 576], W2 [576, 1152]
+//   MODE 2 (layer tail, the default path)   x1 = x + a Wo^T + bo                (model_veto.py:96 and the residual of :20)
+//                                           x  <- x1 + W2 gelu(W1 LN2(x1) + b1) + b2   (:125-132, :137-143, residual of :21)
+//                                           + LayerNorm1 of the NEXT layer's attention written as that layer's QKV operand
+//   MODE 0 (VETO_TAIL_FUSED=0)              the FeedForward alone:  x <- x + W2 gelu(W1 a + b1) + b2,  a = LayerNorm2(x)
+//   MODE 1 (VETO_TAIL_FUSED=0)              the out projection + residual (+ LayerNorm2 rows) alone
 //
-// in ONE launch: the 1152-wide hidden activation never leaves the CU (the two-launch form writes it to HBM as a 1.3 GB
-// mixed-row matrix and reads it back).  VETO_MIXED operands only (fp16 main product + e4m3 correction terms).
+// in ONE launch: neither x1, nor the LayerNorm statistics, nor the 1152-wide hidden activation leaves the CU (the launch-per-Linear
+// form wrote the hidden activation to HBM as a 1.3 GB matrix and read it back, and had two LayerNorm launches per layer).
+// VETO_MIXED operands only (fp16 main product + e4m3 correction terms, common.h): a, W1 [1152, 576], W2 [576, 1152], Wo [576, 576]
+// as mixed rows.
 //
 // One persistent workgroup per CU, 8 waves at two waves per SIMD (<= 256 registers), walks 128-row panels.  Per panel the
-// [128 x 576] fp32 result stays in registers (144 per lane) while the hidden dimension is walked in 6 chunks of 192 columns:
+// [128 x 576] fp32 result stays in registers (144 per lane): it STARTS as the residual rows, the out projection (MODE 1 / 2: 18
+// k-slices x 3 column thirds) accumulates on top, the mid-panel epilogue (MODE 2) adds the bias, writes LayerNorm2 of the rows as
+// the FeedForward's input and leaves x1 where it is, and the hidden dimension is walked in 6 chunks of 192 columns:
 //
 //   fc1 phase   18 stages (9 blocks of 64 k's x {fp16 part, e4m3 part}): [128 x 192] += a[128, stage] . W1[chunk, stage]^T,
 //               48 accumulator registers per lane
@@ -14,20 +22,21 @@
 //               LDS image (same layout as a DMA'd activation stage), then 6 sub-stages {fp16, e4m3} x 3 column thirds of
 //               W2[third, block]: [128 x 192 of 576] += hidden[128, 64] . W2^T
 //
-// Wave (wm, wn) = (w >> 2, w & 3) owns rows 64 wm .. 64 wm + 63 and, of every 64-column group of a stage's weight rows, the 16
-// columns 16 wn ..: its 16-column block j of a chunk is the hidden units 64 j + 16 wn .., so that the hidden block j the fc2
-// phase consumes is complete as soon as every wave has converted ITS block j, and lies in natural k order (no weight
-// re-layout: the kernel reads the same fc1 / fc2 mixed weight rows as the two-launch form).
+// Wave (wm, wn) = (w >> 1, w & 1) of 4 x 2 owns rows 32 wm .. 32 wm + 31 and, of every 64 weight rows of a stage, the 32 at
+// 32 wn: the hidden units 64 j + 32 wn .. of block j of a chunk, so that the hidden block j the fc2 phase consumes is complete as
+// soon as every wave has converted ITS part, and lies in natural k order (no weight re-layout: the kernel reads the same mixed
+// weight rows as the launch-per-Linear form).
 //
 // Every stage is 128 bytes of every row, exactly as in gemm_split_ps.hip: LDS-DMA (global_load_lds_dwordx4) with the
 // source-side XOR swizzle, conflict-free ds_read_b128 fragments, MFMA issued with the weights as the A operand.  There are
 // no loader waves (twelve waves would cap the kernel at 168 registers): every wave issues its share of the DMA of stage T + 2
-// at the start of interval T (5 instructions for an fc1 stage: 16 KiB of activations + 24 KiB of W1; 3 for an fc2 sub-stage:
+// during interval T (5 instructions for an fc1 stage: 16 KiB of activations + 24 KiB of W1; 3 for an fc2 sub-stage:
 // 24 KiB of W2) into a ring of three 40 KiB slots; one s_barrier per interval.
 //
 // Results depend on the row alone (fixed k order, no split-K): bit-identical under batch / chunk / permutation changes.
 //
-// -DVETO_FFN_STAMPS builds a diagnostic copy that accumulates s_memtime deltas per phase.
+// -DVETO_FFN_STAMPS builds a diagnostic copy that accumulates s_memtime deltas per phase; tools/ffn_asm_stats.py and
+// tools/audit_ffn_asm.py check the generated code (spills, compiler waits, hazards around the inline-asm MFMAs).
 #include "common.h"
 #include "kernels.h"
 
