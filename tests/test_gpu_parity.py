@@ -883,13 +883,19 @@ def test_restructured_first_and_last_layer_match_the_plain_path(tmp_path):
             "                roi_depth_features=torch.from_numpy(batch['roi_depth_features']).to(dev))\n"
             "np.save(sys.argv[1], torch.cat(list(out[1])).cpu().numpy())\n") % (root, os.path.join(root, "tests"))
     outs = []
-    for tag, env in (("default", {}), ("plain", {"VETO_QKV0_TABLES": "0", "VETO_CLS_FOLD": "0"})):
+    # ... and the forms behind the other knobs of the default (mixed) path: the folded last layer with its products as two dense
+    # GEMMs instead of four block-structured ones, fp32 q / k / v instead of 3-byte floats, one launch per panel phase
+    variants = (("default", {}), ("plain", {"VETO_QKV0_TABLES": "0", "VETO_CLS_FOLD": "0"}),
+                ("round2-forms", {"VETO_FOLD_BLOCKS": "0", "VETO_QKV_F24": "0", "VETO_TAIL_FUSED": "0", "VETO_FFN_LATE": "0"}))
+    for tag, env in variants:
         path = str(tmp_path / (tag + ".npy"))
         subprocess.run([sys.executable, "-c", code, path], check=True, env=dict(os.environ, **env), timeout=600)
         outs.append(np.load(path))
     g, _, _ = load_golden("predcls_n36_l4h8")
-    assert np.abs(outs[0] - outs[1]).max() < 1e-4
-    assert np.abs(outs[0] - g["rel_dists"]).max() <= LOGIT_TOL and np.abs(outs[1] - g["rel_dists"]).max() <= LOGIT_TOL
+    for o in outs[1:]:
+        assert np.abs(outs[0] - o).max() < 1e-4
+    for o in outs:
+        assert np.abs(o - g["rel_dists"]).max() <= LOGIT_TOL
 
 
 def test_oracle_parity_large_feature_scale():

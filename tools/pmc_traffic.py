@@ -19,7 +19,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # launches of gemm_split_ps_kernel inside one forward step of the L4 / mixed workload, in order (round 3: the FeedForward
 # Linears of the three full layers are the ffn_fused_kernel launches, labelled by kernel name below)
 GEMM_ORDER_L4 = ["gemm_patch", "gemm_qkv0_tab", "gemm_qkv0_tab", "gemm_qkv0_lc", "gemm_qkv0_lc", "gemm_qkv", "gemm_qkv",
-                 "gemm_u_cls", "gemm_out_cls", "gemm_fc1_cls", "gemm_fc2_cls"]
+                 "gemm_q_cls", "gemm_u_cls", "gemm_v_cls", "gemm_out_cls", "gemm_fc1_cls", "gemm_fc2_cls"]
 
 
 def load(d):

@@ -12,8 +12,11 @@ ORDER_L4_UNFUSED = ["gemm_patch", "gemm_qkv0_tab (S)", "gemm_qkv0_tab (O)", "gem
                     "gemm_fc2", "gemm_qkv", "gemm_out", "gemm_fc1", "gemm_fc2", "gemm_qkv", "gemm_out", "gemm_fc1", "gemm_fc2", "gemm_u_cls",
                     "gemm_out_cls", "gemm_fc1_cls", "gemm_fc2_cls"]
 # round 3 (VETO_MIXED): the FeedForward Linears of the three full layers run in ffn_fused_kernel (listed separately below)
+ORDER_L4_PRODUCTS = ["gemm_patch", "gemm_qkv0_tab (S)", "gemm_qkv0_tab (O)", "gemm_qkv0_lc (t17)", "gemm_qkv0_lc (t18)", "gemm_qkv", "gemm_qkv",
+                     "gemm_u_cls", "gemm_out_cls", "gemm_fc1_cls", "gemm_fc2_cls"]
+# ... and the folded last layer runs its two products as four block-structured GEMMs (VETO_FOLD_BLOCKS=0: the list above)
 ORDER_L4 = ["gemm_patch", "gemm_qkv0_tab (S)", "gemm_qkv0_tab (O)", "gemm_qkv0_lc (t17)", "gemm_qkv0_lc (t18)", "gemm_qkv", "gemm_qkv",
-            "gemm_u_cls", "gemm_out_cls", "gemm_fc1_cls", "gemm_fc2_cls"]
+            "gemm_q_cls", "gemm_u_cls", "gemm_v_cls", "gemm_out_cls", "gemm_fc1_cls", "gemm_fc2_cls"]
 
 
 def main(path):
@@ -40,7 +43,7 @@ def main(path):
     for s in steps:
         for i, (inst, us) in enumerate(s):
             acc[(i, inst)].append(us)
-    order = ORDER_L4 if n == len(ORDER_L4) else ORDER_L4_UNFUSED if n == len(ORDER_L4_UNFUSED) else None
+    order = next((o for o in (ORDER_L4, ORDER_L4_PRODUCTS, ORDER_L4_UNFUSED) if n == len(o)), None)
     print("%d forward steps, %d GEMM launches each (4-layer order: %s)" % (len(steps), n, "yes" if order else "n/a"))
     if ffn:
         print("  ffn_fused_kernel<0> (FeedForward): %d launches, mean %8.1f us  (min %8.1f, max %8.1f)" % (len(ffn), sum(ffn) / len(ffn), min(ffn), max(ffn)))

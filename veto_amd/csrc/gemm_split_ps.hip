@@ -132,7 +132,7 @@ __global__ __launch_bounds__(64 * (NCONS + NLOAD), 3) void gemm_split_ps_kernel(
   const int out_tiles = g.tiles_m * g.tiles_n;
   const int ntiles = out_tiles * ksp;        // split-K: (k range, output tile), output tile fastest
   const int K = g.K;
-  const int nk = K / BK / ksp;               // k-steps per tile
+  const int nk = g.kb_tiles > 0 ? g.kb_steps : K / BK / ksp;   // k-steps per tile (block-diagonal weights: the steps of the tile's block)
   // tile of round `it` for this workgroup; gridDim.x is a multiple of 8 (launcher)
   const int per_xcd = gridDim.x >> 3;
   // g.panel_major (A/B, speed only): a workgroup walks the tiles_n tiles of ONE row panel back to back (panels dealt like tiles)
@@ -188,9 +188,10 @@ __global__ __launch_bounds__(64 * (NCONS + NLOAD), 3) void gemm_split_ps_kernel(
       }
     }
     auto setupA = [&](int tile) {
-      const int k0 = (tile / out_tiles) * nk;   // first k-step of this tile's range
+      int k0 = (tile / out_tiles) * nk;   // first k-step of this tile's range
       tile %= out_tiles;
       const int tile_m = tile / g.tiles_n;
+      if (g.kb_tiles > 0) k0 = ((tile % g.tiles_n) / g.kb_tiles) * nk;
       if constexpr (TN) {
         tnA = (const char*)g.a + (size_t)tile_m * (BM * 4);
         tn_rowA = k0 * BK;
@@ -205,9 +206,10 @@ __global__ __launch_bounds__(64 * (NCONS + NLOAD), 3) void gemm_split_ps_kernel(
       }
     };
     auto setupW = [&](int tile) {
-      const int k0 = (tile / out_tiles) * nk;
+      int k0 = (tile / out_tiles) * nk;
       tile %= out_tiles;
       const int tile_n = tile % g.tiles_n;
+      if (g.kb_tiles > 0) k0 = (tile_n / g.kb_tiles) * nk;
       if constexpr (TN) {
         tnW = (const char*)g.w + (size_t)tile_n * (BN * 4);
         tn_rowW = k0 * BK;
@@ -503,9 +505,11 @@ __global__ __launch_bounds__(64 * (NCONS + NLOAD), 3) void gemm_split_ps_kernel(
               v[e] = dropout_keep(g.drop_seed, (unsigned long long)row * g.N + col + e, g.drop_thresh) ? v[e] * g.drop_scale : 0.f;
           }
           if (EPI == EPI_RESID) v += res[u & 1][j];
-          if (EPI == EPI_GELU_SPLIT) {   // the operand format of the next GEMM = this one's
+          if (EPI == EPI_GELU_SPLIT || EPI == EPI_SPLIT) {   // the operand format of the next GEMM = this one's
+            if (EPI == EPI_GELU_SPLIT) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = gelu_sigmoid(v[e]);
+              for (int e = 0; e < 4; ++e) v[e] = gelu_sigmoid(v[e]);
+            }
             store_act4<kMixed ? FMT_MIXED : FMT_SPLIT>(g.c_split + (size_t)row * g.ldc, col, v);
           } else if (EPI == EPI_ATOMIC) {
             float* dstc = g.c + (size_t)row * g.ldc + col;
@@ -567,6 +571,7 @@ hipError_t launch_ps_terms(GemmArgs g, int epi, int nblocks, hipStream_t s) {
     case EPI_F32: VETO_LAUNCH((gemm_split_ps_kernel<NTERMS, EPI_F32>), grid, block, 0, s, g); break;
     case EPI_RESID: VETO_LAUNCH((gemm_split_ps_kernel<NTERMS, EPI_RESID>), grid, block, 0, s, g); break;
     case EPI_GELU_SPLIT: VETO_LAUNCH((gemm_split_ps_kernel<NTERMS, EPI_GELU_SPLIT>), grid, block, 0, s, g); break;
+    case EPI_SPLIT: VETO_LAUNCH((gemm_split_ps_kernel<NTERMS, EPI_SPLIT>), grid, block, 0, s, g); break;
     case EPI_ATOMIC:
       if (g.tn) VETO_LAUNCH((gemm_split_ps_kernel<NTERMS, EPI_ATOMIC, true>), grid, block, 0, s, g);
       else VETO_LAUNCH((gemm_split_ps_kernel<NTERMS, EPI_ATOMIC>), grid, block, 0, s, g);
@@ -607,6 +612,9 @@ hipError_t launch_gemm_split_ps(GemmArgs g, int epi, int precision, hipStream_t 
   g.panel_major = (panel_major == 1 && g.tiles_n == 3 && epi == EPI_RESID) ? 1
                   : (panel_major == 2 && g.tiles_n % 2 == 0 && g.tiles_n >= 4 && ksp == 1 && !g.tn) ? 2 : 0;
   if ((g.K / BK) % ksp != 0) return hipErrorInvalidValue;
+  if (g.kb_tiles > 0 && (ksp != 1 || g.tn || g.fmt == FMT_MIXED || g.kb_steps <= 0 || g.tiles_n % g.kb_tiles != 0 ||
+                         (g.tiles_n / g.kb_tiles) * g.kb_steps != g.K / BK))
+    return hipErrorInvalidValue;
   if (g.tn && (epi != EPI_ATOMIC || !g.zero || g.lda <= 0 || g.ldw <= 0 || g.k_valid <= 0 || g.k_valid > g.K)) return hipErrorInvalidValue;
   const int ntiles = g.tiles_m * g.tiles_n * ksp;
   int nblocks = num_cu;  // one persistent workgroup per CU (LDS: 112 KiB each)

@@ -4,7 +4,7 @@
 
 namespace veto {
 
-enum Epi { EPI_F32 = 0, EPI_RESID = 1, EPI_GELU_SPLIT = 2, EPI_ATOMIC = 3, EPI_RESID_DROP = 4, EPI_F24 = 5 };   // EPI_F24: EPI_F32 written as 3-byte floats (common.h)
+enum Epi { EPI_F32 = 0, EPI_RESID = 1, EPI_GELU_SPLIT = 2, EPI_ATOMIC = 3, EPI_RESID_DROP = 4, EPI_F24 = 5, EPI_SPLIT = 6 };   // EPI_F24: EPI_F32 written as 3-byte floats (common.h); EPI_SPLIT: split rows, no activation
 
 // C[M,N] = A[M,K] . W[N,K]^T with A and W in the split-row format (common.h): rows of 2K bf16.
 struct GemmArgs {
@@ -13,7 +13,7 @@ struct GemmArgs {
   const float* bias;   // [N] or nullptr
   const float* resid;  // EPI_RESID: row r at resid + r*ldr
   float* c;            // EPI_F32 / EPI_RESID: row r at c + r*ldc; EPI_F24: row r at (char*)c + 3*r*ldc, 3 bytes per element
-  __bf16* c_split;     // EPI_GELU_SPLIT: split-row output, row r at c_split + r*ldc (ldc = 2N)
+  __bf16* c_split;     // EPI_GELU_SPLIT / EPI_SPLIT: split-row output, row r at c_split + r*ldc (ldc = 2N)
   int M, N, K;
   long lda;            // A row stride in bf16 elements (0 = 2K)
   long ldr;
@@ -35,6 +35,10 @@ struct GemmArgs {
   // fmt == FMT_MIXED (common.h): a and w are mixed rows (fp16 + e4m3), w_exp points to the weight tensor's e4m3 exponent
   // on the device, and an EPI_GELU_SPLIT output is written as mixed rows too.  Inference forms only (no tn / split-K).
   int fmt;
+  // Block-diagonal weights (kb_tiles > 0; split rows, no split-K, not tn): column tile n multiplies only the k-steps
+  // [(n / kb_tiles) * kb_steps, + kb_steps) of the rows -- the products of the folded last layer (veto_abi.hip) are block-diagonal
+  // over the heads, and the zero blocks are skipped instead of multiplied.
+  int kb_tiles, kb_steps;
   const int* w_exp;
   int tn;
   long ldw;
@@ -90,6 +94,8 @@ hipError_t launch_layer_tail(FfnArgs g, hipStream_t s);
 // ---- weight preparation (once per weight upload) ---------------------------------------------
 // src [rows, K] fp32 -> dst [rows, 2K] split rows
 hipError_t launch_split_rows(const float* src, __bf16* dst, size_t rows, int K, hipStream_t s);
+// block-form weights of the folded last layer (rowops.hip), fp32: which = 0 Wq padded, 1 Wk^T block-diagonal, 2 Wv block-diagonal, 3 Wo padded
+hipError_t launch_fold_blocks(const float* qkv, const float* wo, float* out, int which, int heads, int dhp, hipStream_t s);
 // src [rows, K] fp32 -> dst [rows, 4K bytes] mixed WEIGHT rows (common.h); *exp_out (device) receives the tensor's e4m3 exponent e:
 // the largest e in [0, 24] with 2^e max|w| <= 448
 hipError_t launch_mixed_act_rows(const float* src, __bf16* dst, size_t rows, int K, hipStream_t s);

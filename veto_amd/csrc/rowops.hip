@@ -662,6 +662,43 @@ hipError_t launch_split_rows(const float* src, __bf16* dst, size_t rows, int K, 
   return hipGetLastError();
 }
 
+// Weights of the folded last layer in their block form (veto_abi.hip): `which` = 0 Wq with every head's dh rows padded to dhp
+// [H dhp, 576]; 1 the per-head transposes of Wk, block-diagonal [H 576, H dhp] (row (h, c), column (h, d) = Wk[h dh + d][c]);
+// 2 Wv, block-diagonal [H dhp, H 576] (row (h, d), column (h, c) = Wv[h dh + d][c]); 3 Wo with every head's dh columns padded
+// [576, H dhp].  qkv = the layer's to_qkv weight [1728, 576] (q rows, k rows, v rows), wo = to_out weight [576, 576].  fp32 out.
+namespace {
+__global__ __launch_bounds__(256) void fold_blocks_kernel(const float* __restrict__ qkv, const float* __restrict__ wo, float* __restrict__ out,
+                                                          int which, int H, int dh, int dhp, size_t n) {
+  const int np = H * dhp, hk = H * kDim;
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (size_t)gridDim.x * 256) {
+    float v = 0.f;
+    if (which == 0) {
+      const int r = (int)(e / kDim), c = (int)(e % kDim), h = r / dhp, d = r % dhp;
+      if (d < dh) v = qkv[(size_t)(h * dh + d) * kDim + c];
+    } else if (which == 1) {
+      const int r = (int)(e / np), k = (int)(e % np), h = r / kDim, c = r % kDim, hk2 = k / dhp, d = k % dhp;
+      if (hk2 == h && d < dh) v = qkv[(size_t)(kDim + h * dh + d) * kDim + c];
+    } else if (which == 2) {
+      const int r = (int)(e / hk), k = (int)(e % hk), h = r / dhp, d = r % dhp, hk2 = k / kDim, c = k % kDim;
+      if (hk2 == h && d < dh) v = qkv[(size_t)(2 * kDim + h * dh + d) * kDim + c];
+    } else {
+      const int r = (int)(e / np), k = (int)(e % np), h = k / dhp, d = k % dhp;
+      if (d < dh) v = wo[(size_t)r * kDim + h * dh + d];
+    }
+    out[e] = v;
+  }
+}
+}  // namespace
+
+hipError_t launch_fold_blocks(const float* qkv, const float* wo, float* out, int which, int heads, int dhp, hipStream_t s) {
+  if (heads <= 0 || kDim % heads != 0 || dhp < kDim / heads || which < 0 || which > 3) return hipErrorInvalidValue;
+  const int dh = kDim / heads, np = heads * dhp;
+  const size_t n = which == 0 ? (size_t)np * kDim : which == 1 ? (size_t)heads * kDim * np : which == 2 ? (size_t)np * heads * kDim : (size_t)kDim * np;
+  const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+  VETO_LAUNCH(fold_blocks_kernel, dim3(blocks), dim3(256), 0, s, qkv, wo, out, which, heads, dh, dhp, n);
+  return hipGetLastError();
+}
+
 hipError_t launch_build_patch_weight_t(const float* wd, const float* wv, __bf16* dst, hipStream_t s) {
   VETO_LAUNCH(build_patch_weight_t_kernel, dim3(kPatchTRows), dim3(256), 0, s, wd, wv, dst);
   return hipGetLastError();

@@ -62,6 +62,16 @@ size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 }  // namespace
 
+// Padded head width of the block form of the folded last layer, or 0 when the products are used instead: the head width rounded up
+// to 32 k's must divide a 192-column GEMM tile (heads 12 / 8 / 6 / 3 of the 576 columns), and the form can be switched off
+// (VETO_FOLD_BLOCKS=0, A/B knob).
+static int fold_block_width(int heads) {
+  static const bool off = getenv("VETO_FOLD_BLOCKS") && !strcmp(getenv("VETO_FOLD_BLOCKS"), "0");
+  if (off || heads <= 0 || kDim % heads != 0) return 0;
+  const int dhp = (kDim / heads + 31) / 32 * 32;
+  return 192 % dhp == 0 && (heads * dhp) % 192 == 0 ? dhp : 0;
+}
+
 struct veto_handle_s {
   veto_config_t cfg;
   int dh = 0;
@@ -80,6 +90,11 @@ struct veto_handle_s {
   // last layer, folded CLS attention (attention.hip): Mcat [heads*576, 2*576], Ncat [576, 2*heads*576], and their fp32 staging
   SplitW fold_m = nullptr, fold_n = nullptr;
   float* fold_tmp = nullptr;
+  // ... in block form (fold_dhp > 0: the head width padded to 32 k's divides a 192-column tile): Mcat = Wq^T Wk and Ncat = Wo Wv
+  // are products of rank dh per head, so u = (a0 Wq_pad^T) . blockdiag(Wk) and out = (abar . blockdiag(Wv)^T) Wo_pad^T take four
+  // GEMMs of 67 GF in all (zero blocks skipped: GemmArgs::kb_tiles) instead of two of 80 GF each
+  SplitW fold_q = nullptr, fold_k = nullptr, fold_v = nullptr, fold_o = nullptr;
+  int fold_dhp = 0;
   // layer 0, per-object form of LayerNorm + QKV (rowops.hip): Wqkv diag(gamma) as a GEMM operand, vec = [c2 | b0 | qkv_cls]
   SplitW q0_w = nullptr;
   float* q0_vec = nullptr;
@@ -180,6 +195,17 @@ int finalize_weights(veto_handle_t h, hipStream_t s) {
     const int H = h->cfg.heads, dh = kDim / H;
     const float* qkv = h->p(lname(L - 1, "0.fn.to_qkv.weight"));      // [1728, 576]: q rows, k rows, v rows
     const float* wo = h->p(lname(L - 1, "0.fn.to_out.0.weight"));     // [576, 576]
+    if (h->fold_dhp > 0) {   // block form: the four factors themselves, padded / block-diagonal, as split rows
+      const int np = H * h->fold_dhp;
+      HIP_TRY(launch_fold_blocks(qkv, wo, h->fold_tmp, 0, H, h->fold_dhp, s));
+      HIP_TRY(launch_split_rows(h->fold_tmp, h->fold_q, (size_t)np, kDim, s));
+      HIP_TRY(launch_fold_blocks(qkv, wo, h->fold_tmp, 1, H, h->fold_dhp, s));
+      HIP_TRY(launch_split_rows(h->fold_tmp, h->fold_k, (size_t)H * kDim, np, s));
+      HIP_TRY(launch_fold_blocks(qkv, wo, h->fold_tmp, 2, H, h->fold_dhp, s));
+      HIP_TRY(launch_split_rows(h->fold_tmp, h->fold_v, (size_t)np, H * kDim, s));
+      HIP_TRY(launch_fold_blocks(qkv, wo, h->fold_tmp, 3, H, h->fold_dhp, s));
+      HIP_TRY(launch_split_rows(h->fold_tmp, h->fold_o, (size_t)kDim, np, s));
+    } else {
     for (int hd = 0; hd < H; ++hd)   // Mcat row (hd, c), column c' = sum_d Wk[hd*dh + d, c] Wq[hd*dh + d, c']
       HIP_TRY(launch_sgemm_tn(qkv + ((size_t)kDim + hd * dh) * kDim, kDim, qkv + (size_t)hd * dh * kDim, kDim,
                               h->fold_tmp + (size_t)hd * kDim * kDim, kDim, dh, kDim, kDim, s));
@@ -188,6 +214,7 @@ int finalize_weights(veto_handle_t h, hipStream_t s) {
       HIP_TRY(launch_sgemm_nn(wo + hd * dh, kDim, qkv + ((size_t)2 * kDim + hd * dh) * kDim, kDim, h->fold_tmp + (size_t)hd * kDim,
                               (long)H * kDim, kDim, kDim, dh, s));
     HIP_TRY(launch_split_rows(h->fold_tmp, h->fold_n, (size_t)kDim, H * kDim, s));
+    }
   }
   h->dirty = false;
   ++h->weight_gen;
@@ -253,8 +280,9 @@ struct DropSite {   // one dropout site of the training path: threshold p * 2^24
 
 int run_gemm(veto_handle_t h, hipStream_t s, const char* name, const __bf16* a, SplitW w, const float* bias,
              const float* resid, long ldr, float* c, __bf16* c_split, long ldc, int M, int N, int K, int epi,
-             long lda = 0, int w_row0 = 0, DropSite drop = DropSite(), const int* w_exp = nullptr) {
+             long lda = 0, int w_row0 = 0, DropSite drop = DropSite(), const int* w_exp = nullptr, int kb_tiles = 0, int kb_steps = 0) {
   GemmArgs g{};
+  g.kb_tiles = kb_tiles; g.kb_steps = kb_steps;   // block-diagonal weights (kernels.h): flops / bytes below count the blocks only
   if (w_exp) { g.fmt = FMT_MIXED; g.w_exp = w_exp; }   // a, w (and an EPI_GELU_SPLIT output) are mixed rows
   if (drop.thresh) {
     if (epi != EPI_RESID) return fail(VETO_ERR_INVALID, "dropout is fused into the residual epilogue only");
@@ -265,8 +293,9 @@ int run_gemm(veto_handle_t h, hipStream_t s, const char* name, const __bf16* a, 
   g.w = w + (size_t)w_row0 * 2 * K;
   g.bias = bias; g.resid = resid; g.c = c; g.c_split = c_split;
   g.M = M; g.N = N; g.K = K; g.ldr = ldr; g.ldc = ldc;
-  const double flops = 2.0 * M * (double)N * K;
-  const double bytes = 4.0 * ((double)M * K + (double)N * K) + (double)M * N * (epi == EPI_RESID ? 8.0 : 4.0);
+  const double kk = kb_tiles > 0 ? 32.0 * kb_steps : (double)K;
+  const double flops = 2.0 * M * (double)N * kk;
+  const double bytes = 4.0 * ((double)M * K + (double)N * kk) + (double)M * N * (epi == EPI_RESID ? 8.0 : 4.0);
   ProfScope ps(h, s, name, flops, bytes);
   HIP_TRY(launch_gemm_split(g, epi, h->cfg.precision == VETO_FAST ? 1 : 0, s));
   return VETO_OK;
@@ -361,8 +390,12 @@ int veto_create(const veto_config_t* cfg, veto_handle_t* out) {
   const size_t o_loc = dtake((size_t)kPosDim * 2 * kDim * 4);
   const size_t o_cls = dtake((size_t)E * 2 * kDim * 4);
   const size_t o_head = dtake((size_t)kDim * cfg->num_out * 4);
-  const size_t fold_el = (size_t)cfg->heads * kDim * kDim;
-  const size_t o_fm = dtake(fold_el * 4), o_fn = dtake(fold_el * 4), o_ft = dtake(fold_el * 4);
+  const int fold_dhp = fold_block_width(cfg->heads);
+  const size_t fold_np = (size_t)cfg->heads * (fold_dhp > 0 ? fold_dhp : 0);
+  const size_t fold_el = fold_dhp > 0 ? (size_t)cfg->heads * kDim * fold_np : (size_t)cfg->heads * kDim * kDim;   // largest staged matrix
+  const size_t o_fm = dtake(fold_dhp > 0 ? 256 : fold_el * 4), o_fn = dtake(fold_dhp > 0 ? 256 : fold_el * 4), o_ft = dtake(fold_el * 4);
+  const size_t o_fq = dtake(fold_np * kDim * 4 + 256), o_fk = dtake((size_t)cfg->heads * kDim * fold_np * 4 + 256),
+               o_fv = dtake((size_t)cfg->heads * kDim * fold_np * 4 + 256), o_fo = dtake(fold_np * kDim * 4 + 256);
   const size_t o_q0w = dtake((size_t)3 * kDim * kDim * 4), o_q0v = dtake((size_t)3 * 3 * kDim * 4);
   e = hipMalloc((void**)&h->derived, doff);
   if (e != hipSuccess) { (void)hipFree(h->raw); delete h; return fail(VETO_ERR_HIP, "hipMalloc(derived weights): %s", hipGetErrorString(e)); }
@@ -395,6 +428,11 @@ int veto_create(const veto_config_t* cfg, veto_handle_t* out) {
   h->fold_m = (__bf16*)(h->derived + o_fm);
   h->fold_n = (__bf16*)(h->derived + o_fn);
   h->fold_tmp = (float*)(h->derived + o_ft);
+  h->fold_q = (__bf16*)(h->derived + o_fq);
+  h->fold_k = (__bf16*)(h->derived + o_fk);
+  h->fold_v = (__bf16*)(h->derived + o_fv);
+  h->fold_o = (__bf16*)(h->derived + o_fo);
+  h->fold_dhp = fold_dhp;
   h->q0_w = (__bf16*)(h->derived + o_q0w);
   h->q0_vec = (float*)(h->derived + o_q0v);
   *out = h;
@@ -562,14 +600,35 @@ int veto_forward(veto_handle_t h, void* stream, const veto_inputs_t* in, void* w
           ProfScope ps(h, s, "layernorm_cls", 0, (double)np * kDim * 8);
           HIP_TRY(launch_layernorm(ws.x, (long)kTokens * kDim, w.ln1_w, w.ln1_b, ws.ac, np, s));
         }
-        rc = run_gemm(h, s, "gemm_u_cls", ws.ac, h->fold_m, nullptr, nullptr, 0, u, nullptr, (long)H * kDim, np, H * kDim, kDim, EPI_F32);
+        const int dhp = h->fold_dhp, npad = H * dhp;   // block form: padded width of the per-head q / v rows
+        if (dhp > 0) {
+          // q0 = a0 Wq_pad^T as split rows (every head's dh columns padded to dhp), then u = q0 . blockdiag(Wk): column tile n of u
+          // belongs to head n / 3 and multiplies that head's dhp / 32 k-steps only
+          rc = run_gemm(h, s, "gemm_q_cls", ws.ac, h->fold_q, nullptr, nullptr, 0, nullptr, ws.hc, 2L * npad, np, npad, kDim, EPI_SPLIT);
+          if (rc) return rc;
+          rc = run_gemm(h, s, "gemm_u_cls", ws.hc, h->fold_k, nullptr, nullptr, 0, u, nullptr, (long)H * kDim, np, H * kDim, npad, EPI_F32,
+                        0, 0, DropSite(), nullptr, 3, dhp / 32);
+        } else {
+          rc = run_gemm(h, s, "gemm_u_cls", ws.ac, h->fold_m, nullptr, nullptr, 0, u, nullptr, (long)H * kDim, np, H * kDim, kDim, EPI_F32);
+        }
         if (rc) return rc;
         {
           ProfScope ps(h, s, "attention_cls", 4.0 * np * H * kTokens * kDim, (double)M * kDim * 4 + (double)np * H * kDim * 8);
           HIP_TRY(launch_cls_fold_attention(ws.x, w.ln1_w, w.ln1_b, u, abar, np, H, s));
         }
-        rc = run_gemm(h, s, "gemm_out_cls", abar, h->fold_n, w.out_b, ws.x, (long)kTokens * kDim, ws.xc, nullptr, kDim, np, kDim,
-                      H * kDim, EPI_RESID);
+        if (dhp > 0) {
+          // vbar = abar . blockdiag(Wv)^T as split rows (column tile n covers the 192 / dhp heads whose 576-wide k blocks it needs),
+          // then out = vbar Wo_pad^T + b_o + x_0
+          const int hpt = 192 / dhp;
+          rc = run_gemm(h, s, "gemm_v_cls", abar, h->fold_v, nullptr, nullptr, 0, nullptr, ws.hc, 2L * npad, np, npad, H * kDim, EPI_SPLIT,
+                        0, 0, DropSite(), nullptr, 1, hpt * kDim / 32);
+          if (rc) return rc;
+          rc = run_gemm(h, s, "gemm_out_cls", ws.hc, h->fold_o, w.out_b, ws.x, (long)kTokens * kDim, ws.xc, nullptr, kDim, np, kDim, npad,
+                        EPI_RESID);
+        } else {
+          rc = run_gemm(h, s, "gemm_out_cls", abar, h->fold_n, w.out_b, ws.x, (long)kTokens * kDim, ws.xc, nullptr, kDim, np, kDim,
+                        H * kDim, EPI_RESID);
+        }
         if (rc) return rc;
       } else if (l == 0 && qkv0_tables) {
         if (!attention_reads_tables(H)) {   // head widths without an MFMA attention: materialise the rows of tokens 0..16
