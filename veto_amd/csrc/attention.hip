@@ -14,7 +14,9 @@
 #include "common.h"
 #include "kernels.h"
 
+#include <cstdio>
 #include <cstdlib>
+#include <cstring>
 
 namespace veto {
 
@@ -488,6 +490,239 @@ __global__ __launch_bounds__(256) void cls_fold_attention_kernel(const float* __
   }
 }
 
+// The same kernel with both contractions on the matrix cores (round 3; the VALU form above took 0.17 ms for the scores -- a DPP
+// reduction tree per (head, token) behind the FMAs -- and 0.09 ms for the weighted means of a 0.39 ms launch).  The token vectors
+// a_j go to LDS as bf16 hi / lo images (row = token, 20 rows: row 19 is zero and stands in for tokens 19..31; the row pitch of
+// 1168 bytes puts the 16 rows of a fragment read on 16 different bank quadruples), both products are 16x16x32 MFMAs in the 3-term
+// split-bf16 scheme of the GEMMs:
+//   scores[h][j] = sum_c u[h][c] a[j][c]   A operand = u (lane (m, g): head m, 8 columns at 32 s + 8 g, read from memory as it is,
+//                                          heads >= H are zero rows), B operand = the image rows (ds_read_b128), k-steps s dealt
+//                                          over the 4 waves, partial tiles summed through LDS in a fixed order
+//   abar[h][c]   = sum_j p[h][j] a[j][c]   A operand = p (one k-step: 32 token slots), B operand = the SAME images read through
+//                                          ds_read_b64_tr_b16 (token = contraction index: 4 rows x 16 columns per 16-lane group,
+//                                          delivered column-major), 36 column tiles dealt over the waves
+// The result tiles are staged through LDS (over the images, which are dead by then) so that abar leaves as 128-byte runs.
+constexpr int kFoldPitch = kDim * 2 + 16;            // bytes per image row
+constexpr int kFoldImg = 20 * kFoldPitch;            // one plane (hi or lo)
+typedef short cf_s16x4 __attribute__((ext_vector_type(4)));
+typedef short cf_s16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void split8(const f32x4& v0, const f32x4& v1, bf16x8& hi, bf16x8& lo) {
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    __bf16 hh, ll;
+    split_bf16(t < 4 ? v0[t] : v1[t - 4], hh, ll);
+    hi[t] = hh;
+    lo[t] = ll;
+  }
+}
+
+#ifdef VETO_CLS_STAMPS
+__device__ unsigned long long g_cls_stamps[16];
+#define CST(k) do { if (blockIdx.x == 5000 && tid == 0) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); g_cls_stamps[k] = t_; } } while (0)
+#else
+#define CST(k)
+#endif
+__global__ __launch_bounds__(256, 3) void cls_fold_attention_mfma_kernel(const float* __restrict__ x, const float* __restrict__ ln_w,
+                                                                      const float* __restrict__ ln_b, const float* __restrict__ u,
+                                                                      __bf16* __restrict__ abar, int n_pair, int heads, float scale) {
+  __shared__ __attribute__((aligned(16))) char img[2 * kFoldImg];      // a_j as bf16 hi | lo; later the fp32 staging of abar
+  __shared__ float s_part[4][kFoldMaxHeads][20];                        // per-wave partial score tiles [head][token] (the valid part)
+  __shared__ float p_s[16][32];                                         // probabilities, zero outside [heads][19]
+  const int pair = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  if (pair >= n_pair) return;
+  CST(0);
+  char* a_hi = img;
+  char* a_lo = img + kFoldImg;
+  const int fm = lane & 15, fg = lane >> 4;           // MFMA operand lane: row / column fm, k group fg
+  // ---- every global read of the workgroup up front: the token rows 0..15 (a quarter wave per row, 9 16-byte chunks per lane), the
+  // rows 16..18 (one per wave 0..2, lane l takes the columns l + 64 i), and this wave's k-steps of u in operand layout
+  const int q = tid & 15, j0 = tid >> 4;
+  const float* xp = x + (size_t)pair * kTokens * kDim;
+  f32x4 vrow[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) vrow[i] = *(const f32x4*)(xp + (size_t)j0 * kDim + 4 * (q + 16 * i));
+  float vx[9];
+  if (16 + w < kTokens) {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) vx[i] = xp[(size_t)(16 + w) * kDim + lane + 64 * i];
+  }
+  constexpr int KS = kDim / 32;                       // 18 k-steps of the score product
+  f32x4 uf[(KS + 3) / 4][2];
+  const float* up = u + (size_t)pair * heads * kDim + (size_t)(fm < heads ? fm : 0) * kDim + 8 * fg;
+#pragma unroll
+  for (int i = 0; i < (KS + 3) / 4; ++i) {
+    const int sidx = w + 4 * i;
+    if (sidx < KS && fm < heads) {
+      uf[i][0] = *(const f32x4*)(up + 32 * sidx);
+      uf[i][1] = *(const f32x4*)(up + 32 * sidx + 4);
+    } else {
+      uf[i][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+      uf[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  CST(1);
+  for (int i = tid; i < 16 * 32; i += 256) (&p_s[0][0])[i] = 0.f;
+  for (int i = tid; i < kFoldPitch / 4; i += 256) {            // the zero row of both planes
+    *(uint32_t*)(a_hi + 19 * kFoldPitch + 4 * i) = 0u;
+    *(uint32_t*)(a_lo + 19 * kFoldPitch + 4 * i) = 0u;
+  }
+  CST(2);
+  // ---- a_j = LayerNorm1(x_j) (two-pass statistics as in layernorm_kernel) -> the images
+  {
+    const int j = j0;
+    f32x4 (&v)[9] = vrow;
+    float sm = 0.f;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) sm += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    const float mean = row16_sum(sm) * (1.f / kDim);
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < 9; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { const float d = v[i][e] - mean; sq += d * d; }
+    const float rstd = 1.f / sqrtf(row16_sum(sq) * (1.f / kDim) + 1e-5f);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+      const int c = 4 * (q + 16 * i);
+      const f32x4 g = *(const f32x4*)(ln_w + c), bb = *(const f32x4*)(ln_b + c);
+      bf16x4 hi, lo;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        __bf16 hh, ll;
+        split_bf16((v[i][e] - mean) * rstd * g[e] + bb[e], hh, ll);
+        hi[e] = hh;
+        lo[e] = ll;
+      }
+      *(bf16x4*)(a_hi + j * kFoldPitch + c * 2) = hi;
+      *(bf16x4*)(a_lo + j * kFoldPitch + c * 2) = lo;
+    }
+  }
+  if (16 + w < kTokens) {      // wave-uniform: rows 16..18 on a whole wave each
+    const int j = 16 + w;
+    float sm = 0.f;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) sm += vx[i];
+    const float mean = wave_sum(sm) * (1.f / kDim);
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { const float d = vx[i] - mean; sq += d * d; }
+    const float rstd = 1.f / sqrtf(wave_sum(sq) * (1.f / kDim) + 1e-5f);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+      const int c = lane + 64 * i;
+      __bf16 hh, ll;
+      split_bf16((vx[i] - mean) * rstd * ln_w[c] + ln_b[c], hh, ll);
+      *(__bf16*)(a_hi + j * kFoldPitch + c * 2) = hh;
+      *(__bf16*)(a_lo + j * kFoldPitch + c * 2) = ll;
+    }
+  }
+  CST(3);
+  __syncthreads();
+  CST(4);
+  // ---- scores: this wave's k-steps, two token tiles
+  {
+    f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int i = 0; i < (KS + 3) / 4; ++i) {
+      const int sidx = w + 4 * i;
+      if (sidx >= KS) break;                                   // wave-uniform
+      bf16x8 uh, ul;
+      split8(uf[i][0], uf[i][1], uh, ul);
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int row = 16 * t + fm < kTokens ? 16 * t + fm : kTokens;      // tokens 19..31: the zero row
+        const int off = row * kFoldPitch + (32 * sidx + 8 * fg) * 2;
+        const bf16x8 bh = *(const bf16x8*)(a_hi + off), bl = *(const bf16x8*)(a_lo + off);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ul, bh, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(uh, bl, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(uh, bh, acc[t], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)                                                     // D[row 4 g + e = head][column fm = token]
+        if (4 * fg + e < kFoldMaxHeads && 16 * t + fm < 20) s_part[w][4 * fg + e][16 * t + fm] = acc[t][e];
+  }
+  CST(5);
+  __syncthreads();
+  CST(6);
+  // softmax over the 19 tokens of a head (model_veto.py:91): a half wave per head (lanes 19..31 of a half idle), wave w takes the
+  // heads 2 w, 2 w + 1, then 2 w + 8, 2 w + 9; the four partial tiles are summed in a fixed order
+  for (int h0 = 2 * w; h0 < heads; h0 += 8) {
+    const int sh = h0 + (lane >> 5), sj = lane & 31;
+    const bool valid = sh < heads && sj < kTokens;
+    const int rh = valid ? sh : 0, rj = valid ? sj : 0;
+    const float sc = valid ? ((s_part[0][rh][rj] + s_part[1][rh][rj]) + (s_part[2][rh][rj] + s_part[3][rh][rj])) * scale : -INFINITY;
+    float mx = sc;
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    const float ev = valid ? expf(sc - mx) : 0.f;
+    float sum = ev;
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    if (valid) p_s[sh][sj] = ev / sum;
+  }
+  CST(7);
+  __syncthreads();
+  // ---- abar: this wave's column tiles c = w, w + 4, ...; the probabilities are the A operand (one k-step of 32 token slots)
+  CST(8);
+  constexpr int NTILE = kDim / 16;                     // 36
+  f32x4 out[NTILE / 4];
+  {
+    bf16x8 ph, pl;
+    split8(*(const f32x4*)&p_s[fm][8 * fg], *(const f32x4*)&p_s[fm][8 * fg + 4], ph, pl);
+    const int tq = (lane >> 2) & 3, tp = lane & 3;     // transposed read: this lane addresses row 8 g + q (+ 4), 8-byte piece p
+    const int r0 = 8 * fg + tq < kTokens ? 8 * fg + tq : kTokens, r1 = 8 * fg + tq + 4 < kTokens ? 8 * fg + tq + 4 : kTokens;
+    const int o0 = r0 * kFoldPitch + 8 * tp, o1 = r1 * kFoldPitch + 8 * tp;
+    auto frag = [&](const char* plane, int c) {
+      const cf_s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) cf_s16x4*)(plane + o0 + 32 * c));
+      const cf_s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) cf_s16x4*)(plane + o1 + 32 * c));
+      return __builtin_bit_cast(bf16x8, (cf_s16x8)__builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7));
+    };
+#pragma unroll
+    for (int i = 0; i < NTILE / 4; ++i) {
+      const int c = w + 4 * i;
+      const bf16x8 bh = frag(a_hi, c), bl = frag(a_lo, c);
+      f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
+      o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pl, bh, o, 0, 0, 0);
+      o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph, bl, o, 0, 0, 0);
+      o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph, bh, o, 0, 0, 0);
+      out[i] = o;
+    }
+  }
+  CST(9);
+  __syncthreads();                                     // every wave is done with the images: the staging goes over them
+  CST(10);
+  float* st = (float*)img;                             // [heads][576] fp32
+#pragma unroll
+  for (int i = 0; i < NTILE / 4; ++i) {
+    const int c = w + 4 * i;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (4 * fg + e < heads) st[(4 * fg + e) * kDim + 16 * c + fm] = out[i][e];
+  }
+  __syncthreads();
+  CST(11);
+  __bf16* dst = abar + (size_t)pair * (2 * (size_t)heads * kDim);
+  for (int e = 4 * tid; e < heads * kDim; e += 4 * 256) {      // split rows (the A operand of the GEMM behind), 8 bytes of hi + 8 of lo per thread
+    const f32x4 v = *(const f32x4*)(st + e);
+    bf16x4 hi, lo;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      __bf16 hh, ll;
+      split_bf16(v[t], hh, ll);
+      hi[t] = hh;
+      lo[t] = ll;
+    }
+    __bf16* d = dst + split_index(e);
+    *(bf16x4*)d = hi;
+    *(bf16x4*)(d + 32) = lo;
+  }
+  CST(12);
+}
+
 }  // namespace
 
 int cls_fold_max_heads() { return kFoldMaxHeads; }
@@ -496,7 +731,22 @@ hipError_t launch_cls_fold_attention(const float* x, const float* ln_w, const fl
                                      hipStream_t s) {
   if (heads <= 0 || heads > kFoldMaxHeads || kDim % heads != 0 || n_pair <= 0) return hipErrorInvalidValue;
   const float scale = 1.0f / sqrtf((float)(kDim / heads));
-  VETO_LAUNCH(cls_fold_attention_kernel, dim3(n_pair), dim3(256), 0, s, x, ln_w, ln_b, u, abar, n_pair, heads, scale);
+  static const bool valu = getenv("VETO_CLS_MFMA") && !strcmp(getenv("VETO_CLS_MFMA"), "0");     // A/B knob: the fp32 VALU form
+  if (valu) VETO_LAUNCH(cls_fold_attention_kernel, dim3(n_pair), dim3(256), 0, s, x, ln_w, ln_b, u, abar, n_pair, heads, scale);
+  else VETO_LAUNCH(cls_fold_attention_mfma_kernel, dim3(n_pair), dim3(256), 0, s, x, ln_w, ln_b, u, abar, n_pair, heads, scale);
+#ifdef VETO_CLS_STAMPS
+  {
+    static int printed = 0;
+    if (printed++ == 3) {
+      unsigned long long hst[16];
+      hipDeviceSynchronize();
+      hipMemcpyFromSymbol(hst, HIP_SYMBOL(g_cls_stamps), sizeof(hst));
+      fprintf(stderr, "[cls stamps]");
+      for (int k = 1; k <= 12; ++k) fprintf(stderr, " %lld", (long long)(hst[k] - hst[k - 1]));
+      fprintf(stderr, "  (request | zero | loads->LN start.. | LN+images | barrier | scores | barrier | softmax | barrier | abar | barrier | staging | stores)\n");
+    }
+  }
+#endif
   return hipGetLastError();
 }
 
