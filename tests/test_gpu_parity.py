@@ -884,9 +884,10 @@ def test_restructured_first_and_last_layer_match_the_plain_path(tmp_path):
             "np.save(sys.argv[1], torch.cat(list(out[1])).cpu().numpy())\n") % (root, os.path.join(root, "tests"))
     outs = []
     # ... and the forms behind the other knobs of the default (mixed) path: the folded last layer with its products as two dense
-    # GEMMs instead of four block-structured ones, fp32 q / k / v instead of 3-byte floats, one launch per panel phase
+    # GEMMs instead of four block-structured ones and its attention on the vector ALU, fp32 q / k / v instead of 3-byte floats, one
+    # launch per panel phase
     variants = (("default", {}), ("plain", {"VETO_QKV0_TABLES": "0", "VETO_CLS_FOLD": "0"}),
-                ("round2-forms", {"VETO_FOLD_BLOCKS": "0", "VETO_QKV_F24": "0", "VETO_TAIL_FUSED": "0", "VETO_FFN_LATE": "0"}))
+                ("round2-forms", {"VETO_FOLD_BLOCKS": "0", "VETO_QKV_F24": "0", "VETO_TAIL_FUSED": "0", "VETO_FFN_LATE": "0", "VETO_CLS_MFMA": "0"}))
     for tag, env in variants:
         path = str(tmp_path / (tag + ".npy"))
         subprocess.run([sys.executable, "-c", code, path], check=True, env=dict(os.environ, **env), timeout=600)
