@@ -43,18 +43,12 @@
 #include <cstdio>
 #include <cstdlib>
 
-#ifndef FFN_AGPR
-#define FFN_AGPR 0
-#endif
 // timing ablations (tools/ffn_variants.sh; results are WRONG with any of them set): 1 = no DMA, 2 = no MFMA, 4 = no fragment
 // reads, 8 = no hidden conversion, 16 = no panel epilogue
 #ifndef FFN_ABLATE
 #define FFN_ABLATE 0
 #endif
 // micro-variants (A/B with tools/ffn_variants.sh)
-#ifndef FFN_PRIO
-#define FFN_PRIO 0          // 1: s_setprio 1 for waves 4..7 (the younger wave of every SIMD loses the issue arbitration otherwise)
-#endif
 #ifndef FFN_CONV_G0
 #define FFN_CONV_G0 0       // first of the three MFMA groups of a sub-stage that carry a piece of the hidden conversion (0..3)
 #endif
@@ -159,13 +153,6 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs g) {
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = w >> 1, wn = w & 1;          // 4 x 2 waves: rows 32 wm .., of every 64 weight rows of a stage the 32 at 32 wn
   const int G = gridDim.x, b = blockIdx.x;
-#if FFN_AGPR
-  {   // an inline asm that names an accumulator register makes the compiler select the AGPR form of the MFMAs: the 192
-      // accumulators then live in their own register class and the vector registers hold fragments and addresses only
-    int agpr_probe = 0;
-    asm volatile("" : "+a"(agpr_probe));
-  }
-#endif
   const int my_panels = g.n_panels > b ? (g.n_panels - b + G - 1) / G : 0;   // panels b, b + G, ...
   if (my_panels == 0) return;
 
@@ -364,7 +351,6 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs g) {
     }
   };
 
-  if (FFN_PRIO && w >= 4) __builtin_amdgcn_s_setprio(1);
   unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t_begin = 0, s_wait = 0, s_bar = 0, s_iss = 0, s_cmp = 0, s_hid = 0, s_epi = 0;
   (void)t0; (void)t1; (void)t2; (void)t3; (void)t_begin; (void)s_wait; (void)s_bar; (void)s_iss; (void)s_cmp; (void)s_hid; (void)s_epi;
   STAMP(t_begin);
