@@ -373,9 +373,10 @@ def test_golden_parity(name, precision):
 
 
 @pytest.mark.parametrize("layers,heads,num_objs,relu_like", [(2, 8, [7, 12], True), (3, 6, [9, 4, 1, 6], False),
-                                                             (1, 8, [5], False), (2, 4, [6, 6], False)])
+                                                             (1, 8, [5], False), (2, 4, [6, 6], False), (2, 12, [5, 8], False)])
 def test_oracle_parity_other_inputs(layers, heads, num_objs, relu_like):
-    """HIP path vs the CPU oracle on inputs no golden covers (other seeds, ragged batches, L=1)."""
+    """HIP path vs the CPU oracle on inputs no golden covers (other seeds, ragged batches, L=1; 12 heads: the block form of the
+    folded last layer at the padded head width 64, 4 heads: its product form)."""
     from oracle import veto_oracle as vo
     from veto_amd import synth, testing
     dev = _dev()
