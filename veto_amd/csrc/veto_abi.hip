@@ -295,7 +295,7 @@ int run_gemm(veto_handle_t h, hipStream_t s, const char* name, const __bf16* a, 
   g.M = M; g.N = N; g.K = K; g.ldr = ldr; g.ldc = ldc;
   const double kk = kb_tiles > 0 ? 32.0 * kb_steps : (double)K;
   const double flops = 2.0 * M * (double)N * kk;
-  const double bytes = 4.0 * ((double)M * K + (double)N * kk) + (double)M * N * (epi == EPI_RESID ? 8.0 : 4.0);
+  const double bytes = 4.0 * ((double)M * K + (double)N * kk) + (double)M * N * (epi == EPI_RESID ? 8.0 : epi == EPI_F24 ? 3.0 : 4.0);
   ProfScope ps(h, s, name, flops, bytes);
   HIP_TRY(launch_gemm_split(g, epi, h->cfg.precision == VETO_FAST ? 1 : 0, s));
   return VETO_OK;
@@ -667,7 +667,7 @@ int veto_forward(veto_handle_t h, void* stream, const veto_inputs_t* in, void* w
         }
         const double nq = last ? 1 : kTokens;
         ProfScope ps(h, s, last ? "attention_cls" : "attention", 4.0 * np * nq * kTokens * kDim,
-                     (double)M * 3 * kDim * 4 + (double)np * nq * kDim * 4);
+                     (double)M * 3 * kDim * (qkv_f24 ? 3 : 4) + (double)np * nq * kDim * 4);
         HIP_TRY(launch_attention(a, s));
       }
       if (!last) {
