@@ -132,7 +132,9 @@ __device__ __forceinline__ void mixed_pack4(f32x4 v, u32x2& h, u32x2& xy) {
 #pragma unroll
   for (int p = 0; p < 2; ++p) {
     uint32_t hp;
-    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hp) : "v"(v[2 * p]), "v"(v[2 * p + 1]));
+    // (volatile: the conversion reads MODE -- rounding, FP16_OVFL -- which an asm statement cannot name as an input; this keeps it
+    // behind saturating_conversions_on())
+    asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hp) : "v"(v[2 * p]), "v"(v[2 * p + 1]));
     asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l[2 * p]) : "v"(hp), "v"(v[2 * p]));
     asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(l[2 * p + 1]) : "v"(hp), "v"(v[2 * p + 1]));
     h[p] = hp;
