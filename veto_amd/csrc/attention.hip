@@ -523,6 +523,7 @@ __device__ unsigned long long g_cls_stamps[16];
 #else
 #define CST(k)
 #endif
+template <bool U24>     // U24: u arrives as 3-byte floats (common.h), rows of 3 * heads * 576 bytes
 __global__ __launch_bounds__(256, 3) void cls_fold_attention_mfma_kernel(const float* __restrict__ x, const float* __restrict__ ln_w,
                                                                       const float* __restrict__ ln_b, const float* __restrict__ u,
                                                                       __bf16* __restrict__ abar, int n_pair, int heads, float scale) {
@@ -549,11 +550,17 @@ __global__ __launch_bounds__(256, 3) void cls_fold_attention_mfma_kernel(const f
   }
   constexpr int KS = kDim / 32;                       // 18 k-steps of the score product
   f32x4 uf[(KS + 3) / 4][2];
-  const float* up = u + (size_t)pair * heads * kDim + (size_t)(fm < heads ? fm : 0) * kDim + 8 * fg;
+  const size_t uoff = (size_t)pair * heads * kDim + (size_t)(fm < heads ? fm : 0) * kDim + 8 * fg;     // in elements
+  const float* up = u + uoff;
 #pragma unroll
   for (int i = 0; i < (KS + 3) / 4; ++i) {
     const int sidx = w + 4 * i;
-    if (sidx < KS && fm < heads) {
+    if (U24 && sidx < KS && fm < heads) {       // 8 values = 24 bytes, kept packed until the operand is formed
+      const char* src = (const char*)u + (uoff + 32 * sidx) * 3;
+      const u32x2 d0 = *(const u32x2*)src, d1 = *(const u32x2*)(src + 8), d2 = *(const u32x2*)(src + 16);
+      uf[i][0] = f32x4{__uint_as_float(d0[0]), __uint_as_float(d0[1]), __uint_as_float(d1[0]), __uint_as_float(d1[1])};
+      uf[i][1] = f32x4{__uint_as_float(d2[0]), __uint_as_float(d2[1]), 0.f, 0.f};
+    } else if (sidx < KS && fm < heads) {
       uf[i][0] = *(const f32x4*)(up + 32 * sidx);
       uf[i][1] = *(const f32x4*)(up + 32 * sidx + 4);
     } else {
@@ -628,7 +635,13 @@ __global__ __launch_bounds__(256, 3) void cls_fold_attention_mfma_kernel(const f
       const int sidx = w + 4 * i;
       if (sidx >= KS) break;                                   // wave-uniform
       bf16x8 uh, ul;
-      split8(uf[i][0], uf[i][1], uh, ul);
+      if constexpr (U24) {      // (lanes without a head hold zeros, which unpack to zeros)
+        const f32x4 p0 = uf[i][0], p1 = uf[i][1];
+        split8(unpack_f24x4(__float_as_uint(p0[0]), __float_as_uint(p0[1]), __float_as_uint(p0[2])),
+               unpack_f24x4(__float_as_uint(p0[3]), __float_as_uint(p1[0]), __float_as_uint(p1[1])), uh, ul);
+      } else {
+        split8(uf[i][0], uf[i][1], uh, ul);
+      }
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
         const int row = 16 * t + fm < kTokens ? 16 * t + fm : kTokens;      // tokens 19..31: the zero row
@@ -727,13 +740,21 @@ __global__ __launch_bounds__(256, 3) void cls_fold_attention_mfma_kernel(const f
 
 int cls_fold_max_heads() { return kFoldMaxHeads; }
 
+bool cls_fold_reads_f24() {
+  static const bool valu = getenv("VETO_CLS_MFMA") && !strcmp(getenv("VETO_CLS_MFMA"), "0");
+  static const bool f32 = getenv("VETO_QKV_F24") && !strcmp(getenv("VETO_QKV_F24"), "0");
+  return !valu && !f32;
+}
+
 hipError_t launch_cls_fold_attention(const float* x, const float* ln_w, const float* ln_b, const float* u, __bf16* abar, int n_pair, int heads,
-                                     hipStream_t s) {
+                                     hipStream_t s, bool u_f24) {
   if (heads <= 0 || heads > kFoldMaxHeads || kDim % heads != 0 || n_pair <= 0) return hipErrorInvalidValue;
   const float scale = 1.0f / sqrtf((float)(kDim / heads));
   static const bool valu = getenv("VETO_CLS_MFMA") && !strcmp(getenv("VETO_CLS_MFMA"), "0");     // A/B knob: the fp32 VALU form
+  if (u_f24 && valu) return hipErrorInvalidValue;
   if (valu) VETO_LAUNCH(cls_fold_attention_kernel, dim3(n_pair), dim3(256), 0, s, x, ln_w, ln_b, u, abar, n_pair, heads, scale);
-  else VETO_LAUNCH(cls_fold_attention_mfma_kernel, dim3(n_pair), dim3(256), 0, s, x, ln_w, ln_b, u, abar, n_pair, heads, scale);
+  else if (u_f24) VETO_LAUNCH(cls_fold_attention_mfma_kernel<true>, dim3(n_pair), dim3(256), 0, s, x, ln_w, ln_b, u, abar, n_pair, heads, scale);
+  else VETO_LAUNCH(cls_fold_attention_mfma_kernel<false>, dim3(n_pair), dim3(256), 0, s, x, ln_w, ln_b, u, abar, n_pair, heads, scale);
 #ifdef VETO_CLS_STAMPS
   {
     static int printed = 0;

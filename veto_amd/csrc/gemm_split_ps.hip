@@ -569,6 +569,7 @@ hipError_t launch_ps_terms(GemmArgs g, int epi, int nblocks, hipStream_t s) {
   } else
   switch (epi) {
     case EPI_F32: VETO_LAUNCH((gemm_split_ps_kernel<NTERMS, EPI_F32>), grid, block, 0, s, g); break;
+    case EPI_F24: VETO_LAUNCH((gemm_split_ps_kernel<NTERMS, EPI_F24>), grid, block, 0, s, g); break;
     case EPI_RESID: VETO_LAUNCH((gemm_split_ps_kernel<NTERMS, EPI_RESID>), grid, block, 0, s, g); break;
     case EPI_GELU_SPLIT: VETO_LAUNCH((gemm_split_ps_kernel<NTERMS, EPI_GELU_SPLIT>), grid, block, 0, s, g); break;
     case EPI_SPLIT: VETO_LAUNCH((gemm_split_ps_kernel<NTERMS, EPI_SPLIT>), grid, block, 0, s, g); break;

@@ -201,7 +201,8 @@ bool attention_reads_tables(int heads);   // whether launch_attention takes the 
 // token means per head)
 int cls_fold_max_heads();
 hipError_t launch_cls_fold_attention(const float* x, const float* ln_w, const float* ln_b, const float* u, __bf16* abar, int n_pair, int heads,
-                                     hipStream_t s);
+                                     hipStream_t s, bool u_f24 = false);
+bool cls_fold_reads_f24();   // whether the kernel takes u as 3-byte floats (the MFMA form; VETO_QKV_F24=0 / VETO_CLS_MFMA=0: fp32)
 
 // cls row p at cls + p*ld (ld = 576 for compact CLS rows, 19*576 to read row 0 of every pair of a token matrix)
 hipError_t launch_head(const float* cls, const float* wt, const float* bias, float* out, int n_pair,

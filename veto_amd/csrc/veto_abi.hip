@@ -601,20 +601,22 @@ int veto_forward(veto_handle_t h, void* stream, const veto_inputs_t* in, void* w
           HIP_TRY(launch_layernorm(ws.x, (long)kTokens * kDim, w.ln1_w, w.ln1_b, ws.ac, np, s));
         }
         const int dhp = h->fold_dhp, npad = H * dhp;   // block form: padded width of the per-head q / v rows
+        bool u24 = false;
         if (dhp > 0) {
           // q0 = a0 Wq_pad^T as split rows (every head's dh columns padded to dhp), then u = q0 . blockdiag(Wk): column tile n of u
           // belongs to head n / 3 and multiplies that head's dhp / 32 k-steps only
           rc = run_gemm(h, s, "gemm_q_cls", ws.ac, h->fold_q, nullptr, nullptr, 0, nullptr, ws.hc, 2L * npad, np, npad, kDim, EPI_SPLIT);
           if (rc) return rc;
-          rc = run_gemm(h, s, "gemm_u_cls", ws.hc, h->fold_k, nullptr, nullptr, 0, u, nullptr, (long)H * kDim, np, H * kDim, npad, EPI_F32,
-                        0, 0, DropSite(), nullptr, 3, dhp / 32);
+          u24 = cls_fold_reads_f24();      // u as 3-byte floats: its consumer splits it into bf16 hi + lo, a 16-bit significand
+          rc = run_gemm(h, s, "gemm_u_cls", ws.hc, h->fold_k, nullptr, nullptr, 0, u, nullptr, (long)H * kDim, np, H * kDim, npad,
+                        u24 ? EPI_F24 : EPI_F32, 0, 0, DropSite(), nullptr, 3, dhp / 32);
         } else {
           rc = run_gemm(h, s, "gemm_u_cls", ws.ac, h->fold_m, nullptr, nullptr, 0, u, nullptr, (long)H * kDim, np, H * kDim, kDim, EPI_F32);
         }
         if (rc) return rc;
         {
           ProfScope ps(h, s, "attention_cls", 4.0 * np * H * kTokens * kDim, (double)M * kDim * 4 + (double)np * H * kDim * 8);
-          HIP_TRY(launch_cls_fold_attention(ws.x, w.ln1_w, w.ln1_b, u, abar, np, H, s));
+          HIP_TRY(launch_cls_fold_attention(ws.x, w.ln1_w, w.ln1_b, u, abar, np, H, s, u24));
         }
         if (dhp > 0) {
           // vbar = abar . blockdiag(Wv)^T as split rows (column tile n covers the 192 / dhp heads whose 576-wide k blocks it needs),
