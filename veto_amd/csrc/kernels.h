@@ -154,6 +154,7 @@ struct AssembleArgs {
   float* x;                 // [n_pair*19, 576]
   __bf16* a;                // LN(x), split rows [n_pair*19, 2*576]
   float* stats;             // optional [n_pair*19, 2]: (mean, rstd) of every row; then `a` is written for tokens 17 / 18 only
+  int a_fmt;                // ... in this operand format (FMT_SPLIT / FMT_MIXED; with stats only)
   int n_pair;
   // training only: pos_drop (EMB_DROPOUT) on the assembled tokens; element (row, col) -> index row*576 + col
   unsigned long long drop_seed;

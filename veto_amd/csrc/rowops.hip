@@ -776,7 +776,7 @@ hipError_t launch_assemble(const AssembleArgs& a, hipStream_t s) {
     // LayerNorm'ed split rows of the location / class tokens (rows 19 p + 17, 19 p + 18): 2 of 19 rows, read back from x
     for (int t = kPatchTokens + 1; t < kTokens; ++t) {
       hipError_t e = launch_layernorm(a.x + (size_t)t * kDim, (long)kTokens * kDim, a.ln_w, a.ln_b, a.a + (size_t)t * 2 * kDim, a.n_pair, s,
-                                      FMT_SPLIT, (long)kTokens * 2 * kDim);
+                                      a.a_fmt == FMT_MIXED ? FMT_MIXED : FMT_SPLIT, (long)kTokens * 2 * kDim);
       if (e != hipSuccess) return e;
     }
   } else {

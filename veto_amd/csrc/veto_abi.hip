@@ -578,6 +578,7 @@ int veto_forward(veto_handle_t h, void* stream, const veto_inputs_t* in, void* w
       a.ln_w = h->layers[0].ln1_w; a.ln_b = h->layers[0].ln1_b;
       a.subj = ws.subj + c0; a.obj = ws.obj + c0; a.x = ws.x; a.a = ws.a; a.n_pair = np;
       a.stats = qkv0_tables ? ws.stats : nullptr;
+      a.a_fmt = mixed && qkv0_tables ? FMT_MIXED : FMT_SPLIT;   // (the rows of tokens 17 / 18: the A operand of gemm_qkv0_lc below)
       // bytes = what the kernel WRITES (its HBM stream; the per-object rows it gathers are cache-resident): the fp32 token rows
       // plus either their LayerNorm'ed split copy, or -- per-object layer 0 -- the row statistics and the split rows of tokens 17, 18
       ProfScope ps(h, s, "assemble_tokens", 0, (double)M * kDim * 4 + (qkv0_tables ? (double)M * 8 + 2.0 * np * kDim * 4 : (double)M * kDim * 4));
@@ -637,9 +638,10 @@ int veto_forward(veto_handle_t h, void* stream, const veto_inputs_t* in, void* w
           ProfScope ps(h, s, "qkv0_combine", 0, (double)np * 17 * 3 * kDim * 4 * 3);
           HIP_TRY(launch_qkv0_combine(ws.sw, ws.ow, ws.stats, h->q0_vec, ws.subj + c0, ws.obj + c0, qkv, np, s));
         }
-        for (int t = kTokens - 2; t < kTokens; ++t) {   // the ReLU'd location / class rows: LayerNorm'ed split rows x Wqkv as usual
-          rc = run_gemm(h, s, "gemm_qkv0_lc", ws.a + (size_t)t * 2 * kDim, w.qkv, nullptr, nullptr, 0, qkv + (size_t)t * 3 * kDim, nullptr,
-                        (long)kTokens * 3 * kDim, np, 3 * kDim, kDim, EPI_F32, (long)kTokens * 2 * kDim, 0);
+        for (int t = kTokens - 2; t < kTokens; ++t) {   // the ReLU'd location / class rows: LayerNorm'ed rows x Wqkv as usual (VETO_MIXED: mixed operands)
+          rc = run_gemm(h, s, "gemm_qkv0_lc", ws.a + (size_t)t * 2 * kDim, mixed ? w.qkv_m : w.qkv, nullptr, nullptr, 0,
+                        qkv + (size_t)t * 3 * kDim, nullptr, (long)kTokens * 3 * kDim, np, 3 * kDim, kDim, EPI_F32, (long)kTokens * 2 * kDim, 0,
+                        DropSite(), mixed ? w.exp_m + 0 : nullptr);
           if (rc) return rc;
         }
       } else if (!last) {
