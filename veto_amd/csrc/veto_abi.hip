@@ -542,7 +542,8 @@ int veto_forward(veto_handle_t h, void* stream, const veto_inputs_t* in, void* w
   const bool qkv0_tables = L >= 2 && !tables_off;
   static const bool fold_off = getenv("VETO_CLS_FOLD") && !strcmp(getenv("VETO_CLS_FOLD"), "0");           // A/B knob
   const bool fold_last = !fold_off && H <= cls_fold_max_heads();   // last layer in the folded CLS form (attention.hip)
-  // VETO_MIXED: the four token-row Linears of every layer but the last take fp16 + e4m3 operands (common.h); the per-object and
+  // VETO_MIXED: the four token-row Linears of every layer but the last, and layer 0's QKV launches of the location / class token
+  // rows, take fp16 + e4m3 operands (common.h); the other per-object and
   // CLS-row GEMMs (8 % of the GEMM work) stay on split-bf16 operands.  The out projection only behind the MFMA attention kernel.
   const bool mixed = h->cfg.precision == VETO_MIXED;
   const bool mixed_out = mixed && attention_reads_tables(H);
