@@ -297,6 +297,13 @@ int veto_profile_reset(veto_handle_t h);
 int veto_debug_gemm(void* stream, const float* a, const float* w, const float* bias, float* c, int32_t m,
                     int32_t n, int32_t k, int32_t precision, void* workspace, size_t workspace_bytes);
 size_t veto_debug_gemm_workspace_bytes(int32_t m, int32_t n, int32_t k);
+/* ---- test hook: the same GEMM (3-term split-bf16) in its other forms: block-diagonal weights -- column tile j (192 columns) of C
+ * multiplies only the k-steps (32 k's each) [(j / kb_tiles) * kb_steps, + kb_steps) of the rows, the rest of w is ignored;
+ * kb_tiles = 0: dense -- and the output forms out_form 0 = fp32 [m, n], 1 = split rows (m x 2n bf16: per 32 columns 32 hi, then
+ * 32 lo), 2 = 3-byte floats (m x 3n bytes: the top three bytes of the fp32 rounded to nearest even).  The folded last layer of the
+ * predictor is built from these (roi_relation_predictors.py:4118-4131 -> model_veto.py:85-96 for the CLS query). */
+int veto_debug_gemm_forms(void* stream, const float* a, const float* w, void* c, int32_t m, int32_t n, int32_t k,
+                          int32_t kb_tiles, int32_t kb_steps, int32_t out_form, void* workspace, size_t workspace_bytes);
 
 /* ---- test / measurement hook: the FeedForward block of one layer, x <- x + W2 . gelu(W1 . a + b1) + b2 (model_veto.py:137-143
  * with the residual of :21) on VETO_MIXED operands; mode 0 = two GEMM launches with the hidden activation in HBM, mode 1 = the

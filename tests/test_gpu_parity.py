@@ -266,6 +266,54 @@ def test_fused_layer_tail(m):
     assert (xs[0] - xs[1]).abs().max().item() < 3e-4
 
 
+@pytest.mark.parametrize("m,n,k,kb_tiles,kb_steps", [(1000, 576, 576, 0, 0), (5000, 4608, 768, 3, 3), (3000, 768, 4608, 1, 36),
+                                                      (300, 1152, 192, 2, 2)])
+def test_gemm_block_diagonal_and_output_forms(m, n, k, kb_tiles, kb_steps):
+    """The round-3 forms of the split-row GEMM (veto_debug_gemm_forms): block-diagonal weights -- column tile j multiplies only the
+    k-steps of its block, the rest of w (here: garbage) is ignored -- and the split-row / 3-byte-float epilogues, against fp64.
+    The second and third shapes are the two block products of the folded last layer (veto_abi.hip)."""
+    from veto_amd import native
+    lib = native.load_library()
+    dev = _dev()
+    g = torch.Generator(device="cpu").manual_seed(m + n)
+    a = torch.randn(m, k, generator=g).to(dev)
+    w = (torch.randn(n, k, generator=g) * 0.05).to(dev)
+    wd = w.double()
+    if kb_tiles:        # the reference multiplies by the block-diagonal part only; the kernel must never read the rest
+        mask = torch.zeros(n, k, dtype=torch.bool, device=dev)
+        for j in range(n // 192):
+            k0 = (j // kb_tiles) * kb_steps * 32
+            mask[j * 192:(j + 1) * 192, k0:k0 + kb_steps * 32] = True
+        wd = wd * mask
+        w = torch.where(mask, w, torch.full_like(w, float("nan")))
+    ref = a.double() @ wd.t()
+    scale = (a.abs().double() @ wd.abs().t()).clamp_min(1e-6)
+    ws = torch.empty(lib.veto_debug_gemm_workspace_bytes(m, n, k), dtype=torch.uint8, device=dev)
+
+    def run(form, out):
+        native.check(lib.veto_debug_gemm_forms(None, a.data_ptr(), w.data_ptr(), out.data_ptr(), m, n, k, kb_tiles, kb_steps, form,
+                                               ws.data_ptr(), ws.numel()))
+        torch.cuda.synchronize()
+
+    c = torch.full((m, n), float("nan"), device=dev)
+    run(0, c)
+    assert torch.isfinite(c).all()
+    assert ((c.double() - ref).abs() / scale).max().item() < 2e-5
+    sp = torch.zeros(m, 2 * n, dtype=torch.bfloat16, device=dev)
+    run(1, sp)
+    sp = sp.view(m, n // 32, 2, 32).double()
+    dec = (sp[:, :, 0] + sp[:, :, 1]).reshape(m, n)                      # hi + lo: a 16-bit significand of the fp32 result
+    assert ((dec - c.double()).abs() / c.abs().double().clamp_min(1e-20)).max().item() < 2.0 ** -16
+    f24 = torch.zeros(m, 3 * n, dtype=torch.uint8, device=dev)
+    run(2, f24)
+    b = f24.view(m, n, 3).to(torch.int32)
+    bits = (b[:, :, 0] << 8) | (b[:, :, 1] << 16) | (b[:, :, 2] << 24)
+    dec24 = bits.view(torch.float32)
+    rel = ((dec24.double() - c.double()).abs() / c.abs().double().clamp_min(1e-20)).max().item()
+    assert rel <= 2.0 ** -16, rel                                        # round to nearest at 16 significand bits
+    assert ((dec24.view(torch.int32) & 0xFF) == 0).all()
+
+
 def test_fused_layer_tail_full_size_hand_off():
     """The layer-tail kernel at the headline size (287 280 rows: nine panels per workgroup, every CU streaming): the LayerNorm2
     rows a workgroup writes and re-reads within the launch must be the fresh ones in EVERY row (an L1 line of the rows they replace

@@ -1549,6 +1549,34 @@ int veto_debug_gemm(void* stream, const float* a, const float* w, const float* b
   return VETO_OK;
 }
 
+// Test hook of the round-3 forms of the split-row GEMM: block-diagonal weights (kb_tiles > 0: column tile n multiplies only the
+// k-steps [(n / kb_tiles) * kb_steps, + kb_steps) -- everything outside those blocks of w is ignored) and the output forms:
+// out_form 0 = fp32 rows [m, n], 1 = split rows (m x 2n bf16: per 32 columns 32 hi then 32 lo), 2 = 3-byte floats (m x 3n bytes).
+// Workspace as for veto_debug_gemm.
+int veto_debug_gemm_forms(void* stream, const float* a, const float* w, void* c, int32_t m, int32_t n, int32_t k, int32_t kb_tiles,
+                          int32_t kb_steps, int32_t out_form, void* workspace, size_t workspace_bytes) {
+  if (!a || !w || !c || !workspace) return fail(VETO_ERR_INVALID, "null argument");
+  if (out_form < 0 || out_form > 2) return fail(VETO_ERR_INVALID, "out_form must be 0, 1 or 2");
+  if (workspace_bytes < veto_debug_gemm_workspace_bytes(m, n, k)) return fail(VETO_ERR_WORKSPACE, "workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  const size_t mp = (size_t)gemm_rows_padded(m);
+  char* base = (char*)workspace;
+  __bf16* a_s = (__bf16*)base;
+  __bf16* w_s = (__bf16*)(base + align_up(mp * k * 4, 256));
+  HIP_TRY(hipMemsetAsync(base, 0, align_up(mp * k * 4, 256), s));
+  HIP_TRY(launch_split_rows(a, a_s, (size_t)m, k, s));
+  HIP_TRY(launch_split_rows(w, w_s, (size_t)n, k, s));
+  GemmArgs g{};
+  g.a = a_s; g.w = w_s; g.M = m; g.N = n; g.K = k;
+  g.kb_tiles = kb_tiles; g.kb_steps = kb_steps;
+  if (out_form == 1) { g.c_split = (__bf16*)c; g.ldc = 2L * n; }
+  else { g.c = (float*)c; g.ldc = n; }
+  hipError_t e = launch_gemm_split(g, out_form == 1 ? EPI_SPLIT : out_form == 2 ? EPI_F24 : EPI_F32, 0, s);
+  if (e != hipSuccess) return fail(e == hipErrorInvalidValue ? VETO_ERR_INVALID : VETO_ERR_HIP,
+                                   "gemm launch failed (N a multiple of 192, K of 32, the blocks must tile K): %s", hipGetErrorString(e));
+  return VETO_OK;
+}
+
 // Test / measurement hook of the FeedForward block (model_veto.py:137-143 + the residual of :21) on VETO_MIXED operands:
 // x <- x + W2 . gelu(W1 . a + b1) + b2 for m token rows.  mode 0 = the two GEMM launches (fc1 with the GELU epilogue writing
 // the hidden activation as mixed rows, fc2 with the residual epilogue), mode 1 = the fused kernel (ffn_fused.hip).
