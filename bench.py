@@ -334,9 +334,9 @@ def extra_lines(args, dev, batch, sd):
     dep = torch.from_numpy(batch["roi_depth_features"]).to(dev)
     n_pairs = sum(int(p.shape[0]) for p in pairs)
 
-    def timed(model, steps=20):
+    def timed(model, steps=30):
         with torch.no_grad():
-            for _ in range(3):
+            for _ in range(6):
                 o = model(props, pairs, None, None, roi_features=rgb, roi_depth_features=dep)
             torch.cuda.synchronize(dev)
             t0 = time.perf_counter()
