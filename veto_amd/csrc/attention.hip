@@ -122,14 +122,12 @@ __global__ __launch_bounds__(128, 2) void attention_mfma_kernel(AttnArgs a) {
   __shared__ __attribute__((aligned(16))) char smem[2 * WAVE_LDS];
 
   // A wave works on its own LDS region: no workgroup barrier anywhere (LDS operations of one wave complete in order; the two
-  // barriers of the first version cost 3 % of the launch).  The launcher normally gives every wave ONE item; with fewer
-  // workgroups than items (VETO_ATTN_BLOCKS_PER_CU, an A/B knob) a wave walks items gw, gw + (waves of the grid), ... and requests
-  // the operands of its next item as soon as the registers of the current one have been converted into the LDS images.
+  // barriers of the first version cost 3 % of the launch).  Every wave has ONE item (persistent waves that prefetch their next
+  // item's operands were measured 13 % slower: the dispatcher's refill of finished workgroups spreads the memory phases better
+  // than waves that march in step).
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const long gw = (long)blockIdx.x * 2 + w;
-  const long total = (long)a.n_pair * a.heads;
-  const long stride = (long)gridDim.x * 2;
-  if (gw >= total) return;
+  const long item = (long)blockIdx.x * 2 + w;
+  if (item >= (long)a.n_pair * a.heads) return;
   char* base = smem + w * WAVE_LDS;
   char* q_hi = base;
   char* q_lo = base + QK_PLANE;
@@ -142,7 +140,6 @@ __global__ __launch_bounds__(128, 2) void attention_mfma_kernel(AttnArgs a) {
   f32x4 ld[ROUNDS][2];
   f32x4 ldb[TAB ? ROUNDS : 1][2];     // TAB: the object-side table row of a patch token
   float rs[TAB ? ROUNDS : 1];         // TAB: rstd of the token row
-  auto request = [&](long item) {
   const int pair = (int)(item / a.heads), head = (int)(item % a.heads);
   const float* src0 = a.qkv + (size_t)pair * kTokens * (3 * kDim) + head * DH;
   const float* tab_s = nullptr;
@@ -179,10 +176,6 @@ __global__ __launch_bounds__(128, 2) void attention_mfma_kernel(AttnArgs a) {
       ld[r][1] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
   }
-  };
-  request(gw);
-  for (long item = gw; item < total; item += stride) {
-  const int pair = (int)(item / a.heads), head = (int)(item % a.heads);
 #pragma unroll
   for (int r = 0; r < ROUNDS; ++r) {
     const int e = lane + 64 * r;
@@ -230,7 +223,6 @@ __global__ __launch_bounds__(128, 2) void attention_mfma_kernel(AttnArgs a) {
     *(uint16_t*)(vt_hi + d * VROW + 38) = 0;
     *(uint16_t*)(vt_lo + d * VROW + 38) = 0;
   }
-  if (!TAB && item + stride < total) request(item + stride);
 
   // ---- S^T = K Q^T: row = key j, column = query i ----------------------------------------------
   const int r = lane & 31, h = lane >> 5;
@@ -342,8 +334,6 @@ __global__ __launch_bounds__(128, 2) void attention_mfma_kernel(AttnArgs a) {
     *(bf16x8*)dst = hi;
     *(bf16x8*)(dst + 32) = lo;
   }
-  if constexpr (TAB) break;   // (one item per wave: no loop-carried registers for the compiler to keep)
-  }   // items
 }
 
 
@@ -741,8 +731,8 @@ __global__ __launch_bounds__(256, 3) void cls_fold_attention_mfma_kernel(const f
 int cls_fold_max_heads() { return kFoldMaxHeads; }
 
 bool cls_fold_reads_f24() {
-  static const bool valu = getenv("VETO_CLS_MFMA") && !strcmp(getenv("VETO_CLS_MFMA"), "0");
-  static const bool f32 = getenv("VETO_QKV_F24") && !strcmp(getenv("VETO_QKV_F24"), "0");
+  static const bool valu = env_knob_is("VETO_CLS_MFMA", "0");
+  static const bool f32 = env_knob_is("VETO_QKV_F24", "0");
   return !valu && !f32;
 }
 
@@ -750,7 +740,7 @@ hipError_t launch_cls_fold_attention(const float* x, const float* ln_w, const fl
                                      hipStream_t s, bool u_f24) {
   if (heads <= 0 || heads > kFoldMaxHeads || kDim % heads != 0 || n_pair <= 0) return hipErrorInvalidValue;
   const float scale = 1.0f / sqrtf((float)(kDim / heads));
-  static const bool valu = getenv("VETO_CLS_MFMA") && !strcmp(getenv("VETO_CLS_MFMA"), "0");     // A/B knob: the fp32 VALU form
+  static const bool valu = env_knob_is("VETO_CLS_MFMA", "0");     // A/B knob of the parity tests: the fp32 VALU form
   if (u_f24 && valu) return hipErrorInvalidValue;
   if (valu) VETO_LAUNCH(cls_fold_attention_kernel, dim3(n_pair), dim3(256), 0, s, x, ln_w, ln_b, u, abar, n_pair, heads, scale);
   else if (u_f24) VETO_LAUNCH(cls_fold_attention_mfma_kernel<true>, dim3(n_pair), dim3(256), 0, s, x, ln_w, ln_b, u, abar, n_pair, heads, scale);
@@ -771,13 +761,8 @@ hipError_t launch_cls_fold_attention(const float* x, const float* ln_w, const fl
   return hipGetLastError();
 }
 
-static bool attn_force_valu() {
-  static const bool f = getenv("VETO_ATTN_VALU") != nullptr;  // A/B knob for the parity tests
-  return f;
-}
-
 bool attention_reads_tables(int heads) {
-  if (heads <= 0 || kDim % heads != 0 || attn_force_valu()) return false;
+  if (heads <= 0 || kDim % heads != 0) return false;
   const int dh = kDim / heads;
   return dh == 72 || dh == 96;
 }
@@ -785,23 +770,9 @@ bool attention_reads_tables(int heads) {
 hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
   if (kDim % a.heads != 0) return hipErrorInvalidValue;
   const int dh = kDim / a.heads;
-  const bool force_valu = attn_force_valu();
-  if (!force_valu && (dh == 72 || dh == 96)) {
+  if (dh == 72 || dh == 96) {
     const long items = (long)a.n_pair * a.heads;
     unsigned blocks = (unsigned)((items + 1) / 2);
-    static int num_cu = 0;
-    if (num_cu == 0) {
-      int dev = 0;
-      hipDeviceProp_t prop;
-      if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorInvalidDevice;
-      num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 1;
-    }
-    // VETO_ATTN_BLOCKS_PER_CU=n: persistent waves (n workgroups per CU; four fit the LDS), each prefetching its next item.  Measured
-    // SLOWER than one item per wave (0.94-0.96 vs 0.83-0.86 ms for the two middle-layer launches at n = 4, 1.02 at n = 3): the
-    // hardware dispatcher's refill of finished workgroups spreads the memory phases better than waves that march in step.  Default
-    // 0 = one item per wave (the loop below then runs once).
-    static const int per_cu = getenv("VETO_ATTN_BLOCKS_PER_CU") ? atoi(getenv("VETO_ATTN_BLOCKS_PER_CU")) : 0;
-    if (!a.sw && per_cu > 0 && blocks > (unsigned)(num_cu * per_cu)) blocks = (unsigned)(num_cu * per_cu);
     if (a.sw) {
       if (!a.ow || !a.stats || !a.vec || !a.subj || !a.obj || a.cls_only) return hipErrorInvalidValue;
       if (dh == 72) VETO_LAUNCH((attention_mfma_kernel<72, true>), dim3(blocks), dim3(128), 0, s, a);

@@ -607,8 +607,7 @@ hipError_t launch_attention_backward(const float* qkv, const float* dout, float*
                                      hipStream_t s) {
   if (heads <= 0 || kDim % heads != 0 || n_pair <= 0 || (!dqkv == !dqkv_split)) return hipErrorInvalidValue;
   const int dh = kDim / heads;
-  static const bool force_valu = getenv("VETO_ATTN_BWD_VALU") != nullptr;      // A/B knob
-  if (!force_valu && (dh == 72 || dh == 96)) {
+  if (dh == 72 || dh == 96) {
     const unsigned blocks = (unsigned)(((long)n_pair * heads + 1) / 2);
     if (dh == 72) VETO_LAUNCH(attention_backward_mfma_kernel<72>, dim3(blocks), dim3(128), 0, s, qkv, dout, dqkv, dqkv_split, n_pair, heads, cls_only);
     else VETO_LAUNCH(attention_backward_mfma_kernel<96>, dim3(blocks), dim3(128), 0, s, qkv, dout, dqkv, dqkv_split, n_pair, heads, cls_only);

@@ -176,7 +176,10 @@ __device__ __forceinline__ u32x3 pack_f24x4(f32x4 v) {
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     const uint32_t b = __float_as_uint(v[e]);
-    u[e] = b + 0x7fu + ((b >> 8) & 1u);            // round to nearest even at bit 8 (the low byte is dropped below)
+    const uint32_t r = b + 0x7fu + ((b >> 8) & 1u);   // round to nearest even at bit 8 (the low byte is dropped below)
+    // a NaN keeps its bits (v_cmp_class + v_cndmask): the increment would carry a payload of all ones out of the mantissa and
+    // store +-0; Inf (mantissa 0) is unchanged by the rounding either way
+    u[e] = __builtin_isnan(v[e]) ? (b | 0x00400000u) : r;
   }
   // bytes, low address first: u0.b1 u0.b2 u0.b3 | u1.b1 u1.b2 u1.b3 | u2.b1 .. | u3.b1 u3.b2 u3.b3   (v_perm_b32: selector byte
   // values 0..3 pick bytes of the SECOND operand, 4..7 of the first)

@@ -44,11 +44,17 @@
 #include <cstdlib>
 
 // timing ablations (tools/ffn_variants.sh; results are WRONG with any of them set): 1 = no DMA, 2 = no MFMA, 4 = no fragment
-// reads, 8 = no hidden conversion, 16 = no panel epilogue
+// reads, 8 = no hidden conversion, 16 = no panel epilogue, 32 = the e4m3 stages move 3/5 (activation + weight slice) or 2/3 (weight slice)
+// of their bytes: the DMA volume of 3-byte operand rows (fp16 + ONE e4m3 plane) without their conversion work
 #ifndef FFN_ABLATE
 #define FFN_ABLATE 0
 #endif
 // micro-variants (A/B with tools/ffn_variants.sh)
+// the wait states in front of every inline-asm MFMA (see mma() below).  -DFFN_MMA_NOP='""' builds the kernel WITHOUT them: the
+// negative control of tests/test_ffn_asm.py (the audit must then report hazards)
+#ifndef FFN_MMA_NOP
+#define FFN_MMA_NOP "s_nop 1\n\t"
+#endif
 #ifndef FFN_CONV_G0
 #define FFN_CONV_G0 0       // first of the three MFMA groups of a sub-stage that carry a piece of the hidden conversion (0..3)
 #endif
@@ -90,6 +96,8 @@ template <int V> struct Tag { static constexpr int value = V; };
 // the transfer (it would otherwise put s_waitcnt vmcnt(0) in front of every later ds_read of this wave; the kernel counts
 // its own vmcnt).  The s_nop covers the SALU-writes-M0 -> LDS-DMA wait state and the five states between a scalar write of
 // the base (the compiler computes it right in front of the statement) and its use by a vector-memory instruction.
+// M0 cannot be named as a clobber (the compiler reserves it and warns); it holds nothing of the compiler's in these kernels -- LDS
+// instructions need no M0 on gfx9+, and tests/test_ffn_asm.py fails if a compiler-generated instruction ever reads or writes it.
 __device__ __forceinline__ void glds16(const char* base, unsigned voff, unsigned lds_addr) {
   if (FFN_ABLATE & 1) return;
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_addr), "v"(voff), "s"(base) : "memory");
@@ -156,16 +164,14 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs g) {
   const int my_panels = g.n_panels > b ? (g.n_panels - b + G - 1) / G : 0;   // panels b, b + G, ...
   if (my_panels == 0) return;
 
-  // Start-phase stagger (speed only): equal panels keep the persistent workgroups in lockstep, so all 256 CUs would reach their
-  // panel epilogue -- 0.6 / 0.9 MB of HBM traffic per workgroup with no matrix work beside it -- at the same moment and share
-  // the HBM bandwidth (~10 B/clk/CU: 42 us per panel, measured).  The phases are per XCD (b & 7): the 32 workgroups of an XCD
-  // stay in step, because they stream the same weight stages through their shared L2 at the same time.
-  // ... What does pay (a little): the workgroups that have one panel FEWER than the others (n_panels is rarely a multiple of the
-  // grid) have a whole panel of slack, so they start `late` microseconds late for free and their epilogues fall into the others'
-  // matrix phases: 2.27 -> 2.22-2.25 ms per layer-tail launch with 59 of 256 workgroups shifted by ~90 us.
+  // Equal panels keep the persistent workgroups in lockstep, so all 256 CUs reach their panel epilogue -- 0.6 / 0.9 MB of HBM
+  // traffic per workgroup with no matrix work beside it -- at the same moment.  Start offsets per XCD or inside an XCD were
+  // measured null (what they save in the epilogues they cost at the end of the launch).  What does pay (a
+  // little): the workgroups that have one panel FEWER than the others (n_panels is rarely a multiple of the grid) have a whole
+  // panel of slack, so they start `late` microseconds late for free and their epilogues fall into the others' matrix phases:
+  // 2.27 -> 2.22-2.25 ms per layer-tail launch with 59 of 256 workgroups shifted by ~90 us.
   if (my_panels >= 2 && my_panels < (g.n_panels + G - 1) / G)
     for (int i = g.late; i > 0; --i) __builtin_amdgcn_s_sleep(32);               // ~1 us per unit
-  for (int i = g.stagger * (b & 7); i > 0; --i) __builtin_amdgcn_s_sleep(32);
   if (MODE != 1)
     for (int i = tid; i < FH; i += 512) ((float*)(smem + kB1Off))[i] = g.b1[i];
   for (int i = tid; i < kDim; i += 512) ((float*)(smem + kB2Off))[i] = g.b2[i];
@@ -187,12 +193,14 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs g) {
   // instruction k (of 5) of fc1 stage ks of hidden chunk c: 16 KiB of activation rows (k = 0, 1) + 24 KiB of W1 rows (2..4)
   auto issue_fc1 = [&](const char* a_panel, int c, int ks, int slot, int k) {
     const unsigned dst = lds0 + slot * kSlot + w * 1024;
+    if ((FFN_ABLATE & 32) && (ks & 1) && (k == 1 || k == 4)) return;
     if (k < 2) glds16(a_panel + ks * 128 + k * 64 * kRow1, voff1, dst + k * 8 * 1024);
     else glds16(g.w1 + (size_t)c * ((size_t)FC * kRow1) + ks * 128 + (k - 2) * 64 * kRow1, voff1, dst + kAB + (k - 2) * 8 * 1024);
   };
   // instruction k (of 3) of an fc2 sub-stage: 24 KiB of W2 rows (column third t, 128-byte slice `slice` of the row)
   auto issue_fc2 = [&](int slice, int t, int slot, int k) {
     const unsigned dst = lds0 + slot * kSlot + w * 1024 + kAB;
+    if ((FFN_ABLATE & 32) && (slice & 1) && k == 2) return;
     glds16(g.w2 + (size_t)t * ((size_t)FC * kRow2) + slice * 128 + (size_t)k * 64 * kRow2, voff2, dst + k * 8 * 1024);
   };
 
@@ -200,6 +208,7 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs g) {
   // t > 0: the weight third (k = 0..2).  The weight rows have K = 576 (row pitch kRow1).
   auto issue_out = [&](const char* a_panel, int ks, int t, int slot, int k) {
     const int kw = t == 0 ? k - 2 : k;
+    if ((FFN_ABLATE & 32) && (ks & 1) && (t == 0 ? (k == 1 || k == 4) : k == 2)) return;
     if (t == 0 && k < 2) glds16(a_panel + ks * 128 + k * 64 * kRow1, voff1, lds0 + w * 1024 + k * 8 * 1024);
     else if (kw >= 0 && kw < 3)
       glds16(w_out + (size_t)t * ((size_t)FC * kRow1) + ks * 128 + kw * 64 * kRow1, voff1, lds0 + slot * kSlot + kAB + w * 1024 + kw * 8 * 1024);
@@ -232,11 +241,11 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs g) {
       return;
     }
     if constexpr (KIND == 0) {
-      asm("s_nop 1\n\tv_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(fw0), "v"(fa0));
-      asm("s_nop 1\n\tv_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(fw1), "v"(fa1));
+      asm(FFN_MMA_NOP "v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(fw0), "v"(fa0));
+      asm(FFN_MMA_NOP "v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(fw1), "v"(fa1));
     } else {
       const i32x8 w8 = __builtin_shufflevector(fw0, fw1, 0, 1, 2, 3, 4, 5, 6, 7), a8 = __builtin_shufflevector(fa0, fa1, 0, 1, 2, 3, 4, 5, 6, 7);
-      asm("s_nop 1\n\tv_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0]" : "+v"(acc) : "v"(w8), "v"(a8), "v"(scale), "v"(0x7f7f7f7f));
+      asm(FFN_MMA_NOP "v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0]" : "+v"(acc) : "v"(w8), "v"(a8), "v"(scale), "v"(0x7f7f7f7f));
     }
   };
   // MFMA result -> VALU / LDS reader: more than 18 wait states, tied to the accumulators it fences (the MFMA statements are
@@ -734,9 +743,7 @@ hipError_t launch_panel(FfnArgs g, int mode, hipStream_t s) {
     if (num_cu < 1) num_cu = 1;
   }
   g.n_panels = (g.M + FR - 1) / FR;
-  static const int stagger = getenv("VETO_FFN_STAGGER") ? atoi(getenv("VETO_FFN_STAGGER")) : 0;   // A/B knob (speed only)
-  g.stagger = stagger;
-  static const int late = getenv("VETO_FFN_LATE") ? atoi(getenv("VETO_FFN_LATE")) : 90;                 // A/B knob (speed only)
+  static const int late = env_knob_int("VETO_FFN_LATE", 90);      // (speed only; 0 in one arm of the parity tests)
   g.late = late;
   const int nblocks = g.n_panels < num_cu ? g.n_panels : num_cu;   // one persistent workgroup per CU (LDS: 159 KiB each)
   if (mode == 0) VETO_LAUNCH(ffn_fused_kernel<0>, dim3(nblocks), dim3(512), 0, s, g);
@@ -762,7 +769,7 @@ hipError_t launch_panel(FfnArgs g, int mode, hipStream_t s) {
         fprintf(stderr, "  (bias adds | x stores | LN pass 1 | pass 2 | normalise+stores | drain)\n");
       }
     }
-    if (!printed++) {
+    if (mode != 1 && !printed++) {
       static unsigned long long tl[2 * 36 * 9];
       hipMemcpyFromSymbol(tl, HIP_SYMBOL(g_ffn_timeline), sizeof(tl));
       for (int wv = 0; wv < 2; ++wv)

@@ -135,27 +135,11 @@ __global__ __launch_bounds__(64 * (NCONS + NLOAD), 3) void gemm_split_ps_kernel(
   const int nk = g.kb_tiles > 0 ? g.kb_steps : K / BK / ksp;   // k-steps per tile (block-diagonal weights: the steps of the tile's block)
   // tile of round `it` for this workgroup; gridDim.x is a multiple of 8 (launcher)
   const int per_xcd = gridDim.x >> 3;
-  // g.panel_major (A/B, speed only): a workgroup walks the tiles_n tiles of ONE row panel back to back (panels dealt like tiles)
-  const int pm = g.panel_major == 1 ? g.tiles_n : 1;
-  // g.panel_major == 2 (A/B, speed only; tiles_n even): the XCDs work in pairs, each XCD of a pair on one HALF of the column
-  // tiles of the same row panels, so that its half of the weight matrix stays in its 4 MB L2
-  const int hn = g.tiles_n >> 1;
-  auto tile_of = [&](int it) {
-    if (g.panel_major == 2) {
-      const int lin = (it * 4 + ((b & 7) >> 1)) * per_xcd + (b >> 3);
-      return (lin / hn) * g.tiles_n + (b & 1) * hn + lin % hn;
-    }
-    return ((it / pm * 8 + (b & 7)) * per_xcd + (b >> 3)) * pm + it % pm;
-  };
+  auto tile_of = [&](int it) { return (it * 8 + (b & 7)) * per_xcd + (b >> 3); };
   int my_tiles = 0;
   while (tile_of(my_tiles) < ntiles) ++my_tiles;  // tile_of is increasing in `it`
   if (my_tiles == 0) return;
   const int nstages = my_tiles * nk;
-  // Phase stagger (speed only): equal tiles keep the persistent workgroups in lockstep, so all 256 CUs
-  // would reach their epilogue -- a chip-wide HBM burst of 50-100 MB with no MFMA work beside it -- at
-  // the same moment.  Starting the workgroups of an XCD in 4 phases spreads the bursts under the
-  // other phases' matrix work.
-  for (int i = g.stagger * ((b >> 3) & 3); i > 0; --i) __builtin_amdgcn_s_sleep(127);
 
   if (w >= NCONS) {
     // ------------------------------- loader wave ------------------------------------------------
@@ -598,9 +582,6 @@ hipError_t launch_gemm_split(GemmArgs g, int epi, int precision, hipStream_t s) 
 
 // g.tiles_m / g.tiles_n / g.lda are already filled by launch_gemm_split.
 hipError_t launch_gemm_split_ps(GemmArgs g, int epi, int precision, hipStream_t s) {
-  static const int stagger = getenv("VETO_GEMM_STAGGER") ? atoi(getenv("VETO_GEMM_STAGGER")) : 0;
-  g.stagger = stagger;
-  static const int panel_major = getenv("VETO_GEMM_PANEL") ? atoi(getenv("VETO_GEMM_PANEL")) : 0;   // A/B knob (speed only)
   static int num_cu = 0;
   if (num_cu == 0) {
     int dev = 0;
@@ -610,8 +591,6 @@ hipError_t launch_gemm_split_ps(GemmArgs g, int epi, int precision, hipStream_t 
     if (num_cu < 8) num_cu = 8;
   }
   const int ksp = epi == EPI_ATOMIC && g.k_splits > 1 ? g.k_splits : 1;
-  g.panel_major = (panel_major == 1 && g.tiles_n == 3 && epi == EPI_RESID) ? 1
-                  : (panel_major == 2 && g.tiles_n % 2 == 0 && g.tiles_n >= 4 && ksp == 1 && !g.tn) ? 2 : 0;
   if ((g.K / BK) % ksp != 0) return hipErrorInvalidValue;
   if (g.kb_tiles > 0 && (ksp != 1 || g.tn || g.fmt == FMT_MIXED || g.kb_steps <= 0 || g.tiles_n % g.kb_tiles != 0 ||
                          (g.tiles_n / g.kb_tiles) * g.kb_steps != g.K / BK))

@@ -26,8 +26,6 @@ struct GemmArgs {
   unsigned drop_thresh;
   float drop_scale;
   int tiles_m, tiles_n;  // filled by the launcher
-  int stagger;           // persistent kernel: start-phase stagger in units of s_sleep(127) (speed only)
-  int panel_major;       // persistent kernel: tiles of one row panel back to back on one workgroup (speed only)
   // tn (EPI_ATOMIC only, weight gradients): C[M, N] += A^T B with BOTH operands row-major in the reduction index, i.e. the
   // split rows the backward already holds: a = dY split rows [k_valid, lda] (M = its column count), w = X split rows
   // [k_valid, ldw] (N = its column count), K = the reduction length rounded up to 32 * k_splits.  Reduction rows >= k_valid
@@ -46,6 +44,10 @@ struct GemmArgs {
   const __bf16* zero;
 };
 
+// Environment knobs (veto_abi.hip): every one selects a path that a parity test compares against the default (INTEGRATION.md
+// lists them); call sites cache the answer in a function-local static.
+bool env_knob_is(const char* name, const char* value);   // the variable is set to exactly `value`
+int env_knob_int(const char* name, int dflt);
 int gemm_rows_padded(int m);
 // precision: 0 = three split-bf16 terms, 1 = one; g.fmt == FMT_MIXED selects the fp16 + e4m3 kernel regardless
 hipError_t launch_gemm_split(GemmArgs g, int epi, int precision, hipStream_t s);
@@ -79,7 +81,6 @@ struct FfnArgs {
   const float* lnm_w;
   const float* lnm_b;
   int n_panels;          // filled by the launcher
-  int stagger;           // filled by the launcher (speed only): start delay of workgroup b = (b & 7) * stagger * s_sleep(32) (~1 us): one phase per XCD
   int late;              // filled by the launcher (speed only): start delay (~us) of the workgroups that have one panel fewer than the others
 };
 int ffn_panel_rows();

@@ -5,6 +5,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -62,11 +63,22 @@ size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 }  // namespace
 
+namespace veto {
+bool env_knob_is(const char* name, const char* value) {
+  const char* v = getenv(name);
+  return v && !strcmp(v, value);
+}
+int env_knob_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v ? atoi(v) : dflt;
+}
+}  // namespace veto
+
 // Padded head width of the block form of the folded last layer, or 0 when the products are used instead: the head width rounded up
 // to 32 k's must divide a 192-column GEMM tile (heads 12 / 8 / 6 / 3 of the 576 columns), and the form can be switched off
 // (VETO_FOLD_BLOCKS=0, A/B knob).
 static int fold_block_width(int heads) {
-  static const bool off = getenv("VETO_FOLD_BLOCKS") && !strcmp(getenv("VETO_FOLD_BLOCKS"), "0");
+  static const bool off = env_knob_is("VETO_FOLD_BLOCKS", "0");
   if (off || heads <= 0 || kDim % heads != 0) return 0;
   const int dhp = (kDim / heads + 31) / 32 * 32;
   return 192 % dhp == 0 && (heads * dhp) % 192 == 0 ? dhp : 0;
@@ -468,6 +480,7 @@ int veto_load_weights(veto_handle_t h, const char* name, const float* src, size_
   HIP_TRY(hipMemcpyAsync(h->raw + q.offset, src, numel * sizeof(float), hipMemcpyDefault, (hipStream_t)stream));
   q.loaded = true;
   h->dirty = true;
+  h->train_gen.clear();   // (no workspace's saved activations match the weights any more; also bounds the map)
   return VETO_OK;
 }
 
@@ -538,23 +551,21 @@ int veto_forward(veto_handle_t h, void* stream, const veto_inputs_t* in, void* w
   // Layer 0 in the per-object form: LayerNorm + QKV of the 16 patch tokens of every pair come from two
   // per-object tables SW = S W'^T, OW = O W'^T (S | O = the halves of patch_tab, W' = Wqkv diag(gamma)) -- a GEMM over the
   // n_obj*16 object rows instead of the n_pair*19 token rows.  Needs a layer behind it that reads LN1 rows as usual (L >= 2).
-  static const bool tables_off = getenv("VETO_QKV0_TABLES") && !strcmp(getenv("VETO_QKV0_TABLES"), "0");   // A/B knob
+  static const bool tables_off = env_knob_is("VETO_QKV0_TABLES", "0");   // A/B knob of the parity tests
   const bool qkv0_tables = L >= 2 && !tables_off;
-  static const bool fold_off = getenv("VETO_CLS_FOLD") && !strcmp(getenv("VETO_CLS_FOLD"), "0");           // A/B knob
+  static const bool fold_off = env_knob_is("VETO_CLS_FOLD", "0");         // A/B knob of the parity tests
   const bool fold_last = !fold_off && H <= cls_fold_max_heads();   // last layer in the folded CLS form (attention.hip)
   // VETO_MIXED: the four token-row Linears of every layer but the last, and layer 0's QKV launches of the location / class token
   // rows, take fp16 + e4m3 operands (common.h); the other per-object and
   // CLS-row GEMMs (8 % of the GEMM work) stay on split-bf16 operands.  The out projection only behind the MFMA attention kernel.
   const bool mixed = h->cfg.precision == VETO_MIXED;
   const bool mixed_out = mixed && attention_reads_tables(H);
-  static const bool ffn_off = getenv("VETO_FFN_FUSED") && !strcmp(getenv("VETO_FFN_FUSED"), "0");          // A/B knob
-  const bool ffn_fused = !ffn_off;   // VETO_MIXED: fc1 -> GELU -> fc2 + residual as one launch
-  static const bool out_off = getenv("VETO_OUT_FUSED") && !strcmp(getenv("VETO_OUT_FUSED"), "0");           // A/B knob
-  const bool out_fused = !out_off;   // VETO_MIXED: out projection + residual + LayerNorm2 as one launch on full rows
-  static const bool tail_off = getenv("VETO_TAIL_FUSED") && !strcmp(getenv("VETO_TAIL_FUSED"), "0");        // A/B knob
-  const bool tail_fused = !tail_off;   // ... and both of them as ONE launch per layer
-  static const bool ffn_ln_off = getenv("VETO_FFN_LN") && !strcmp(getenv("VETO_FFN_LN"), "0");              // A/B knob
-  static const bool qkv_f24_off = getenv("VETO_QKV_F24") && !strcmp(getenv("VETO_QKV_F24"), "0");           // A/B knob
+  // VETO_MIXED runs everything of a layer behind its attention as ONE panel launch (ffn_fused.hip MODE 2); VETO_TAIL_FUSED=0 (a knob
+  // the parity tests compare against) splits it into the out projection + LayerNorm2 launch and the FeedForward + LayerNorm1 launch
+  // of the same kernel.  VETO_PRECISE / VETO_FAST take the launch-per-Linear GEMMs and LayerNorm launches.
+  static const bool tail_off = env_knob_is("VETO_TAIL_FUSED", "0");
+  const bool tail_fused = !tail_off;
+  static const bool qkv_f24_off = env_knob_is("VETO_QKV_F24", "0");
   if (qkv0_tables) {
     const int R = n_obj * 16;
     HIP_TRY(launch_centre_split(ws.patch_tab, ws.ptab_split, R, s));
@@ -677,8 +688,8 @@ int veto_forward(veto_handle_t h, void* stream, const veto_inputs_t* in, void* w
       }
       if (!last) {
         // ... and the LayerNorm in front of the next layer's QKV GEMM in the FeedForward epilogue, when that GEMM takes mixed rows
-        const bool ffn_ln_next = mixed && ffn_fused && !ffn_ln_off && l + 1 < L - 1;
-        if (mixed_out && out_fused && ffn_fused && tail_fused) {
+        const bool ffn_ln_next = mixed && l + 1 < L - 1;
+        if (mixed_out && tail_fused) {
           // everything of the layer behind its attention in ONE launch (ffn_fused.hip, MODE 2): x1 = x + a Wo^T + bo stays in
           // registers, LayerNorm2(x1) is written in place over the attention output and streamed back as the FeedForward's
           // input, fc2 accumulates on top of x1, the epilogue stores x (and the next layer's LayerNorm1 rows)
@@ -691,7 +702,7 @@ int veto_forward(veto_handle_t h, void* stream, const veto_inputs_t* in, void* w
                        (double)M * kDim * 16 + 5.0 * kDim * kDim * 4);
           HIP_TRY(launch_layer_tail(f, s));
         } else {
-        if (mixed_out && out_fused) {
+        if (mixed_out) {
           // out projection + residual + LayerNorm2 in one launch on full rows (ffn_fused.hip, MODE 1): x <- x + a Wo^T + bo, then
           // a <- LayerNorm2(x) as mixed rows in place over the attention output
           FfnArgs f{};
@@ -708,7 +719,7 @@ int veto_forward(veto_handle_t h, void* stream, const veto_inputs_t* in, void* w
             HIP_TRY(launch_layernorm(ws.x, kDim, w.ln2_w, w.ln2_b, ws.a, M, s, mixed ? FMT_MIXED : FMT_SPLIT));
           }
         }
-        if (mixed && ffn_fused) {
+        if (mixed) {
           // FeedForward in one launch (ffn_fused.hip): the hidden activation never leaves the CU
           FfnArgs f{};
           f.a = (const char*)ws.a; f.w1 = (const char*)w.fc1_m; f.w2 = (const char*)w.fc2_m; f.b1 = w.fc1_b; f.b2 = w.fc2_b;
@@ -975,7 +986,7 @@ int veto_forward_train(veto_handle_t h, void* stream, const veto_inputs_t* in, c
   hipStream_t s = (hipStream_t)stream;
   HIP_TRY(hipSetDevice(h->cfg.device));
   if (h->dirty) { rc = finalize_weights(h, s); if (rc) return rc; }
-  h->train_gen[workspace] = h->weight_gen;
+  h->train_gen.erase(workspace);     // (stamped at the end: a failed forward leaves no workspace that veto_backward would accept)
   const int n_obj = in->n_obj, n_pair = in->n_pair, L = h->cfg.layers, H = h->cfg.heads, n_out = h->cfg.num_out;
   const int M = n_pair * kTokens;
   TrainWs ws = carve_train((char*)workspace, h, n_obj, n_pair);
@@ -1060,6 +1071,7 @@ int veto_forward_train(veto_handle_t h, void* stream, const veto_inputs_t* in, c
     HIP_TRY(launch_layernorm(xnext, kDim, h->layers[l + 1].ln1_w, h->layers[l + 1].ln1_b, ws.layers[l + 1].a1, M, s));
   }
   HIP_TRY(launch_head(ws.xout, h->head_wt, h->p("rel_out.bias"), out_logits, n_pair, n_out, s, (long)kDim));
+  h->train_gen[workspace] = h->weight_gen;
   return VETO_OK;
 }
 
