@@ -123,6 +123,35 @@ size_t veto_workspace_bytes(veto_handle_t h, int32_t n_obj, int32_t n_pair);
 int veto_forward(veto_handle_t h, void* stream, const veto_inputs_t* in, void* workspace,
                  size_t workspace_bytes, float* out_logits, const veto_debug_outputs_t* dbg);
 
+/* ---- saturation audit of the VETO_MIXED operands (diagnostic) ---------------------------------
+ * VETO_MIXED stores every activation that feeds a token-row Linear as fp16 + two e4m3 planes (value, residual x 2^11).  The
+ * conversions SATURATE (MODE.FP16_OVFL is set in every kernel that writes such rows): |a| > 448 clamps both e4m3 planes of that
+ * element at +-448 -- it then carries fp16 precision (2^-11) instead of 2^-16 -- and |a| > 65504 clamps its fp16 at +-65504, i.e.
+ * an Inf or an overflow becomes a FINITE wrong value where the fp32 reference would propagate Inf (a NaN stays a NaN).  Both
+ * happen silently in veto_forward.  This call makes them visible: it runs the same forward in its launch-per-stage form (every
+ * mixed-row operand exists in memory; logits equal to veto_forward's up to the rounding order of the fused kernels) and counts,
+ * behind every producer, the elements that sit AT the clamp values.  counts[layer * VETO_SAT_SITES + site] (host memory,
+ * capacity >= layers * VETO_SAT_SITES entries); the last layer runs on split-bf16 operands and reports zeros, layer 0 feeds only
+ * the location / class token rows through a mixed QKV projection.  Non-zero value_saturated / resid_saturated: those elements lost
+ * the correction terms (harmless in small numbers: the 1e-3 logit tolerance holds with 3 % of the hidden units at x 30 and some at
+ * x 300, tests/test_gpu_parity.py::test_parity_on_trained_like_activations).  Non-zero f16_saturated: the result is wrong; use
+ * VETO_PRECISE for this checkpoint. */
+enum veto_saturation_site {
+  VETO_SAT_QKV_IN = 0,    /* LayerNorm1 rows: the QKV projection's operand (model_veto.py:125-132 -> :85) */
+  VETO_SAT_ATTN_OUT = 1,  /* attention output: the out projection's operand (:94-96) */
+  VETO_SAT_FFN_IN = 2,    /* LayerNorm2 rows: fc1's operand (:137-139) */
+  VETO_SAT_HIDDEN = 3,    /* gelu(fc1): fc2's operand (:140-143) */
+  VETO_SAT_SITES = 4
+};
+typedef struct veto_saturation {
+  int64_t elements;          /* operand elements scanned at this site (0: the site does not exist in this layer) */
+  int64_t f16_saturated;     /* fp16 values at +-65504 */
+  int64_t value_saturated;   /* e4m3 value-plane bytes at +-448 */
+  int64_t resid_saturated;   /* e4m3 residual-plane bytes at +-448 */
+} veto_saturation_t;
+int veto_forward_saturation(veto_handle_t h, void* stream, const veto_inputs_t* in, void* workspace, size_t workspace_bytes,
+                            float* out_logits, veto_saturation_t* counts, int32_t capacity);
+
 /* out: device [max(n*(n-1), 1), 2] int64, row-major (i, j), i != j; [[0,0]] when n <= 1. */
 int veto_enumerate_pairs(void* stream, int32_t n, int64_t* out);
 

@@ -470,6 +470,30 @@ def test_parity_under_sharp_attention(precision):
     assert err <= 3e-4, err
 
 
+def _trained_like_state_dict(layers, hidden_factor=300.0):
+    """The synthetic weights re-parameterised the way training leaves a transformer (same function): LayerNorm gains x 8 with shifted
+    biases, 3 % of the hidden units x 30 and six x `hidden_factor`, one outlier entry per Linear weight."""
+    from veto_amd import synth
+    sd = {k: np.array(v).copy() for k, v in synth.predictor_state_dict(0, layers=layers).items()}
+    rng = np.random.RandomState(3)
+    T = "fusion_transformer.transformer.layers.%d."
+    for l in range(layers):
+        for norm, lin in (("0.norm", "0.fn.to_qkv"), ("1.norm", "1.fn.net.0")):
+            sd[(T % l) + norm + ".weight"] *= 8.0
+            sd[(T % l) + norm + ".bias"] += 3.0 * rng.randn(576).astype(np.float32)
+            sd[(T % l) + lin + ".weight"] /= 8.0
+        w1, b1, w2 = (T % l) + "1.fn.net.0.weight", (T % l) + "1.fn.net.0.bias", (T % l) + "1.fn.net.3.weight"
+        units = rng.permutation(1152)
+        for sel, f in ((units[:35], 30.0), (units[35:41], hidden_factor)):
+            sd[w1][sel] *= f
+            sd[b1][sel] *= f
+            sd[w2][:, sel] /= f
+        for name in ("0.fn.to_qkv", "0.fn.to_out.0", "1.fn.net.0", "1.fn.net.3"):
+            w = sd[(T % l) + name + ".weight"]
+            w[rng.randint(w.shape[0]), rng.randint(w.shape[1])] = 20.0 * np.abs(w).max()
+    return sd
+
+
 @pytest.mark.parametrize("precision", ["mixed", "precise"])
 def test_parity_on_trained_like_activations(precision):
     """Random-init weights keep every activation small (max |LayerNorm out| 5.6, max |GELU hidden| 2.6 on the fixtures); trained
@@ -482,23 +506,7 @@ def test_parity_on_trained_like_activations(precision):
     from veto_amd import synth, testing
     dev = _dev()
     layers, heads = 4, 8
-    sd = {k: np.array(v).copy() for k, v in synth.predictor_state_dict(0, layers=layers).items()}
-    rng = np.random.RandomState(3)
-    T = "fusion_transformer.transformer.layers.%d."
-    for l in range(layers):
-        for norm, lin in (("0.norm", "0.fn.to_qkv"), ("1.norm", "1.fn.net.0")):
-            sd[(T % l) + norm + ".weight"] *= 8.0
-            sd[(T % l) + norm + ".bias"] += 3.0 * rng.randn(576).astype(np.float32)
-            sd[(T % l) + lin + ".weight"] /= 8.0
-        w1, b1, w2 = (T % l) + "1.fn.net.0.weight", (T % l) + "1.fn.net.0.bias", (T % l) + "1.fn.net.3.weight"
-        units = rng.permutation(1152)
-        for sel, f in ((units[:35], 30.0), (units[35:41], 300.0)):
-            sd[w1][sel] *= f
-            sd[b1][sel] *= f
-            sd[w2][:, sel] /= f
-        for name in ("0.fn.to_qkv", "0.fn.to_out.0", "1.fn.net.0", "1.fn.net.3"):
-            w = sd[(T % l) + name + ".weight"]
-            w[rng.randint(w.shape[0]), rng.randint(w.shape[1])] = 20.0 * np.abs(w).max()
+    sd = _trained_like_state_dict(layers)
     batch = synth.synthetic_batch(11, 2, [12, 9])
     model = testing.make_predictor(testing.make_config(layers, heads, precision=precision), sd, dev)
     out, _ = _run(model, batch, "predcls", dev)
@@ -508,6 +516,49 @@ def test_parity_on_trained_like_activations(precision):
     err = (got - ref).abs().max().item()
     print("trained-like activations [%s]: logit max-abs-err %.3e (max |logit| %.2f)" % (precision, err, ref.abs().max().item()))
     assert err <= 3e-4, err
+
+
+def test_saturation_audit_counts_what_the_mixed_format_clamps():
+    """veto_forward_saturation (VETO_AMD.COUNT_SATURATION) makes the silent part of the mixed operand format visible: elements beyond
+    |a| = 448 lose their e4m3 correction terms, beyond 65504 their fp16 value clamps.  On the fixtures nothing is clamped; with the
+    trained-like weights a few of the hidden units scaled x 300 are (value plane), and the logits of the audit forward
+    (launch-per-stage form) agree with the default forward.  Hidden units scaled x 60000 overflow fp16 itself."""
+    from veto_amd import synth, testing
+    dev = _dev()
+    layers, heads = 4, 8
+    batch = synth.synthetic_batch(11, 2, [12, 9])
+    cfg = testing.make_config(layers, heads)
+    cfg.VETO_AMD.COUNT_SATURATION = True
+
+    g, sd0, gbatch = load_golden("predcls_n10_l4h8")
+    model = testing.make_predictor(cfg, sd0, dev)
+    out, _ = _run(model, gbatch, "predcls", dev)
+    assert np.abs(torch.cat(list(out[1])).cpu().numpy() - g["rel_dists"]).max() <= LOGIT_TOL
+    rep = model.last_saturation
+    assert len(rep) == layers and all(set(r) == {"qkv_in", "attn_out", "ffn_in", "hidden"} for r in rep)
+    n_rows = 90 * 19
+    for l in range(layers - 1):
+        assert rep[l]["attn_out"]["elements"] == n_rows * 576 and rep[l]["hidden"]["elements"] == n_rows * 1152, rep[l]
+        assert rep[l]["qkv_in"]["elements"] == (90 * 2 * 576 if l == 0 else n_rows * 576), rep[l]
+    assert all(v["elements"] == 0 for v in rep[layers - 1].values())          # the last layer runs on split-bf16 operands
+    assert all(v["f16_saturated"] == 0 and v["value_saturated"] == 0 and v["resid_saturated"] == 0 for r in rep for v in r.values()), rep
+
+    sd = _trained_like_state_dict(layers)
+    plain = testing.make_predictor(testing.make_config(layers, heads), sd, dev)
+    ref, _ = _run(plain, batch, "predcls", dev)
+    model = testing.make_predictor(cfg, sd, dev)
+    out, _ = _run(model, batch, "predcls", dev)
+    assert (torch.cat(list(out[1])) - torch.cat(list(ref[1]))).abs().max().item() <= 1e-4
+    rep = model.last_saturation
+    print("saturation audit, trained-like weights:", [{k: (v["value_saturated"], v["resid_saturated"]) for k, v in r.items()} for r in rep])
+    hid = [rep[l]["hidden"] for l in range(layers - 1)]
+    # (the residual plane clamps only where the fp16 rounding error itself exceeds 448 / 2^11 = 0.22, i.e. for some |a| >= 512)
+    assert sum(h["value_saturated"] for h in hid) > 0, rep
+    assert all(h["f16_saturated"] == 0 and h["value_saturated"] < 0.01 * h["elements"] for h in hid), rep
+
+    model = testing.make_predictor(cfg, _trained_like_state_dict(layers, hidden_factor=60000.0), dev)
+    _run(model, batch, "predcls", dev)
+    assert sum(r["hidden"]["f16_saturated"] for r in model.last_saturation) > 0, model.last_saturation
 
 
 def test_fast_mode_error_is_reported_not_trusted():

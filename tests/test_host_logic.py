@@ -201,3 +201,20 @@ def test_relation_head_forward_has_the_reference_signature():
     head.train()
     with pytest.raises(ValueError, match="sampler"):            # pair sampling belongs to the host code base
         head([torch.zeros(1, 256, 8, 8)], [], torch.zeros(1, 256, 2, 2), targets=[object()])
+
+
+def test_relation_head_builds_the_host_sampler_like_the_reference(monkeypatch):
+    """ROIRelationHead.__init__ builds its sampler from cfg (relation_head.py:66-67); VETORelationHead(cfg, in_channels) does the same
+    when the host code base is importable, keeps an explicit one, and stays None (raising only on a training forward) otherwise."""
+    import sys
+    import types
+    from veto_amd import relation_head, testing
+    cfg = testing.make_config(1, 8)
+    assert relation_head._host_samp_processor(cfg) is None            # no pysgg in this process
+    seen = []
+    mod = types.ModuleType("pysgg.modeling.roi_heads.relation_head.sampling")
+    mod.make_roi_relation_samp_processor = lambda c: seen.append(c) or "host-sampler"
+    for name in ("pysgg", "pysgg.modeling", "pysgg.modeling.roi_heads", "pysgg.modeling.roi_heads.relation_head"):
+        monkeypatch.setitem(sys.modules, name, types.ModuleType(name))
+    monkeypatch.setitem(sys.modules, mod.__name__, mod)
+    assert relation_head._host_samp_processor(cfg) == "host-sampler" and seen == [cfg]

@@ -75,5 +75,8 @@ def default_config():
     # time of "precise" at 5-9e-5 logit error) | "precise" (3-term split bf16, 2-3e-5) | "fast" (single bf16 pass, ~1e-2: reported only)
     c.VETO_AMD.PRECISION = "mixed"
     c.VETO_AMD.MAX_CHUNK_PAIRS = 0
+    # True: eval forwards count, per layer and operand, the mixed-row elements that hit the e4m3 (448) / fp16 (65504) clamps of
+    # the "mixed" mode and leave them in predictor.last_saturation (diagnostic: slower, synchronises the stream)
+    c.VETO_AMD.COUNT_SATURATION = False
     c.VETO_AMD.TRAIN_FORWARD_ONLY = False         # True: .train() runs the forward + losses (no backward exists yet)
     return c

@@ -117,9 +117,9 @@ __device__ __forceinline__ bf16x8 lds_tr_frag(const char* p, int pitch4) {
 
 template <int NTERMS, int EPI_T, bool TN = false>
 __global__ __launch_bounds__(64 * (NCONS + NLOAD), 3) void gemm_split_ps_kernel(GemmArgs g) {
-  saturating_conversions_on();
   constexpr bool kDrop = EPI_T == EPI_RESID_DROP;          // training-only instantiation: dropout before the residual add
   constexpr bool kMixed = NTERMS == 2;                     // fp16 + e4m3 operands (mixed rows)
+  if constexpr (kMixed) saturating_conversions_on();       // (only these instantiations can write mixed rows: the fc1 epilogue)
   static_assert(!(kMixed && TN), "the mixed-row format has no transposed (weight-gradient) form");
   constexpr int EPI = kDrop ? (int)EPI_RESID : EPI_T;
   __shared__ __attribute__((aligned(16))) char smem[kLdsBytes];

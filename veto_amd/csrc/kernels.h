@@ -177,6 +177,8 @@ hipError_t launch_dropout_apply(const float* x, float* y, size_t rows, int n_col
 
 // LayerNorm(eps 1e-5) of `rows` rows (row r at x + r*ldx) -> split rows [rows, 2*576]
 // dst row r at dst + r*ldd (bf16 elements; 0 = contiguous rows of 2*576)
+// counters[4] += {elements, fp16 values at +-65504, e4m3 value-plane bytes at +-448, e4m3 residual-plane bytes at +-448} of mixed rows
+hipError_t launch_count_saturation(const void* base, long stride_bytes, int rows, int K, unsigned long long* counters, hipStream_t s);
 hipError_t launch_layernorm(const float* x, long ldx, const float* w, const float* b, __bf16* dst, int rows,
                             hipStream_t s, int fmt = FMT_SPLIT, long ldd = 0);
 

@@ -793,6 +793,47 @@ hipError_t launch_qkv0_combine(const float* sw, const float* ow, const float* st
   return hipGetLastError();
 }
 
+// Saturation audit of mixed rows (VETO_MIXED activations, common.h; veto_forward_saturation): counts, over `rows` rows of K elements
+// (row r at base + r * stride bytes), the fp16 values at +-65504 and the e4m3 bytes at +-448 of the value plane (Y) and of the
+// residual plane (X).  A thread takes 16 bytes at a time; counters = {elements, fp16, value plane, residual plane}.
+__global__ __launch_bounds__(256) void count_saturation_kernel(const char* base, long stride, int rows, int K, unsigned long long* counters) {
+  const int per_row = K / 4;                      // 16-byte pieces of a row (4 K bytes)
+  const long total = (long)rows * per_row;
+  unsigned nf = 0, nv = 0, nr = 0;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int r = (int)(i / per_row), c = (int)(i % per_row);
+    const u32x4 v = *(const u32x4*)(base + (size_t)r * stride + (size_t)c * 16);
+    if ((c & 15) < 8) {                           // the fp16 half of a 256-byte block
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        nf += (v[e] & 0x7fffu) == 0x7bffu;
+        nf += ((v[e] >> 16) & 0x7fffu) == 0x7bffu;
+      }
+    } else {                                      // groups of 8 bytes: 4 x X (residual), 4 x Y (value)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          const unsigned hit = ((v[e] >> (8 * b)) & 0x7fu) == 0x7eu;
+          if (e & 1) nv += hit; else nr += hit;
+        }
+    }
+  }
+  unsigned long long f = nf, vv = nv, rr = nr;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    f += __shfl_xor(f, o, 64);
+    vv += __shfl_xor(vv, o, 64);
+    rr += __shfl_xor(rr, o, 64);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    if (f) atomicAdd(counters + 1, f);
+    if (vv) atomicAdd(counters + 2, vv);
+    if (rr) atomicAdd(counters + 3, rr);
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(counters, (unsigned long long)rows * K);
+  }
+}
+
 hipError_t launch_centre_split(const float* patch_tab, __bf16* dst, int rows, hipStream_t s) {
   VETO_LAUNCH(centre_split_kernel, dim3((unsigned)((2L * rows + 15) / 16)), dim3(256), 0, s, patch_tab, dst, rows);
   return hipGetLastError();
@@ -829,6 +870,14 @@ hipError_t launch_mixed_weight_rows(const float* src, __bf16* dst, size_t rows, 
   VETO_LAUNCH(absmax_bits_kernel, dim3(blocks), dim3(256), 0, s, src, n, (unsigned*)exp_out);
   VETO_LAUNCH(mixed_weight_rows_kernel, dim3(blocks), dim3(256), 0, s, src, dst, n, K, exp_out);
   VETO_LAUNCH(finish_weight_exp_kernel, dim3(1), dim3(1), 0, s, exp_out);
+  return hipGetLastError();
+}
+
+hipError_t launch_count_saturation(const void* base, long stride_bytes, int rows, int K, unsigned long long* counters, hipStream_t s) {
+  if (rows <= 0 || K % 64 != 0 || !counters) return hipErrorInvalidValue;
+  const long pieces = (long)rows * (K / 4);
+  const int blocks = (int)((pieces + 255) / 256 < 4096 ? (pieces + 255) / 256 : 4096);
+  VETO_LAUNCH(count_saturation_kernel, dim3(blocks), dim3(256), 0, s, (const char*)base, stride_bytes, rows, K, counters);
   return hipGetLastError();
 }
 

@@ -114,6 +114,10 @@ struct veto_handle_s {
   float* loc_wt = nullptr;
   float* cls_wt = nullptr;
   float* head_wt = nullptr;
+  // veto_forward_saturation: device counters [layers][VETO_SAT_SITES][4]; `sat` is non-null only inside that call and makes
+  // veto_forward take the launch-per-stage form of the mixed path (every mixed-row operand exists in memory) and count behind every producer
+  unsigned long long* sat_buf = nullptr;
+  unsigned long long* sat = nullptr;
   // profiling
   bool prof_on = false;
   std::vector<std::string> prof_names;
@@ -458,6 +462,7 @@ int veto_destroy(veto_handle_t h) {
   for (hipEvent_t e : h->event_pool) (void)hipEventDestroy(e);
   (void)hipFree(h->raw);
   (void)hipFree(h->derived);
+  if (h->sat_buf) (void)hipFree(h->sat_buf);
   delete h;
   return VETO_OK;
 }
@@ -564,7 +569,12 @@ int veto_forward(veto_handle_t h, void* stream, const veto_inputs_t* in, void* w
   // the parity tests compare against) splits it into the out projection + LayerNorm2 launch and the FeedForward + LayerNorm1 launch
   // of the same kernel.  VETO_PRECISE / VETO_FAST take the launch-per-Linear GEMMs and LayerNorm launches.
   static const bool tail_off = env_knob_is("VETO_TAIL_FUSED", "0");
-  const bool tail_fused = !tail_off;
+  const bool tail_fused = !tail_off && !h->sat;
+  const bool panel = !h->sat;        // (the saturation audit needs the LayerNorm2 rows and the hidden activation in memory)
+  auto count_sat = [&](int layer, int site, const void* rows, long stride_bytes, int n_rows, int K) -> hipError_t {
+    if (!h->sat) return hipSuccess;
+    return launch_count_saturation(rows, stride_bytes, n_rows, K, h->sat + ((size_t)layer * VETO_SAT_SITES + site) * 4, s);
+  };
   static const bool qkv_f24_off = env_knob_is("VETO_QKV_F24", "0");
   if (qkv0_tables) {
     const int R = n_obj * 16;
@@ -651,6 +661,7 @@ int veto_forward(veto_handle_t h, void* stream, const veto_inputs_t* in, void* w
           HIP_TRY(launch_qkv0_combine(ws.sw, ws.ow, ws.stats, h->q0_vec, ws.subj + c0, ws.obj + c0, qkv, np, s));
         }
         for (int t = kTokens - 2; t < kTokens; ++t) {   // the ReLU'd location / class rows: LayerNorm'ed rows x Wqkv as usual (VETO_MIXED: mixed operands)
+          if (mixed) HIP_TRY(count_sat(l, VETO_SAT_QKV_IN, ws.a + (size_t)t * 2 * kDim, (long)kTokens * kDim * 4, np, kDim));
           rc = run_gemm(h, s, "gemm_qkv0_lc", ws.a + (size_t)t * 2 * kDim, mixed ? w.qkv_m : w.qkv, nullptr, nullptr, 0,
                         qkv + (size_t)t * 3 * kDim, nullptr, (long)kTokens * 3 * kDim, np, 3 * kDim, kDim, EPI_F32, (long)kTokens * 2 * kDim, 0,
                         DropSite(), mixed ? w.exp_m + 0 : nullptr);
@@ -660,6 +671,7 @@ int veto_forward(veto_handle_t h, void* stream, const veto_inputs_t* in, void* w
         const bool mq = mixed && l > 0;   // layer 0's LayerNorm'ed rows come from token assembly (split rows)
         // q / k / v as 3-byte floats between this GEMM and the attention kernel (common.h; VETO_QKV_F24=0: fp32)
         qkv_f24 = mq && !qkv_f24_off && attention_reads_tables(H);
+        if (mq) HIP_TRY(count_sat(l, VETO_SAT_QKV_IN, ws.a, (long)kDim * 4, M, kDim));
         rc = run_gemm(h, s, "gemm_qkv", ws.a, mq ? w.qkv_m : w.qkv, nullptr, nullptr, 0, qkv, nullptr, 3 * kDim, M, 3 * kDim, kDim,
                       qkv_f24 ? EPI_F24 : EPI_F32, 0, 0, DropSite(), mq ? w.exp_m + 0 : nullptr);
         if (rc) return rc;
@@ -685,10 +697,11 @@ int veto_forward(veto_handle_t h, void* stream, const veto_inputs_t* in, void* w
         ProfScope ps(h, s, last ? "attention_cls" : "attention", 4.0 * np * nq * kTokens * kDim,
                      (double)M * 3 * kDim * (qkv_f24 ? 3 : 4) + (double)np * nq * kDim * 4);
         HIP_TRY(launch_attention(a, s));
+        if (a.o_fmt == FMT_MIXED) HIP_TRY(count_sat(l, VETO_SAT_ATTN_OUT, ws.a, (long)kDim * 4, M, kDim));
       }
       if (!last) {
         // ... and the LayerNorm in front of the next layer's QKV GEMM in the FeedForward epilogue, when that GEMM takes mixed rows
-        const bool ffn_ln_next = mixed && l + 1 < L - 1;
+        const bool ffn_ln_next = mixed && panel && l + 1 < L - 1;
         if (mixed_out && tail_fused) {
           // everything of the layer behind its attention in ONE launch (ffn_fused.hip, MODE 2): x1 = x + a Wo^T + bo stays in
           // registers, LayerNorm2(x1) is written in place over the attention output and streamed back as the FeedForward's
@@ -702,7 +715,7 @@ int veto_forward(veto_handle_t h, void* stream, const veto_inputs_t* in, void* w
                        (double)M * kDim * 16 + 5.0 * kDim * kDim * 4);
           HIP_TRY(launch_layer_tail(f, s));
         } else {
-        if (mixed_out) {
+        if (mixed_out && panel) {
           // out projection + residual + LayerNorm2 in one launch on full rows (ffn_fused.hip, MODE 1): x <- x + a Wo^T + bo, then
           // a <- LayerNorm2(x) as mixed rows in place over the attention output
           FfnArgs f{};
@@ -718,8 +731,9 @@ int veto_forward(veto_handle_t h, void* stream, const veto_inputs_t* in, void* w
             ProfScope ps(h, s, "layernorm", 0, (double)M * kDim * 8);
             HIP_TRY(launch_layernorm(ws.x, kDim, w.ln2_w, w.ln2_b, ws.a, M, s, mixed ? FMT_MIXED : FMT_SPLIT));
           }
+          if (mixed) HIP_TRY(count_sat(l, VETO_SAT_FFN_IN, ws.a, (long)kDim * 4, M, kDim));
         }
-        if (mixed) {
+        if (mixed && panel) {
           // FeedForward in one launch (ffn_fused.hip): the hidden activation never leaves the CU
           FfnArgs f{};
           f.a = (const char*)ws.a; f.w1 = (const char*)w.fc1_m; f.w2 = (const char*)w.fc2_m; f.b1 = w.fc1_b; f.b2 = w.fc2_b;
@@ -734,6 +748,7 @@ int veto_forward(veto_handle_t h, void* stream, const veto_inputs_t* in, void* w
           rc = run_gemm(h, s, "gemm_fc1", ws.a, mixed ? w.fc1_m : w.fc1, w.fc1_b, nullptr, 0, nullptr, hid, 4 * kDim, M, 2 * kDim, kDim,
                         EPI_GELU_SPLIT, 0, 0, DropSite(), mixed ? w.exp_m + 2 : nullptr);
           if (rc) return rc;
+          if (mixed) HIP_TRY(count_sat(l, VETO_SAT_HIDDEN, hid, (long)2 * kDim * 4, M, 2 * kDim));
           rc = run_gemm(h, s, "gemm_fc2", hid, mixed ? w.fc2_m : w.fc2, w.fc2_b, ws.x, kDim, ws.x, nullptr, kDim, M, kDim, 2 * kDim, EPI_RESID,
                         0, 0, DropSite(), mixed ? w.exp_m + 3 : nullptr);
           if (rc) return rc;
@@ -777,6 +792,32 @@ int veto_forward(veto_handle_t h, void* stream, const veto_inputs_t* in, void* w
     }
     if (dbg && dbg->cls)
       HIP_TRY(hipMemcpyAsync(dbg->cls + (size_t)c0 * kDim, ws.xc, (size_t)np * kDim * 4, hipMemcpyDeviceToDevice, s));
+  }
+  return VETO_OK;
+}
+
+int veto_forward_saturation(veto_handle_t h, void* stream, const veto_inputs_t* in, void* workspace, size_t workspace_bytes,
+                            float* out_logits, veto_saturation_t* counts, int32_t capacity) {
+  if (!h || !counts) return fail(VETO_ERR_INVALID, "null argument");
+  if (h->cfg.precision != VETO_MIXED) return fail(VETO_ERR_INVALID, "veto_forward_saturation audits the VETO_MIXED operands; this handle computes in another mode");
+  const int n = h->cfg.layers * VETO_SAT_SITES;
+  if (capacity < n) return fail(VETO_ERR_INVALID, "counts holds %d entries, need layers * VETO_SAT_SITES = %d", capacity, n);
+  hipStream_t s = (hipStream_t)stream;
+  HIP_TRY(hipSetDevice(h->cfg.device));
+  if (!h->sat_buf) HIP_TRY(hipMalloc((void**)&h->sat_buf, (size_t)n * 4 * sizeof(unsigned long long)));
+  HIP_TRY(hipMemsetAsync(h->sat_buf, 0, (size_t)n * 4 * sizeof(unsigned long long), s));
+  h->sat = h->sat_buf;
+  const int rc = veto_forward(h, stream, in, workspace, workspace_bytes, out_logits, nullptr);
+  h->sat = nullptr;
+  if (rc != VETO_OK) return rc;
+  std::vector<unsigned long long> host((size_t)n * 4);
+  HIP_TRY(hipMemcpyAsync(host.data(), h->sat_buf, host.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  for (int i = 0; i < n; ++i) {
+    counts[i].elements = (int64_t)host[i * 4 + 0];
+    counts[i].f16_saturated = (int64_t)host[i * 4 + 1];
+    counts[i].value_saturated = (int64_t)host[i * 4 + 2];
+    counts[i].resid_saturated = (int64_t)host[i * 4 + 3];
   }
   return VETO_OK;
 }

@@ -16,7 +16,7 @@ _LIB = None
 
 EXPORTS = [
     "veto_last_error", "veto_version", "veto_create", "veto_destroy", "veto_num_weights",
-    "veto_weight_info", "veto_load_weights", "veto_workspace_bytes", "veto_forward",
+    "veto_weight_info", "veto_load_weights", "veto_workspace_bytes", "veto_forward", "veto_forward_saturation",
     "veto_enumerate_pairs", "veto_profile_enable", "veto_profile_collect", "veto_profile_entry",
     "veto_profile_reset", "veto_debug_gemm", "veto_debug_gemm_workspace_bytes", "veto_debug_gemm_forms", "veto_debug_ffn", "veto_debug_ffn_workspace_bytes", "veto_debug_outproj", "veto_debug_outproj_workspace_bytes", "veto_debug_layer_tail", "veto_debug_layer_tail_workspace_bytes",
     "veto_postprocess", "veto_postprocess_workspace_bytes", "veto_postprocess_meet", "veto_postprocess_vote",
@@ -51,6 +51,13 @@ class VetoDebugOutputs(Structure):
         ("struct_size", c_int32), ("reserved0", c_int32),
         ("subj_inds", c_void_p), ("obj_inds", c_void_p), ("tokens", c_void_p), ("cls", c_void_p),
     ]
+
+
+class VetoSaturation(Structure):
+    _fields_ = [(n, c_int64) for n in ("elements", "f16_saturated", "value_saturated", "resid_saturated")]
+
+
+SATURATION_SITES = ("qkv_in", "attn_out", "ffn_in", "hidden")       # enum veto_saturation_site
 
 
 class VetoPostArgs(Structure):
@@ -130,6 +137,8 @@ def load_library():
     lib.veto_workspace_bytes.restype = c_size_t
     lib.veto_forward.argtypes = [c_void_p, c_void_p, POINTER(VetoInputs), c_void_p, c_size_t, c_void_p,
                                  POINTER(VetoDebugOutputs)]
+    lib.veto_forward_saturation.argtypes = [c_void_p, c_void_p, POINTER(VetoInputs), c_void_p, c_size_t, c_void_p,
+                                            POINTER(VetoSaturation), c_int32]
     lib.veto_enumerate_pairs.argtypes = [c_void_p, c_int32, c_void_p]
     lib.veto_profile_enable.argtypes = [c_void_p, c_int32]
     lib.veto_profile_collect.argtypes = [c_void_p]
@@ -238,6 +247,20 @@ class Engine:
     def forward(self, stream, inputs, workspace_ptr, workspace_bytes, out_ptr, dbg=None):
         check(self.lib.veto_forward(self.handle, c_void_p(stream), byref(inputs), c_void_p(workspace_ptr),
                                     workspace_bytes, c_void_p(out_ptr), byref(dbg) if dbg is not None else None))
+
+    def forward_saturation(self, stream, inputs, workspace_ptr, workspace_bytes, out_ptr):
+        """veto_forward_saturation: the forward in its launch-per-stage form plus, per layer and operand site, the count of mixed-row
+        elements that sit at the clamp values.  Returns [{site: dict(elements, f16_saturated, value_saturated, resid_saturated)}]
+        with one entry per layer (synchronises the stream)."""
+        n = self.cfg.layers * len(SATURATION_SITES)
+        counts = (VetoSaturation * n)()
+        check(self.lib.veto_forward_saturation(self.handle, c_void_p(stream), byref(inputs), c_void_p(workspace_ptr), workspace_bytes,
+                                               c_void_p(out_ptr), counts, n))
+        out = []
+        for layer in range(self.cfg.layers):
+            out.append({site: {f: int(getattr(counts[layer * len(SATURATION_SITES) + i], f)) for f, _ in VetoSaturation._fields_}
+                        for i, site in enumerate(SATURATION_SITES)})
+        return out
 
     def weight_offsets(self):
         """{weight name: (offset, numel)} in floats into the flat gradient buffer of veto_backward."""

@@ -193,6 +193,10 @@ class _NativeForward:
         self._num_out = sum(h.out_features for h in head_modules)
         self._precision = _precision(config)
         self._max_chunk = _max_chunk(config)
+        # VETO_AMD.COUNT_SATURATION: eval forwards go through veto_forward_saturation (slower: launch per stage, one stream
+        # synchronisation) and leave the per-layer counts of clamped mixed-row elements in `self.last_saturation`
+        self._count_saturation = bool(getattr(getattr(config, "VETO_AMD", None), "COUNT_SATURATION", False))
+        self.last_saturation = None
         object.__setattr__(self, "_trunk", trunk)  # not a sub-module registration
         self._engine = None
         self._engine_device = None
@@ -349,7 +353,10 @@ class _NativeForward:
             dbg.subj_inds, dbg.obj_inds = extras["subj_inds"].data_ptr(), extras["obj_inds"].data_ptr()
             dbg.tokens, dbg.cls = extras["tokens"].data_ptr(), extras["cls"].data_ptr()
         stream = torch.cuda.current_stream(device).cuda_stream
-        eng.forward(stream, inp, self._workspace.data_ptr(), self._workspace.numel(), out.data_ptr(), dbg)
+        if self._count_saturation and bn_batch_stats is None and not debug:
+            self.last_saturation = eng.forward_saturation(stream, inp, self._workspace.data_ptr(), self._workspace.numel(), out.data_ptr())
+        else:
+            eng.forward(stream, inp, self._workspace.data_ptr(), self._workspace.numel(), out.data_ptr(), dbg)
         # the inputs above are referenced by enqueued kernels: keep them alive on this stream
         for t in keep:
             t.record_stream(torch.cuda.current_stream(device))

@@ -28,10 +28,21 @@ def to_onehot(vec, num_classes, fill=1000.0):
     return out
 
 
+def _host_samp_processor(cfg):
+    """The host code base's own relation sampler, built the way the reference's head builds it (relation_head.py:66-67:
+    `self.samp_processor = make_roi_relation_samp_processor(cfg)`), or None when this process has no pysgg to import."""
+    try:
+        from pysgg.modeling.roi_heads.relation_head.sampling import make_roi_relation_samp_processor
+    except Exception:     # not installed / its own imports fail outside the host code base
+        return None
+    return make_roi_relation_samp_processor(cfg)
+
+
 class VETORelationHead(nn.Module):
     def __init__(self, cfg, in_channels=512, samp_processor=None):
-        """samp_processor: the relation sampler of the host code base (the reference's make_roi_relation_samp_processor(cfg),
-        relation_head.py:66); only the training branch uses it (gtbox_relsample).  Pair sampling is outside this package."""
+        """samp_processor: the relation sampler; only the training branch uses it (gtbox_relsample).  Default (None): the host code
+        base's own, built from cfg exactly as the reference does (relation_head.py:66-67), so `VETORelationHead(cfg, in_channels)`
+        trains inside pysgg like the head it replaces; outside pysgg pass one explicitly (pair sampling is not part of this package)."""
         super().__init__()
         self.cfg = cfg
         rh = cfg.MODEL.ROI_RELATION_HEAD
@@ -43,7 +54,7 @@ class VETORelationHead(nn.Module):
         self.box_feature_extractor = make_roi_box_feature_extractor(cfg, in_channels, for_relation=True)  # :53
         self.predictor = registry.make_roi_relation_predictor(cfg, in_channels)
         self.post_processor = make_roi_relation_post_processor(cfg)
-        self.samp_processor = samp_processor
+        self.samp_processor = samp_processor if samp_processor is not None else _host_samp_processor(cfg)
         self.num_obj_cls = self.predictor.num_obj_cls
         self.max_proposal_pairs = int(getattr(rh, "MAX_PROPOSAL_PAIR", 2048))
 
@@ -60,7 +71,8 @@ class VETORelationHead(nn.Module):
             if targets is None:
                 raise ValueError("training needs the targets (GT BoxLists with a 'relation' matrix)")
             if self.samp_processor is None:
-                raise ValueError("training needs the host code base's relation sampler: VETORelationHead(cfg, samp_processor=...)")
+                raise ValueError("training needs a relation sampler: pysgg's make_roi_relation_samp_processor(cfg) could not be "
+                                 "imported in this process; pass VETORelationHead(cfg, in_channels, samp_processor=...)")
             self._overload_predcls_fields(proposals, features[0].device)
             with torch.no_grad():
                 proposals, rel_labels, rel_pair_idxs, _ = self.samp_processor.gtbox_relsample(proposals, targets)
