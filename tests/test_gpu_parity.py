@@ -312,6 +312,20 @@ def test_gemm_block_diagonal_and_output_forms(m, n, k, kb_tiles, kb_steps):
     rel = ((dec24.double() - c.double()).abs() / c.abs().double().clamp_min(1e-20)).max().item()
     assert rel <= 2.0 ** -16, rel                                        # round to nearest at 16 significand bits
     assert ((dec24.view(torch.int32) & 0xFF) == 0).all()
+    if kb_tiles == 0:
+        # non-finite results keep their class in the 3-byte form: Inf stays Inf of its sign, a NaN stays a NaN (the rounding increment
+        # must not carry a NaN's mantissa into the exponent: it would be stored as +-0)
+        a2 = a.clone()
+        a2[0, 0], a2[1, 0], a2[2, 0] = float("inf"), float("-inf"), float("nan")
+        w2 = w.clone()
+        w2[:, 0] = w2[:, 0].abs() + 0.01
+        native.check(lib.veto_debug_gemm_forms(None, a2.data_ptr(), w2.data_ptr(), f24.data_ptr(), m, n, k, 0, 0, 2, ws.data_ptr(), ws.numel()))
+        torch.cuda.synchronize()
+        b = f24.view(m, n, 3).to(torch.int32)
+        d = ((b[:, :, 0] << 8) | (b[:, :, 1] << 16) | (b[:, :, 2] << 24)).view(torch.float32)
+        assert torch.isnan(d[2]).all() and torch.isfinite(d[3:]).all()
+        # (an Inf operand goes through the split-bf16 terms as Inf - Inf in the low plane: NaN or Inf, never a finite value)
+        assert (~torch.isfinite(d[0])).all() and (~torch.isfinite(d[1])).all()
 
 
 def test_fused_layer_tail_full_size_hand_off():
