@@ -565,6 +565,12 @@ int veto_forward(veto_handle_t h, void* stream, const veto_inputs_t* in, void* w
   // CLS-row GEMMs (8 % of the GEMM work) stay on split-bf16 operands.  The out projection only behind the MFMA attention kernel.
   const bool mixed = h->cfg.precision == VETO_MIXED;
   const bool mixed_out = mixed && attention_reads_tables(H);
+#ifndef VETO_CLS_FFN_MIXED
+#define VETO_CLS_FFN_MIXED 0
+#endif
+  // the CLS rows' FeedForward of the last layer stays on split-bf16 operands by default: those rows ARE the classifier's input
+  // (-DVETO_CLS_FFN_MIXED=1: 0.03 ms per step faster, logit error measured in profiles/r04_tail_variants_b.txt)
+  const bool cls_mixed = mixed && VETO_CLS_FFN_MIXED;
   // VETO_MIXED runs everything of a layer behind its attention as ONE panel launch (ffn_fused.hip MODE 2); VETO_TAIL_FUSED=0 (a knob
   // the parity tests compare against) splits it into the out projection + LayerNorm2 launch and the FeedForward + LayerNorm1 launch
   // of the same kernel.  VETO_PRECISE / VETO_FAST take the launch-per-Linear GEMMs and LayerNorm launches.
@@ -776,13 +782,13 @@ int veto_forward(veto_handle_t h, void* stream, const veto_inputs_t* in, void* w
         }
         {
           ProfScope ps(h, s, "layernorm_cls", 0, (double)np * kDim * 8);
-          HIP_TRY(launch_layernorm(ws.xc, kDim, w.ln2_w, w.ln2_b, ws.ac, np, s));
+          HIP_TRY(launch_layernorm(ws.xc, kDim, w.ln2_w, w.ln2_b, ws.ac, np, s, cls_mixed ? FMT_MIXED : FMT_SPLIT));
         }
-        rc = run_gemm(h, s, "gemm_fc1_cls", ws.ac, w.fc1, w.fc1_b, nullptr, 0, nullptr, ws.hc, 4 * kDim, np, 2 * kDim, kDim,
-                      EPI_GELU_SPLIT);
+        rc = run_gemm(h, s, "gemm_fc1_cls", ws.ac, cls_mixed ? w.fc1_m : w.fc1, w.fc1_b, nullptr, 0, nullptr, ws.hc, 4 * kDim, np, 2 * kDim, kDim,
+                      EPI_GELU_SPLIT, 0, 0, DropSite(), cls_mixed ? w.exp_m + 2 : nullptr);
         if (rc) return rc;
-        rc = run_gemm(h, s, "gemm_fc2_cls", ws.hc, w.fc2, w.fc2_b, ws.xc, kDim, ws.xc, nullptr, kDim, np, kDim, 2 * kDim,
-                      EPI_RESID);
+        rc = run_gemm(h, s, "gemm_fc2_cls", ws.hc, cls_mixed ? w.fc2_m : w.fc2, w.fc2_b, ws.xc, kDim, ws.xc, nullptr, kDim, np, kDim, 2 * kDim,
+                      EPI_RESID, 0, 0, DropSite(), cls_mixed ? w.exp_m + 3 : nullptr);
         if (rc) return rc;
       }
     }
