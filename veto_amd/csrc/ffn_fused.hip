@@ -45,7 +45,8 @@
 
 // timing ablations (tools/ffn_variants.sh; results are WRONG with any of them set): 1 = no DMA, 2 = no MFMA, 4 = no fragment
 // reads, 8 = no hidden conversion, 16 = no panel epilogue, 32 = the e4m3 stages move 3/5 (activation + weight slice) or 2/3 (weight slice)
-// of their bytes: the DMA volume of 3-byte operand rows (fp16 + ONE e4m3 plane) without their conversion work
+// of their bytes: the DMA volume of 3-byte operand rows (fp16 + ONE e4m3 plane) without their conversion work,
+// 64 = every workgroup streams the SAME FeedForward input panel (L2-resident) instead of its own: what the re-reads of the LayerNorm2 rows cost
 #ifndef FFN_ABLATE
 #define FFN_ABLATE 0
 #endif
@@ -54,6 +55,10 @@
 // negative control of tests/test_ffn_asm.py (the audit must then report hazards)
 #ifndef FFN_MMA_NOP
 #define FFN_MMA_NOP "s_nop 1\n\t"
+#endif
+// 1: odd hidden chunks walk the 64-k blocks of the panel backwards (see issue_fc1; -1.5 % on the layer tail; 0 = every chunk forwards)
+#ifndef FFN_SNAKE
+#define FFN_SNAKE 1
 #endif
 #ifndef FFN_CONV_G0
 #define FFN_CONV_G0 0       // first of the three MFMA groups of a sub-stage that carry a piece of the hidden conversion (0..3)
@@ -189,9 +194,14 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs g) {
   const char* const w_out = MODE == 2 ? g.wo : g.w2;       // weight rows of the out-projection phase (MODE 1: the only GEMM)
   auto panel_base = [&](int it) { return g.a + (size_t)(b + (size_t)it * G) * ((size_t)FR * kRow1); };
   // MODE 2: the FeedForward phase of a panel reads the LayerNorm2 rows its out-projection phase wrote (ln_out; normally = a)
-  auto ffn_base = [&](int it) { return (MODE == 2 ? (const char*)g.ln_out : g.a) + (size_t)(b + (size_t)it * G) * ((size_t)FR * kRow1); };
+  auto ffn_base = [&](int it) { return (MODE == 2 ? (const char*)g.ln_out : g.a) + ((FFN_ABLATE & 64) ? (size_t)0 : (size_t)(b + (size_t)it * G) * ((size_t)FR * kRow1)); };
   // instruction k (of 5) of fc1 stage ks of hidden chunk c: 16 KiB of activation rows (k = 0, 1) + 24 KiB of W1 rows (2..4)
   auto issue_fc1 = [&](const char* a_panel, int c, int ks, int slot, int k) {
+#if FFN_SNAKE
+    // odd chunks walk the 64-k blocks of the panel from the last to the first: the LayerNorm2 rows an XCD's 32 workgroups re-read
+    // per hidden chunk (9.4 MB) do not fit its 4 MB L2, but the blocks a chunk reads last are the ones the next chunk then reads first
+    if (c & 1) ks = 2 * (8 - (ks >> 1)) + (ks & 1);
+#endif
     const unsigned dst = lds0 + slot * kSlot + w * 1024;
     if ((FFN_ABLATE & 32) && (ks & 1) && (k == 1 || k == 4)) return;
     if (k < 2) glds16(a_panel + ks * 128 + k * 64 * kRow1, voff1, dst + k * 8 * 1024);
