@@ -378,6 +378,9 @@ def test_ce_loss_edge_cases_follow_torch():
     bad = labels.clone()
     bad[5] = 11
     assert torch.isnan(ce_loss(logits.to(dev), bad.to(dev), weight=w.to(dev)).detach()).all()
+    # ... and its gradient row too (and, through the NaN weight sum, nothing else can be trusted either): no optimizer step on it
+    loss, grad = relation_ce_loss(logits.to(dev), bad.to(dev), weight=w.to(dev), want_grad=True)
+    assert torch.isnan(loss).all() and torch.isnan(grad[5]).all()
 
 
 @pytest.mark.gpu

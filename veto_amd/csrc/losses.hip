@@ -67,7 +67,9 @@ __global__ __launch_bounds__(256) void ce_grad_kernel(CeLossArgs a) {
   const float* z = a.logits + r * a.ld;
   const long yl = a.labels[i];
   const int y = (yl >= 0 && yl < a.C) ? (int)yl : -1;      // ignored rows have w_row = 0: zero gradient
-  const float scale = a.w_row[i] * a.inv_wsum[0], lse = a.lse[i];
+  // a label >= C made the loss NaN (above); its gradient row is NaN too, so that an optimizer step cannot proceed on a loss that
+  // never was one (torch raises in this case)
+  const float scale = yl >= a.C ? __builtin_nanf("") : a.w_row[i] * a.inv_wsum[0], lse = a.lse[i];
   float* g = a.grad + (size_t)i * a.C;
   for (int c = lane; c < a.C; c += 64) g[c] = (expf(z[c] - lse) - (c == y ? 1.f : 0.f)) * scale;
 }
