@@ -278,6 +278,9 @@ def main():
                          "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic,
                          "note": "achieved = algorithmic 2*M*N*K of one launch / its mean hipEvent duration; this precision mode "
                                  "issues %.4g bf16-equivalent MFMA passes per algorithmic FLOP" % passes},
+            # the four floors of the dominant launch (rates measured on MI355X in round 4): it runs above all of
+            # them because an in-order wave overlaps its matrix, LDS-DMA, L2-miss and HBM streams only partly
+            "floors": layer_tail_floors(n_pairs * 19, prof[dom], traffic, gemms[dom]["avg_ms"]) if dom == "layer_tail_fused" else None,
             # north_star: "HBM GB/s on the gather and MFMA utilisation on the attention GEMMs"
             "gather": {"bound": "hbm", "kernel": "assemble_tokens", "achieved": gather_gbps, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                        "frac": gather_gbps / PEAK_HBM_GBS,
@@ -381,6 +384,21 @@ def usable_cores():
     except (OSError, ValueError):
         pass
     return n
+
+
+def layer_tail_floors(rows, rec, l2_miss_bytes, avg_ms):
+    """Lower bounds (ms) of one layer-tail launch from the rates measured in round 4 (profiles/r04_ldsdma_scale.txt,
+    profiles/r04_tail_variants_b.txt): matrix pipe at the 1.44 PFLOP/s (algorithmic, both precision terms) of the MFMA-only ablation;
+    L2 -> LDS at 91 GB/s per CU x 256 for the 8.7 MB of operand stages a 128-row panel streams; the L2 misses (PMC) at the ~8 TB/s
+    of the path behind the L2; the algorithmic HBM bytes at the ~5 TB/s a chip-wide store burst reaches."""
+    panels = (rows + 127) // 128
+    lds_bytes = panels * (576 * 576 + 2 * 576 * 1152) * 4.0 + panels * 128 * 576 * 4.0 * 7      # weights + activation panel x (1 + 6)
+    out = {"matrix_ms": rec["flops_per_launch"] / 1.44e15 * 1e3, "l2_to_lds_ms": lds_bytes / (256 * 91e9) * 1e3,
+           "l2_miss_ms": (l2_miss_bytes / 8e12 * 1e3) if l2_miss_bytes else None,
+           "hbm_ms": rec["bytes_per_launch"] / 5e12 * 1e3, "measured_ms": avg_ms}
+    tight = max(v for k, v in out.items() if v is not None and k != "measured_ms")
+    out["frac_of_tightest_floor"] = tight / avg_ms
+    return {k: (round(v, 4) if v is not None else None) for k, v in out.items()}
 
 
 def cpu_baseline(sd, args, batch, gpu_logits, pairs):
