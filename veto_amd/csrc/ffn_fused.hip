@@ -46,6 +46,7 @@
 // timing ablations (tools/ffn_variants.sh; results are WRONG with any of them set): 1 = no DMA, 2 = no MFMA, 4 = no fragment
 // reads, 8 = no hidden conversion, 16 = no panel epilogue, 32 = the e4m3 stages move 3/5 (activation + weight slice) or 2/3 (weight slice)
 // of their bytes: the DMA volume of 3-byte operand rows (fp16 + ONE e4m3 plane) without their conversion work,
+// 128 = the activation half of 32 alone (the LayerNorm2 rows of fc1 as fp16 + one e4m3 plane: upper bound of DESIGN.md section 11 item 1a),
 // 64 = every workgroup streams the SAME FeedForward input panel (L2-resident) instead of its own: what the re-reads of the LayerNorm2 rows cost
 #ifndef FFN_ABLATE
 #define FFN_ABLATE 0
@@ -204,6 +205,7 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs g) {
 #endif
     const unsigned dst = lds0 + slot * kSlot + w * 1024;
     if ((FFN_ABLATE & 32) && (ks & 1) && (k == 1 || k == 4)) return;
+    if ((FFN_ABLATE & 128) && (ks & 1) && k == 1) return;   // (the activation half of ablation 32 alone)
     if (k < 2) glds16(a_panel + ks * 128 + k * 64 * kRow1, voff1, dst + k * 8 * 1024);
     else glds16(g.w1 + (size_t)c * ((size_t)FC * kRow1) + ks * 128 + (k - 2) * 64 * kRow1, voff1, dst + kAB + (k - 2) * 8 * 1024);
   };
