@@ -31,3 +31,27 @@ def test_audit_rejects_a_build_without_the_mfma_pads(tmp_path):
     missing = asmcheck.unpadded(bad)
     assert len(missing) > 1000, len(missing)           # every MFMA statement of the three kernels
     assert len(asmcheck.problems(bad)) >= len(missing)   # (what check() -- and with it __graft_entry__.build() -- raises on)
+
+
+def test_auditor_on_hand_written_snippets(tmp_path):
+    """The auditor itself, on small assembly texts: what it must flag and what it must let through."""
+    def write(name, body):
+        p = tmp_path / name
+        p.write_text(body)
+        return str(p)
+
+    mfma = "v_mfma_f32_16x16x32_f16 v[0:3], v[8:11], v[12:15], v[0:3]"
+    ok = write("ok.s", "\n".join([";;#ASMSTART", "s_nop 1", mfma, ";;#ASMEND", "s_nop 15", "s_nop 15", "v_add_f32 v4, v0, v1", "s_endpgm"]))
+    assert asmcheck.hazards(ok) == [] and asmcheck.unpadded(ok) == [] and asmcheck.m0_users(ok) == []
+    # an accumulator read 1 state behind the MFMA that writes it
+    early = write("early.s", "\n".join([";;#ASMSTART", "s_nop 1", mfma, ";;#ASMEND", "v_add_f32 v4, v0, v1", "s_endpgm"]))
+    assert len(asmcheck.hazards(early)) == 1
+    # a vector write of an MFMA operand right in front of an unpadded MFMA
+    fresh = write("fresh.s", "\n".join(["v_mov_b32 v8, v20", ";;#ASMSTART", mfma, ";;#ASMEND", "s_endpgm"]))
+    assert any("vector write of v8" in f for f in asmcheck.hazards(fresh)) and len(asmcheck.unpadded(fresh)) == 1
+    # ... which the pad inside the statement cures
+    padded = write("padded.s", "\n".join(["v_mov_b32 v8, v20", ";;#ASMSTART", "s_nop 1", mfma, ";;#ASMEND", "s_endpgm"]))
+    assert asmcheck.hazards(padded) == [] and asmcheck.unpadded(padded) == []
+    # the accumulate chain (next MFMA takes the result whole as C) needs no wait; compiler code that touches M0 is reported
+    chain = write("chain.s", "\n".join([";;#ASMSTART", "s_nop 1", mfma, ";;#ASMEND", ";;#ASMSTART", "s_nop 1", mfma, ";;#ASMEND", "s_mov_b32 m0, s4", "s_endpgm"]))
+    assert asmcheck.hazards(chain) == [] and asmcheck.m0_users(chain) == ["s_mov_b32 m0, s4"]
