@@ -104,8 +104,9 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 // from the two per-object table rows (L2 / Infinity Cache), the row's rstd and c2 (AttnArgs::sw ...).  (Giving each XCD a
 // contiguous eighth of the items, so that an image's table rows meet in one L2, measured neutral.)
 // F24: q / k / v arrive as 3-byte floats (common.h): a chunk of 8 values is 24 bytes, and hi + lo of such a value is exact.
+template <int V> struct IntTag { static constexpr int value = V; };
 template <int DH, bool TAB = false, bool F24 = false>
-__global__ __launch_bounds__(128, 2) void attention_mfma_kernel(AttnArgs a) {
+__global__ __launch_bounds__(128, TAB ? 2 : 3) void attention_mfma_kernel(AttnArgs a) {
   static_assert(!(TAB && F24), "the per-object form reads fp32 tables");
   saturating_conversions_on();   // (the mixed-row output path converts without clamps, common.h)
   constexpr int DHP = (DH + 15) / 16 * 16;  // contraction extent of QK^T (zero padded)
@@ -113,12 +114,23 @@ __global__ __launch_bounds__(128, 2) void attention_mfma_kernel(AttnArgs a) {
   constexpr int NT = (DH + 31) / 32;        // 32-wide output tiles of PV
   constexpr int VROW = 40;                  // bytes per row of the transposed V image: 20 keys (19 + one zero)
   constexpr int QK_PLANE = kTokens * RB;
-  constexpr int VT_PLANE = NT * 32 * VROW;
-  constexpr int WAVE_LDS = 4 * QK_PLANE + 2 * VT_PLANE;
+  // LDS of a wave, in two phases (round 4): the four Q / K images; then, once S^T = K Q^T has been issued, the two transposed V
+  // images and the fp32 output rows OVER them (V waits in registers meanwhile).  12 160 B instead of 19 840 B per wave at DH = 72,
+  // 14 976 B instead of 22 272 B at DH = 96: the kernel is bound by the bytes it has in flight (measured at DH = 72 by padding the LDS:
+  // 4 / 6 / 8 waves per CU = 2.55 / 1.97 / 1.72 ms for the step's three launches; nothing beyond 8), and the six-head configuration
+  // (DH = 96: the reference's shipped architecture) went from 6 to 10 waves per CU with this layout.  A V^T plane holds DH rows; the
+  // MFMA tiles read NT * 32 rows, i.e. past it into whatever follows (the other plane, the output rows): those are output columns
+  // >= DH, which are dropped, and a contraction never mixes columns.  (The table form of layer 0 keeps 2 waves per SIMD: at 3 it
+  // spills, and the spill costs more than the occupancy gives.)
+  constexpr int VT_PLANE = DH * VROW;
+  constexpr int O_BYTES = kTokens * DH * 4;
+  constexpr int PHASE2 = 2 * VT_PLANE + O_BYTES;
+  constexpr int WAVE_LDS = (4 * QK_PLANE > PHASE2 ? 4 * QK_PLANE : PHASE2) + 15 & ~15;
+  static_assert(VT_PLANE + NT * 32 * VROW <= WAVE_LDS, "the over-read of the last PV tile stays inside the wave's region");
   constexpr int CH = DH / 8;                // 8-element chunks per row
   constexpr int PER_MAT = kTokens * CH;
   constexpr int ROUNDS = (3 * PER_MAT + 63) / 64;
-  static_assert(DH % 8 == 0 && QK_PLANE % 16 == 0 && kTokens * DH * 4 <= 4 * QK_PLANE, "layout");
+  static_assert(DH % 8 == 0 && QK_PLANE % 16 == 0 && VT_PLANE % 16 == 0, "layout");
   __shared__ __attribute__((aligned(16))) char smem[2 * WAVE_LDS];
 
   // A wave works on its own LDS region: no workgroup barrier anywhere (LDS operations of one wave complete in order; the two
@@ -133,7 +145,7 @@ __global__ __launch_bounds__(128, 2) void attention_mfma_kernel(AttnArgs a) {
   char* q_lo = base + QK_PLANE;
   char* k_hi = base + 2 * QK_PLANE;
   char* k_lo = base + 3 * QK_PLANE;
-  char* vt_hi = base + 4 * QK_PLANE;
+  char* vt_hi = base;                  // (second phase)
   char* vt_lo = vt_hi + VT_PLANE;
 
   // ---- global -> registers (all loads in flight), then -> bf16 hi/lo LDS images ----------------
@@ -180,52 +192,57 @@ __global__ __launch_bounds__(128, 2) void attention_mfma_kernel(AttnArgs a) {
       ld[r][1] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
   }
+  // Conversion of the loaded chunks into the bf16 hi / lo images.  PHASE 0: the Q and K chunks (and, TAB, the table arithmetic of
+  // every chunk, so that only its result stays in registers); PHASE 1, behind S^T: the V chunks into the transposed images.
+  auto convert = [&](auto phase_tag) {
+    constexpr int PHASE = decltype(phase_tag)::value;
 #pragma unroll
-  for (int r = 0; r < ROUNDS; ++r) {
-    const int e = lane + 64 * r;
-    if (e >= 3 * PER_MAT) continue;
-    const int mat = e / PER_MAT, rem = e % PER_MAT, i = rem / CH, c = rem % CH;
-    if (TAB && i >= 1 && i <= kPatchTokens) {     // rstd (SW + OW) + c2 (c2: 3 * DH floats per head, L1-resident)
-      const float* c2 = a.vec + head * DH + mat * kDim + c * 8;
-      const f32x4 c20 = *(const f32x4*)c2, c21 = *(const f32x4*)(c2 + 4);
-      ld[r][0] = rs[TAB ? r : 0] * (ld[r][0] + ldb[TAB ? r : 0][0]) + c20;
-      ld[r][1] = rs[TAB ? r : 0] * (ld[r][1] + ldb[TAB ? r : 0][1]) + c21;
-    }
-    if constexpr (F24) {      // (rows that were not read hold zeros, which unpack to zeros)
-      const f32x4 p0 = ld[r][0], p1 = ld[r][1];
-      ld[r][0] = unpack_f24x4(__float_as_uint(p0[0]), __float_as_uint(p0[1]), __float_as_uint(p0[2]));
-      ld[r][1] = unpack_f24x4(__float_as_uint(p0[3]), __float_as_uint(p1[0]), __float_as_uint(p1[1]));
-    }
-    bf16x8 hi, lo;
-#pragma unroll
-    for (int t = 0; t < 8; ++t) {
-      __bf16 hh, ll;
-      split_bf16(ld[r][t >> 2][t & 3], hh, ll);
-      hi[t] = hh;
-      lo[t] = ll;
-    }
-    if (mat < 2) {
-      char* dst = (mat == 0 ? q_hi : k_hi) + i * RB + c * 16;
-      *(bf16x8*)dst = hi;
-      *(bf16x8*)(dst + QK_PLANE) = lo;
-    } else {
+    for (int r = 0; r < ROUNDS; ++r) {
+      // (rounds that hold no chunk of this phase; TAB: phase 0 visits the V rounds too, for the table arithmetic)
+      if (PHASE == 0 ? (!TAB && 64 * r >= 2 * PER_MAT) : 64 * r + 63 < 2 * PER_MAT) continue;
+      const int e = lane + 64 * r;
+      if (e >= 3 * PER_MAT) continue;
+      const int mat = e / PER_MAT, rem = e % PER_MAT, i = rem / CH, c = rem % CH;
+      if (PHASE == 0 && TAB && i >= 1 && i <= kPatchTokens) {     // rstd (SW + OW) + c2 (c2: 3 * DH floats per head, L1-resident)
+        const float* c2 = a.vec + head * DH + mat * kDim + c * 8;
+        const f32x4 c20 = *(const f32x4*)c2, c21 = *(const f32x4*)(c2 + 4);
+        ld[r][0] = rs[TAB ? r : 0] * (ld[r][0] + ldb[TAB ? r : 0][0]) + c20;
+        ld[r][1] = rs[TAB ? r : 0] * (ld[r][1] + ldb[TAB ? r : 0][1]) + c21;
+      }
+      if (PHASE == 0 ? mat == 2 : mat < 2) continue;
+      f32x4 v0 = ld[r][0], v1 = ld[r][1];
+      if constexpr (F24) {      // (rows that were not read hold zeros, which unpack to zeros)
+        v0 = unpack_f24x4(__float_as_uint(ld[r][0][0]), __float_as_uint(ld[r][0][1]), __float_as_uint(ld[r][0][2]));
+        v1 = unpack_f24x4(__float_as_uint(ld[r][0][3]), __float_as_uint(ld[r][1][0]), __float_as_uint(ld[r][1][1]));
+      }
+      bf16x8 hi, lo;
 #pragma unroll
       for (int t = 0; t < 8; ++t) {
-        *(__bf16*)(vt_hi + (c * 8 + t) * VROW + i * 2) = hi[t];
-        *(__bf16*)(vt_lo + (c * 8 + t) * VROW + i * 2) = lo[t];
+        __bf16 hh, ll;
+        split_bf16(t < 4 ? v0[t & 3] : v1[t & 3], hh, ll);
+        hi[t] = hh;
+        lo[t] = ll;
+      }
+      if (PHASE == 0) {
+        char* dst = (mat == 0 ? q_hi : k_hi) + i * RB + c * 16;
+        *(bf16x8*)dst = hi;
+        *(bf16x8*)(dst + QK_PLANE) = lo;
+      } else {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+          *(__bf16*)(vt_hi + (c * 8 + t) * VROW + i * 2) = hi[t];
+          *(__bf16*)(vt_lo + (c * 8 + t) * VROW + i * 2) = lo[t];
+        }
       }
     }
-  }
+  };
+  convert(IntTag<0>());
   if (DHP > DH) {  // zero the contraction padding of the Q / K rows
     for (int idx = lane; idx < 4 * kTokens; idx += 64) {
       char* dst = base + (idx / kTokens) * QK_PLANE + (idx % kTokens) * RB + DH * 2;
 #pragma unroll
       for (int t = 0; t < (DHP - DH) / 2; ++t) *(uint32_t*)(dst + 4 * t) = 0u;
     }
-  }
-  for (int d = lane; d < NT * 32; d += 64) {  // key 19 of every V^T row is a finite zero
-    *(uint16_t*)(vt_hi + d * VROW + 38) = 0;
-    *(uint16_t*)(vt_lo + d * VROW + 38) = 0;
   }
 
   // ---- S^T = K Q^T: row = key j, column = query i ----------------------------------------------
@@ -272,8 +289,16 @@ __global__ __launch_bounds__(128, 2) void attention_mfma_kernel(AttnArgs a) {
     pl[t >> 3][t & 7] = ll;
   }
 
+  // ---- the V^T images over the Q / K images: every ds_read of those has returned (each was waited for in front of its MFMA, and a
+  // wave's LDS operations complete in order)
+  convert(IntTag<1>());
+  for (int d = lane; d < DH; d += 64) {  // key 19 of every V^T row is a finite zero
+    *(uint16_t*)(vt_hi + d * VROW + 38) = 0;
+    *(uint16_t*)(vt_lo + d * VROW + 38) = 0;
+  }
+
   // ---- O = P V: A operand = P^T accumulators; element e of k-step s is key 16s + 8(e>>2) + 4h + (e&3)
-  float* o_lds = (float*)base;  // [19][DH] fp32, re-uses the (now dead) Q / K images
+  float* o_lds = (float*)(base + 2 * VT_PLANE);  // [19][DH] fp32, behind the V^T images
   const bf16x4 z4 = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
 #pragma unroll
   for (int n = 0; n < NT; ++n) {
