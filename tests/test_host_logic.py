@@ -218,3 +218,19 @@ def test_relation_head_builds_the_host_sampler_like_the_reference(monkeypatch):
         monkeypatch.setitem(sys.modules, name, types.ModuleType(name))
     monkeypatch.setitem(sys.modules, mod.__name__, mod)
     assert relation_head._host_samp_processor(cfg) == "host-sampler" and seen == [cfg]
+
+
+def test_bench_reports_the_floors_of_the_layer_tail():
+    """bench.py's `floors` object: the four lower bounds of one layer-tail launch at the headline size, and the
+    fraction of the tightest one that the measured time reaches."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    rows = 15120 * 19
+    flops = 2.0 * rows * 576 * 576 + 4.0 * rows * 576 * 1152
+    f = bench.layer_tail_floors(rows, {"flops_per_launch": flops, "bytes_per_launch": rows * 576 * 16.0}, 7.56e9, 2.25)
+    assert abs(f["matrix_ms"] - 0.662) < 0.01 and abs(f["l2_to_lds_ms"] - 0.838) < 0.01 and abs(f["l2_miss_ms"] - 0.945) < 0.01
+    assert 0.5 < f["hbm_ms"] < 0.6 and abs(f["frac_of_tightest_floor"] - 0.945 / 2.25) < 0.01
+    assert bench.layer_tail_floors(rows, {"flops_per_launch": flops, "bytes_per_launch": 1.0}, None, 2.25)["l2_miss_ms"] is None
