@@ -46,6 +46,7 @@
 // timing ablations (tools/ffn_variants.sh; results are WRONG with any of them set): 1 = no DMA, 2 = no MFMA, 4 = no fragment
 // reads, 8 = no hidden conversion, 16 = no panel epilogue, 32 = the e4m3 stages move 3/5 (activation + weight slice) or 2/3 (weight slice)
 // of their bytes: the DMA volume of 3-byte operand rows (fp16 + ONE e4m3 plane) without their conversion work,
+// 256 = no residual-row loads (the accumulators start at zero: what the read burst at the top of a panel costs),
 // 128 = the activation half of 32 alone (the LayerNorm2 rows of fc1 as fp16 + one e4m3 plane: upper bound of DESIGN.md section 11 item 1a),
 // 64 = every workgroup streams the SAME FeedForward input panel (L2-resident) instead of its own: what the re-reads of the LayerNorm2 rows cost
 #ifndef FFN_ABLATE
@@ -555,10 +556,12 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs g) {
           for (int m = 0; m < 2; ++m) {
             int row = panel * FR + wm * 32 + m * 16 + r;
             if (row >= g.M) row = g.M - 1;          // clamp: rows past the end are never stored
-            acc2[t][i][m] = *(const f32x4*)(g.resid + (size_t)row * g.ldr + wn * 32 + q * 4 + t * FC + (i >> 1) * 64 + (i & 1) * 16);
+            if (FFN_ABLATE & 256) acc2[t][i][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+            else acc2[t][i][m] = *(const f32x4*)(g.resid + (size_t)row * g.ldr + wn * 32 + q * 4 + t * FC + (i >> 1) * 64 + (i & 1) * 16);
           }
       if (it == 0) {
-        asm volatile("s_waitcnt vmcnt(36)" ::: "memory");   // the prologue's stages 0 and 1 have landed (they are older than the 36 loads)
+        if (FFN_ABLATE & 256) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(36)" ::: "memory");   // the prologue's stages 0 and 1 have landed (they are older than the 36 loads)
         skip = 2;
       }
     }
