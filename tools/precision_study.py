@@ -79,6 +79,15 @@ QKV_PARTS = "qkv"
 QKV_DT = None   # storage type of q, k, v between the projection and the attention (None = fp32)
 
 
+X_F24 = False    # --xf24: the residual stream leaves every layer as 3-byte floats (16-bit significand), DESIGN.md section 11 item 3
+
+
+def q_f24(x):
+    b = x.contiguous().view(torch.int32)
+    r = (b + 0x7f + ((b >> 8) & 1)) & ~0xff
+    return r.view(torch.float32)
+
+
 QK_SCALE = 1.0   # --sharp: q / k rows of every to_qkv weight scaled by this (sharper attention); the yardstick is then the fp64 oracle
 
 
@@ -123,7 +132,8 @@ def run(name, scheme):
         y = vo.layer_norm(x, T("1.norm.weight"), T("1.norm.bias"))
         h = vo.gelu_erf(mm(y.reshape(-1, D), T("1.fn.net.0.weight")) + T("1.fn.net.0.bias"))
         y = mm(h, T("1.fn.net.3.weight")) + T("1.fn.net.3.bias")
-        return y.reshape(b, n, D) + x
+        out = y.reshape(b, n, D) + x
+        return q_f24(out) if X_F24 and l < cfg_.layers - 1 else out
 
     vo.encoder_layer = enc
     try:
@@ -143,6 +153,15 @@ if __name__ == "__main__":
             for dt, parts in ((None, "qkv"), (torch.float16, "qk+v3")):
                 QKV_DT, QKV_PARTS = dt, parts
                 print("q/k weight scale %g, q/k/v stored as %s:" % (sc, "fp32" if dt is None else "fp16 q, k + 3-byte v"),
+                      "  ".join("%s %.2e" % (n, run(n, "f16+e4m3")) for n in names), flush=True)
+        sys.exit(0)
+    if "--xf24" in sys.argv:
+        QKV_DT = None
+        for sc in (1.0, 5.0):
+            QK_SCALE = sc
+            for xf in (False, True):
+                X_F24 = xf
+                print("q/k weight scale %g, residual stream between the layers as %s, Linears f16+e4m3:" % (sc, "3-byte floats" if xf else "fp32"),
                       "  ".join("%s %.2e" % (n, run(n, "f16+e4m3")) for n in names), flush=True)
         sys.exit(0)
     if "--qkv16" in sys.argv:
