@@ -145,9 +145,10 @@ enum veto_saturation_site {
 };
 typedef struct veto_saturation {
   int64_t elements;          /* operand elements scanned at this site (0: the site does not exist in this layer) */
-  int64_t f16_saturated;     /* fp16 values at +-65504 */
-  int64_t value_saturated;   /* e4m3 value-plane bytes at +-448 */
-  int64_t resid_saturated;   /* e4m3 residual-plane bytes at +-448 */
+  /* upper bounds: an encoding at the clamp also holds values that merely round to it, and NaN / Inf encodings are counted too */
+  int64_t f16_saturated;     /* fp16 values at or beyond +-65504 (incl. Inf / NaN) */
+  int64_t value_saturated;   /* e4m3 value-plane bytes at +-448 (incl. the NaN encoding) */
+  int64_t resid_saturated;   /* e4m3 residual-plane bytes at +-448 (incl. the NaN encoding) */
 } veto_saturation_t;
 int veto_forward_saturation(veto_handle_t h, void* stream, const veto_inputs_t* in, void* workspace, size_t workspace_bytes,
                             float* out_logits, veto_saturation_t* counts, int32_t capacity);
@@ -363,6 +364,14 @@ int veto_debug_layer_tail(void* stream, const float* a, const float* wo, const f
                           int32_t reps, float* ms_per_rep, void* workspace, size_t workspace_bytes, const float* ln_w,
                           const float* ln_b, void* ln_rows);
 size_t veto_debug_layer_tail_workspace_bytes(int32_t m);
+
+/* ---- test / measurement hook: QKV projection + per-pair attention of a middle layer (model_veto.py:78-96) on VETO_MIXED operands:
+ * a [19 n_pair, 576] = LayerNorm1 rows, wqkv [1728, 576] (no bias); out_rows receives the merged-heads attention output as mixed
+ * activation rows (19 n_pair x 2304 bytes: the operand of the out projection).  mode 1 = ONE launch (qkv_attn_fused.hip: q / k / v never
+ * reach memory), mode 0 = the two launches it replaces (QKV GEMM writing 3-byte q / k / v + the attention launch).  heads 8 or 6. */
+int veto_debug_qkv_attn(void* stream, const float* a, const float* wqkv, int32_t n_pair, int32_t heads, int32_t mode, int32_t reps,
+                        float* ms_per_rep, void* workspace, size_t workspace_bytes, void* out_rows);
+size_t veto_debug_qkv_attn_workspace_bytes(int32_t n_pair);
 
 /* ---- training losses and MEET expert sampling (partial) -------------------------
  * veto_ce_loss: nn.CrossEntropyLoss(weight)(logits[rows], labels), mean reduction -- the relation loss of

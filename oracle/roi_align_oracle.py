@@ -3,18 +3,21 @@
 TEST INFRASTRUCTURE ONLY: imported by tests/ and nothing else; the product path is
 veto_amd/csrc/roialign.hip behind veto_roi_pool / veto_roi_pool_backward.
 
-PARITY UNPINNED against executed reference code: the reference's ROIAlign lives in its C++/CUDA
-extension (pysgg/csrc/cpu/ROIAlign_cpu.cpp, pysgg/csrc/cuda/ROIAlign_cuda.cu), which does not compile
-against this image's torch 2.10 headers (AT_DISPATCH_FLOATING_TYPES(input.type(), ...) ->
-torch/headeronly/core/Dispatch.h:36 "cannot convert DeprecatedTypeProperties to ScalarType"), and
-pysgg/modeling/poolers.py imports torchvision, which is absent.  What pins this file instead:
-  * it restates the published legacy ("aligned=False") ROIAlign line by line (citations below);
+PARITY PINNED to the executed reference (round 5): oracle/build_ref.sh compiles the reference's own CPU kernel templates
+(pysgg/csrc/cpu/ROIAlign_cpu.cpp:1-219, unmodified, against the installed torch headers; only the 35-line ATen wrapper behind
+them targets torch 1.4 and is replaced by a ctypes binding) into oracle/_ref/libroialign_ref.so, and
+tests/golden/make_golden.py::run_roialign drives it through the reference's own ROIAlign layer (layers/roi_align.py) and Pooler
+(modeling/poolers.py: LevelMapper, convert_to_roi_format, per-level dispatch, fixed 1/16 depth pooler) ->
+tests/golden/roialign_single.npz / roialign_pooler.npz.  tests/test_roi_align.py checks this file against them BIT FOR BIT
+(five (pooled, sampling ratio) shapes incl. the adaptive grid, out-of-map / sub-pixel / malformed ROIs, all four FPN levels).
+The backward exists in the reference only as CUDA (cuda/ROIAlign_cuda.cu:178-262; ROIAlign.h:44 "Not implemented on the CPU"):
+its restatement below is pinned by the adjoint identity <pool(f), g> = <f, pool_backward(g)> against the pinned forward.
+Kept next to the goldens:
   * analytic known answers in tests/test_roi_align.py: on an affine feature map f(y, x) = a*y + b*x + c
     bilinear sampling is exact, so every interior bin must equal f at the bin centre; constant maps,
     hand-computed border / out-of-map samples, and the FPN level boundaries of the LevelMapper formula;
   * the one published known-answer vector of this kernel lineage (maskrcnn-benchmark's legacy ROIAlign, kept by detectron2 as
-    `aligned=False` and pinned there as `old_results`: arange(25) as 5 x 5, box (1, 1, 3, 3), 4 x 4 bins), reproduced exactly;
-  * the backward restatement is checked to be the exact adjoint of the forward (ROIAlign is linear in the map).
+    `aligned=False` and pinned there as `old_results`: arange(25) as 5 x 5, box (1, 1, 3, 3), 4 x 4 bins), reproduced exactly.
 
 All arithmetic is float32 in the reference's operation order (numpy does not fuse multiply-adds),
 so the HIP kernel, which uses explicitly rounded mul/add, is compared bit for bit.

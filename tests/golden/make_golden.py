@@ -96,6 +96,12 @@ def import_reference():
         six.int_classes = (int,)
         torch._six = six
         sys.modules["torch._six"] = six
+    # apex is absent: its amp.float_function decorator (pysgg/layers/roi_align.py:57) only pins the op to fp32
+    for m in ("apex", "apex.amp"):
+        if isinstance(sys.modules[m], mock.MagicMock):
+            sys.modules[m].float_function = lambda f: f
+    if isinstance(sys.modules["apex"], mock.MagicMock):
+        sys.modules["apex"].amp = sys.modules["apex.amp"]
     sys.path.insert(0, REF)
     import pysgg.modeling.roi_heads.relation_head.roi_relation_predictors as P
     from pysgg.config import cfg
@@ -510,6 +516,76 @@ def run_sgg_eval(cfg, BoxList, name):
     print(evaluator["eval_recall"].generate_print_string(mode) + evaluator["eval_pair_accuracy"].generate_print_string(mode), end="")
 
 
+# ---------------------------------------------------------------------------
+# ROI feature extraction: the reference's OWN ROIAlign arithmetic and Pooler.
+# ---------------------------------------------------------------------------
+def _reference_roi_align_forward():
+    """The binding the reference's C++ extension exposes as `_C.roi_align_forward` (csrc/ROIAlign.h:10-24 ->
+    cpu/ROIAlign_cpu.cpp:221-257).  That 35-line ATen wrapper does not build against torch 2.10; the kernel templates it
+    calls (ROIAlign_cpu.cpp:1-219) do, unmodified: oracle/build_ref.sh compiles them into oracle/_ref/libroialign_ref.so and
+    this function is the wrapper's equivalent over ctypes (same argument order, same output allocation)."""
+    import ctypes
+    import subprocess
+    path = os.path.join(REPO, "oracle", "_ref", "libroialign_ref.so")
+    if not os.path.exists(path):
+        subprocess.check_call([os.path.join(REPO, "oracle", "build_ref.sh")])
+    lib = ctypes.CDLL(path)
+    fp = ctypes.POINTER(ctypes.c_float)
+    lib.veto_ref_roi_align_forward.argtypes = [fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, fp, ctypes.c_int, ctypes.c_float,
+                                               ctypes.c_int, ctypes.c_int, fp]
+    lib.veto_ref_roi_align_forward.restype = None
+
+    def forward(input, rois, spatial_scale, pooled_height, pooled_width, sampling_ratio):
+        assert pooled_height == pooled_width and input.dtype == torch.float32 and not input.is_cuda
+        inp, r = input.contiguous(), rois.contiguous().float()
+        out = torch.empty((r.shape[0], inp.shape[1], pooled_height, pooled_width), dtype=torch.float32)
+        if out.numel():
+            lib.veto_ref_roi_align_forward(ctypes.cast(inp.data_ptr(), fp), inp.shape[1], inp.shape[2], inp.shape[3],
+                                           ctypes.cast(r.data_ptr(), fp), r.shape[0], float(spatial_scale), pooled_height,
+                                           sampling_ratio, ctypes.cast(out.data_ptr(), fp))
+        return out
+    return forward
+
+
+ROI_KEEP_CHANNELS = 6      # ROIAlign treats channels independently: the fixtures keep the first few
+
+
+def run_roialign(BoxList):
+    """roialign_single.npz: the reference's ROIAlign layer (layers/roi_align.py:50-61 -> ROIAlign_cpu.cpp) on
+    veto_amd.synth.synthetic_roi_single; roialign_pooler.npz: the reference's Pooler (poolers.py:45-171, cat_all_levels False,
+    the way VETOFeatureExtractor builds it) -- LevelMapper, convert_to_roi_format, per-level dispatch, the fixed 1/16 depth
+    pooler -- on veto_amd.synth.synthetic_roi_pyramid."""
+    sys.modules["pysgg._C"].roi_align_forward = _reference_roi_align_forward()
+    import pysgg
+    pysgg._C = sys.modules["pysgg._C"]
+    from pysgg.layers.roi_align import ROIAlign
+    from pysgg.modeling.poolers import LevelMapper, Pooler
+    out = {}
+    for pooled, ratio in synth.ROI_SINGLE_CASES:
+        feat, rois = synth.synthetic_roi_single(pooled, ratio, channels=ROI_KEEP_CHANNELS)
+        y = ROIAlign((pooled, pooled), 1.0 / 16, ratio)(torch.from_numpy(feat), torch.from_numpy(rois))
+        out["rois_p%d_r%d" % (pooled, ratio)] = rois
+        out["out_p%d_r%d" % (pooled, ratio)] = y.numpy()
+    np.savez_compressed(os.path.join(HERE, "roialign_single.npz"), **out)
+    print("%-24s %s" % ("roialign_single", {k: v.shape for k, v in out.items() if k.startswith("out")}))
+
+    feats, depth, boxes, size = synth.synthetic_roi_pyramid(channels=ROI_KEEP_CHANNELS)
+    props = [BoxList(torch.from_numpy(b), size, mode="xyxy") for b in boxes]
+    pooler = Pooler((8, 8), (0.25, 0.125, 0.0625, 0.03125), 2, in_channels=ROI_KEEP_CHANNELS, cat_all_levels=False)
+    rgb, dep = pooler([torch.from_numpy(f) for f in feats], props, depth_features=torch.from_numpy(depth))
+    levels = pooler.map_levels(props)
+    rois = pooler.convert_to_roi_format(props)
+    # the level boundaries of test_roi_align.py::test_level_mapper_boundaries through the reference's LevelMapper
+    def box(w, h):
+        return [10.0, 20.0, 10.0 + w - 1, 20.0 + h - 1]
+    bnd = np.array([box(8, 8), box(111, 111), box(112, 112), box(223, 223), box(224, 224), box(447, 447), box(448, 448),
+                    box(2000, 2000), box(56, 224)], dtype=np.float32)
+    bnd_levels = LevelMapper(2, 5)([BoxList(torch.from_numpy(bnd), (4000, 4000), mode="xyxy")])
+    np.savez_compressed(os.path.join(HERE, "roialign_pooler.npz"), rgb=rgb.numpy(), depth=dep.numpy(), levels=levels.numpy(),
+                        rois=rois.numpy(), boundary_boxes=bnd, boundary_levels=bnd_levels.numpy())
+    print("%-24s rgb %s depth %s levels %s" % ("roialign_pooler", tuple(rgb.shape), tuple(dep.shape), np.bincount(levels.numpy().astype(np.int64)).tolist()))
+
+
 # Full-size cases (round 2): the BASELINE.json workloads that round 1 only exercised at <= 14 objects per image.
 RAGGED12 = [1, 2, 64, 36, 7, 50, 13, 3, 46, 20, 36, 5]     # 64 / 50 / 46 objects exceed MAX_PROPOSAL_PAIR = 2048 candidates
 
@@ -539,6 +615,9 @@ def predictor_cases(P, cfg, BoxList):
 def main():
     torch.set_num_threads(8)
     P, cfg, BoxList = import_reference()
+    if os.environ.get("GOLDEN_ONLY") == "roialign":    # regenerate only the ROI feature extraction fixtures
+        run_roialign(BoxList)
+        return
     if os.environ.get("GOLDEN_ONLY") == "relsample":
         run_relsample(BoxList, "relsample_gtbox")
         return
@@ -566,6 +645,7 @@ def main():
         run_postprocessor_vote(cfg, BoxList, "postvote_gqa_c_n7", 7, "GQA", "C")
         run_case(P, cfg, BoxList, "meetx_n10_l4h8", "predcls", 4, 8, [10], meet=True, experts=True)
         return
+    run_roialign(BoxList)
     run_relsample(BoxList, "relsample_gtbox")
     run_train_losses(P, cfg, BoxList, "train_vanilla", meet=False)
     run_train_losses(P, cfg, BoxList, "train_vanilla_beta", meet=False, beta_loss=True)

@@ -266,6 +266,50 @@ def test_fused_layer_tail(m):
     assert (xs[0] - xs[1]).abs().max().item() < 3e-4
 
 
+def _attention_fp64(a, wqkv, n_pair, heads):
+    """model_veto.py:85-96 on LayerNorm'ed rows a [19 n_pair, 576], fp64."""
+    dh = 576 // heads
+    qkv = (a.double() @ wqkv.double().t()).reshape(n_pair, 19, 3, heads, dh)
+    q, k, v = (qkv[:, :, i].permute(0, 2, 1, 3) for i in range(3))            # [pair, head, token, dh]
+    att = torch.softmax(q @ k.transpose(-1, -2) * dh ** -0.5, dim=-1)
+    return (att @ v).permute(0, 2, 1, 3).reshape(n_pair * 19, 576)
+
+
+@pytest.mark.parametrize("heads", [8, 6])
+@pytest.mark.parametrize("n_pair,sharp", [(1, 1.0), (16, 1.0), (37, 3.0), (1260, 1.0), (4099, 2.0)])
+def test_fused_qkv_attention(n_pair, sharp, heads):
+    """QKV projection + per-pair attention in one launch (qkv_attn_fused.hip; model_veto.py:78-96) against fp64 and against the two
+    launches it replaces, on pair counts that leave partial 16-pair tiles, fewer tiles than workgroups and several tiles per
+    workgroup; `sharp` scales q and k so that the softmax is far from uniform (scores of +-30)."""
+    from veto_amd import native
+    lib = native.load_library()
+    dev = _dev()
+    g = torch.Generator(device="cpu").manual_seed(n_pair * 10 + heads)
+    m = n_pair * 19
+    a = torch.randn(m, 576, generator=g).to(dev)
+    wqkv = (torch.randn(1728, 576, generator=g) * 0.05)
+    wqkv[:1152] *= sharp
+    wqkv = wqkv.to(dev)
+    ref = _attention_fp64(a, wqkv, n_pair, heads)
+    ws = torch.empty(lib.veto_debug_qkv_attn_workspace_bytes(n_pair), dtype=torch.uint8, device=dev)
+    outs, errs = [], []
+    for mode in (1, 0):
+        rows = torch.zeros(m, 4 * 576, dtype=torch.uint8, device=dev)
+        native.check(lib.veto_debug_qkv_attn(None, a.data_ptr(), wqkv.data_ptr(), n_pair, heads, mode, 1, None, ws.data_ptr(), ws.numel(),
+                                             rows.data_ptr()))
+        torch.cuda.synchronize()
+        h, hx, y = _decode_mixed_rows(rows, 576)
+        assert torch.isfinite(hx).all()
+        errs.append((hx - ref).abs().max().item())
+        outs.append(hx)
+    # a score carries the 2^-16 of its operands times sum |q||k|, so the error grows with the sharpness: the bar is the plain case's,
+    # scaled, and the two-launch form's own error (the fused form keeps q / k / v in fp32 up to the bf16 hi / lo split, the two-launch
+    # form rounds them to 3-byte floats first: the fused form is the more accurate of the two)
+    bar = 2e-4 * sharp ** 2 * max(1.0, ref.abs().max().item())
+    assert errs[0] < bar and errs[0] < 1.5 * errs[1] + 2e-5, (n_pair, heads, errs)
+    assert (outs[0] - outs[1]).abs().max().item() < 2 * bar
+
+
 @pytest.mark.parametrize("m,n,k,kb_tiles,kb_steps", [(1000, 576, 576, 0, 0), (5000, 4608, 768, 3, 3), (3000, 768, 4608, 1, 36),
                                                       (300, 1152, 192, 2, 2)])
 def test_gemm_block_diagonal_and_output_forms(m, n, k, kb_tiles, kb_steps):
@@ -1001,7 +1045,8 @@ def test_restructured_first_and_last_layer_match_the_plain_path(tmp_path):
     # GEMMs instead of four block-structured ones and its attention on the vector ALU, fp32 q / k / v instead of 3-byte floats, one
     # launch per panel phase
     variants = (("default", {}), ("plain", {"VETO_QKV0_TABLES": "0", "VETO_CLS_FOLD": "0"}),
-                ("round2-forms", {"VETO_FOLD_BLOCKS": "0", "VETO_QKV_F24": "0", "VETO_TAIL_FUSED": "0", "VETO_FFN_LATE": "0", "VETO_CLS_MFMA": "0"}))
+                ("round2-forms", {"VETO_FOLD_BLOCKS": "0", "VETO_QKV_F24": "0", "VETO_TAIL_FUSED": "0", "VETO_FFN_LATE": "0", "VETO_CLS_MFMA": "0"}),
+                ("two-launch-attention", {"VETO_QKV_ATTN_FUSED": "0"}))
     for tag, env in variants:
         path = str(tmp_path / (tag + ".npy"))
         subprocess.run([sys.executable, "-c", code, path], check=True, env=dict(os.environ, **env), timeout=600)

@@ -1,17 +1,49 @@
 """ROI feature extraction.
 
-The reference's ROIAlign cannot be executed in this image (its C++ extension does not compile against
-torch 2.10 and torchvision is absent), so the CPU restatement oracle/roi_align_oracle.py is pinned by
-ANALYTIC known answers here (CPU tests), and the HIP kernel is compared with it bit for bit (GPU tests)."""
+PINNED to the executed reference: tests/golden/roialign_*.npz are outputs of the reference's own CPU ROIAlign kernel
+(pysgg/csrc/cpu/ROIAlign_cpu.cpp:1-219, compiled unmodified by oracle/build_ref.sh) driven through its own ROIAlign layer
+and Pooler (tests/golden/make_golden.py::run_roialign).  The CPU restatement oracle/roi_align_oracle.py reproduces them bit
+for bit (CPU tests below, next to the analytic known answers), and so does the HIP kernel (GPU tests)."""
 import ctypes
+import os
 
 import numpy as np
 import pytest
 import torch
 
 from oracle import roi_align_oracle as ro
+from veto_amd import synth
 
 F = np.float32
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+KEEP = 6     # channels the fixtures hold (make_golden.py ROI_KEEP_CHANNELS; ROIAlign treats channels independently)
+
+
+# ----------------------------------------------------------------------------------------------------
+# oracle vs the executed reference (CPU), bit for bit
+# ----------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("pooled,ratio", synth.ROI_SINGLE_CASES)
+def test_oracle_matches_the_reference_kernel(pooled, ratio):
+    g = np.load(os.path.join(GOLDEN, "roialign_single.npz"))
+    feat, rois = synth.synthetic_roi_single(pooled, ratio, channels=KEEP)
+    assert np.array_equal(rois, g["rois_p%d_r%d" % (pooled, ratio)])
+    want = g["out_p%d_r%d" % (pooled, ratio)]
+    got = ro.roi_align(feat, rois, 1.0 / 16, pooled, ratio)
+    assert got.shape == want.shape and np.array_equal(got, want), ((got != want).sum(), np.abs(got - want).max())
+    assert (want[1] == 0).any()      # the mostly-outside ROI exercises the out-of-map branch
+
+
+def test_oracle_matches_the_reference_pooler():
+    """LevelMapper (poolers.py:17-43), convert_to_roi_format (:96-107), the per-level dispatch and the fixed 1/16 depth pooler
+    (:109-171) of the reference's own Pooler, cat_all_levels False."""
+    g = np.load(os.path.join(GOLDEN, "roialign_pooler.npz"))
+    feats, depth, boxes, _ = synth.synthetic_roi_pyramid(channels=KEEP)
+    assert np.array_equal(ro.to_rois(boxes), g["rois"])
+    lv = ro.map_levels(np.concatenate(boxes))
+    assert np.array_equal(lv, g["levels"].astype(np.int64)) and set(lv.tolist()) == {0, 1, 2, 3}
+    assert np.array_equal(ro.map_levels(g["boundary_boxes"]), g["boundary_levels"].astype(np.int64))
+    rgb, dep = ro.pooler_forward(feats, boxes, depth)
+    assert np.array_equal(rgb, g["rgb"]) and np.array_equal(dep, g["depth"])
 
 
 def _affine_map(B, C, H, W, seed=0):
@@ -145,15 +177,7 @@ def test_roi_pool_abi_rejects_bad_arguments_without_a_gpu():
 # ----------------------------------------------------------------------------------------------------
 # HIP kernel vs oracle (GPU), bit for bit
 # ----------------------------------------------------------------------------------------------------
-def _random_boxes(rng, n, W, H):
-    xy = rng.uniform(-20, [W * 0.9, H * 0.9], size=(n, 2))
-    wh = np.exp(rng.uniform(np.log(2), np.log(max(W, H) * 1.2), size=(n, 2)))
-    b = np.concatenate([xy, xy + wh], 1).astype(F)
-    b[0] = [0, 0, W - 1, H - 1]            # the whole image
-    b[1] = [W - 3, H - 3, W + 40, H + 40]  # mostly outside
-    b[2] = [30.2, 40.7, 30.3, 40.8]        # sub-pixel -> forced to 1x1 on the map
-    b[3] = [50, 60, 40, 30]                # malformed (x2 < x1)
-    return b
+_random_boxes = synth.roi_test_boxes
 
 
 @pytest.mark.gpu
@@ -161,14 +185,16 @@ def _random_boxes(rng, n, W, H):
 def test_hip_roi_align_single_level_bit_exact(pooled, ratio):
     from veto_amd.poolers import ROIAlign
     dev = torch.device("cuda:0")
-    rng = np.random.RandomState(pooled * 10 + ratio)
-    feat = rng.randn(2, 37, 50, 84).astype(F)
-    boxes = _random_boxes(rng, 23, 84 * 16, 50 * 16)
-    rois = np.concatenate([rng.randint(0, 2, size=(23, 1)).astype(F), boxes], 1)
+    feat, rois = synth.synthetic_roi_single(pooled, ratio)      # 37 channels; the first KEEP are the fixture's maps
     got = ROIAlign((pooled, pooled), 1.0 / 16, ratio)(torch.from_numpy(feat).to(dev), torch.from_numpy(rois).to(dev)).cpu().numpy()
     want = ro.roi_align(feat, rois, 1.0 / 16, pooled, ratio)
     assert got.shape == want.shape == (23, 37, pooled, pooled)
     assert np.array_equal(got, want), ((got != want).sum(), np.abs(got - want).max())
+    # ... and the executed reference itself (tests/golden/roialign_single.npz)
+    ref = np.load(os.path.join(GOLDEN, "roialign_single.npz"))["out_p%d_r%d" % (pooled, ratio)]
+    feat6, rois6 = synth.synthetic_roi_single(pooled, ratio, channels=KEEP)
+    got6 = ROIAlign((pooled, pooled), 1.0 / 16, ratio)(torch.from_numpy(feat6).to(dev), torch.from_numpy(rois6).to(dev)).cpu().numpy()
+    assert np.array_equal(got6, ref), ((got6 != ref).sum(), np.abs(got6 - ref).max())
 
 
 @pytest.mark.gpu
@@ -178,11 +204,7 @@ def test_hip_pooler_fpn_and_depth_bit_exact():
     from veto_amd.poolers import make_roi_box_feature_extractor
     from veto_amd.structures import BoxList
     dev = torch.device("cuda:0")
-    rng = np.random.RandomState(11)
-    W, H = 1024, 640
-    feats = [rng.randn(3, 256, H >> (2 + l), W >> (2 + l)).astype(F) for l in range(4)]
-    depth = rng.randn(3, 256, H >> 4, W >> 4).astype(F)
-    boxes = [_random_boxes(rng, n, W, H) for n in (9, 17, 5)]
+    feats, depth, boxes, (W, H) = synth.synthetic_roi_pyramid()
     cfg = testing.make_config(1, 8)
     ext = make_roi_box_feature_extractor(cfg, 256, for_relation=True)
     ext.pooler.keep_levels = True
@@ -195,6 +217,16 @@ def test_hip_pooler_fpn_and_depth_bit_exact():
     assert np.array_equal(ext.pooler.last_levels.cpu().numpy(), lv)
     assert np.array_equal(x2d.cpu().numpy(), want_rgb)
     assert np.array_equal(d2d.cpu().numpy(), want_dep)
+    # ... and the reference's own Pooler (tests/golden/roialign_pooler.npz holds its outputs for the KEEP-channel pyramid)
+    g = np.load(os.path.join(GOLDEN, "roialign_pooler.npz"))
+    f6, d6, b6, _ = synth.synthetic_roi_pyramid(channels=KEEP)
+    assert all(np.array_equal(a, b) for a, b in zip(b6, boxes))
+    from veto_amd.poolers import Pooler
+    p6 = Pooler((8, 8), (0.25, 0.125, 0.0625, 0.03125), 2)
+    p6.keep_levels = True
+    r6, dd6 = p6([torch.from_numpy(f).to(dev) for f in f6], props, depth_features=torch.from_numpy(d6).to(dev))
+    assert np.array_equal(p6.last_levels.cpu().numpy(), g["levels"].astype(np.int64))
+    assert np.array_equal(r6.cpu().numpy(), g["rgb"]) and np.array_equal(dd6.cpu().numpy(), g["depth"])
 
 
 @pytest.mark.gpu

@@ -1,11 +1,12 @@
-"""Checks on the GENERATED code of veto_amd/csrc/ffn_fused.hip (gfx950).
+"""Checks on the GENERATED code of veto_amd/csrc/ffn_fused.hip and veto_amd/csrc/qkv_attn_fused.hip (gfx950).
 
-The panel kernel's MFMAs are inline asm with tied accumulators (192 of 256 registers are accumulators; the compiler's own MFMA
-forms rename and spill them), so the compiler pads no MFMA hazard around them and counts none of the kernel's LDS-DMA.  What keeps
+Both kernels' GEMM MFMAs are inline asm with tied accumulators (140 - 192 of 256 registers are accumulators; the compiler's own MFMA
+forms rename and spill them), so the compiler pads no MFMA hazard around them and counts none of the kernels' LDS-DMA.  What keeps
 the kernel correct is instruction placement, and this module is what checks it after every build:
 
-  * hazards()      every compiler instruction that reads or writes a register an MFMA wrote fewer than 18 wait states earlier,
-                   and every vector write of an MFMA operand fewer than 2 states ahead of the MFMA;
+  * hazards()      every compiler instruction that reads or writes a register an INLINE-ASM MFMA wrote fewer than 18 wait states
+                   earlier, and every vector write of an MFMA operand fewer than 2 states ahead of the MFMA (MFMAs the compiler
+                   emitted itself -- the attention products of qkv_attn_fused.hip -- get their wait states from the compiler);
   * unpadded()     every inline-asm MFMA that is not opened by its own `s_nop 1` (the pad that makes the second rule hold by
                    construction, whatever the compiler puts in front of the statement);
   * m0_users()     compiler-generated instructions that touch M0 (the LDS-DMA statements write it without being able to declare it);
@@ -53,8 +54,8 @@ def _split_ops(text):
     return parts[0], [p.strip() for p in parts[1].split(",")]
 
 
-def _instructions(path):
-    """(text, inside_inline_asm) for every instruction line of the file, in order."""
+def _instructions(path, labels=False):
+    """(text, inside_inline_asm) for every instruction line of the file, in order; with labels=True also ("label:", False) rows."""
     out, inasm = [], False
     for raw in open(path):
         s = raw.strip()
@@ -64,6 +65,9 @@ def _instructions(path):
         if s.startswith(";;#ASMEND"):
             inasm = False
             continue
+        if labels and re.match(r"^[.\w$]+:", s) and not s.startswith(".amdhsa"):
+            out.append((s.split(":")[0] + ":", False))
+            continue
         if not s or s.startswith((";", ".", "//")) or s.endswith(":"):
             continue
         out.append((s.split(";")[0].strip(), inasm))
@@ -71,43 +75,74 @@ def _instructions(path):
 
 
 def hazards(path):
-    """List of findings (strings); empty when the generated code keeps both MFMA rules."""
-    written_at = {}     # register -> wait-state clock of the last MFMA write
-    valu_write_at = {}  # register -> clock of the last non-MFMA vector write
-    clock, found = 0, []
-    for text, _ in _instructions(path):
-        op, ops = _split_ops(text)
-        if op == "s_nop":
-            clock += int(ops[0]) + 1
-            continue
-        if op.startswith("v_mfma"):
-            dst = _regs(ops[0])
-            srcs = set()
-            for o in ops[1:]:
-                srcs |= _regs(o)
-            for r in srcs - dst:
-                if r in valu_write_at and clock - valu_write_at[r] < 2:
-                    found.append("vector write of v%d %d states ahead of: %s" % (r, clock - valu_write_at[r], text))
-            for r in (_regs(ops[3]) if len(ops) > 3 else set()):
-                if r in valu_write_at and clock - valu_write_at[r] < 2:
-                    found.append("vector write of accumulator v%d %d states ahead of: %s" % (r, clock - valu_write_at[r], text))
-            for r in dst:
-                written_at[r] = clock
+    """List of findings (strings); empty when the generated code keeps the MFMA rules.
+
+    Control flow: the scan is linear, but at every label the "states since the last MFMA write" of a register is merged (minimum)
+    with what a first pass recorded at each branch to that label -- forward branches and loop back-edges alike -- so a result read
+    too early across a back-edge or behind a branch target is seen.  (One merge round, not a fixpoint: a hazard that only exists
+    after two trips through different back-edges in a row would need a second round; every branch distance is an under-estimate of
+    the real one because taken branches cost cycles that are not counted.)"""
+    instrs = _instructions(path, labels=True)
+
+    def scan(snapshots, collect):
+        written_at = {}     # register -> wait-state clock of the last MFMA write
+        valu_write_at = {}  # register -> clock of the last non-MFMA vector write
+        clock, found = 0, []
+        for text, inasm in instrs:
+            if text.endswith(":"):
+                for dist in snapshots.get(text[:-1], ()):
+                    for r, d in dist.items():
+                        written_at[r] = max(written_at.get(r, -10 ** 9), clock - d)
+                continue
+            op, ops = _split_ops(text)
+            if op == "s_nop":
+                clock += int(ops[0]) + 1
+                continue
+            if op in ("s_branch",) or op.startswith("s_cbranch"):
+                if collect and ops:
+                    snapshots.setdefault(ops[-1], []).append({r: clock + 1 - t for r, t in written_at.items() if clock + 1 - t < MIN_STATES})
+                clock += 1
+                continue
+            if op.startswith("v_mfma"):
+                dst = _regs(ops[0])
+                srcs = set()
+                for o in ops[1:]:
+                    srcs |= _regs(o)
+                for r in srcs - dst:
+                    if r in valu_write_at and clock - valu_write_at[r] < 2:
+                        found.append("vector write of v%d %d states ahead of: %s" % (r, clock - valu_write_at[r], text))
+                    # an MFMA result used as the A / B operand of a later MFMA (not the tied accumulator) needs the full distance too
+                    if r in written_at and clock - written_at[r] < MIN_STATES:
+                        found.append("MFMA operand v%d %d states behind an MFMA write: %s" % (r, clock - written_at[r], text))
+                for r in (_regs(ops[3]) if len(ops) > 3 else set()):
+                    if r in valu_write_at and clock - valu_write_at[r] < 2:
+                        found.append("vector write of accumulator v%d %d states ahead of: %s" % (r, clock - valu_write_at[r], text))
+                if inasm:       # (an MFMA the compiler emitted itself gets its wait states from the compiler: only the inline-asm ones are tracked)
+                    for r in dst:
+                        written_at[r] = clock
+                else:
+                    for r in dst:
+                        written_at.pop(r, None)
+                clock += 1
+                continue
+            touched = set()
+            for o in ops:
+                touched |= _regs(o)
+            for r in touched:
+                if r in written_at and clock - written_at[r] < MIN_STATES:
+                    found.append("%s touches v%d %d states behind an MFMA write" % (text, r, clock - written_at[r]))
+                    break
+            # (v_cmp* / v_readfirstlane / v_readlane write a scalar destination: their first operand names no vector register)
+            if op.startswith(("v_", "ds_read", "ds_bpermute", "global_load_dword", "scratch_load")) and ops and not op.startswith(("v_cmp", "v_readfirstlane", "v_readlane")):
+                for r in _regs(ops[0]):
+                    valu_write_at[r] = clock
+                    written_at.pop(r, None)
             clock += 1
-            continue
-        touched = set()
-        for o in ops:
-            touched |= _regs(o)
-        for r in touched:
-            if r in written_at and clock - written_at[r] < MIN_STATES:
-                found.append("%s touches v%d %d states behind an MFMA write" % (text, r, clock - written_at[r]))
-                break
-        if op.startswith(("v_", "ds_read", "ds_bpermute", "global_load_dword", "scratch_load")) and ops:
-            for r in _regs(ops[0]):
-                valu_write_at[r] = clock
-                written_at.pop(r, None)
-        clock += 1
-    return found
+        return found
+
+    snapshots = {}
+    scan(snapshots, True)
+    return scan(snapshots, False)
 
 
 def unpadded(path):
@@ -132,11 +167,16 @@ def m0_users(path):
     return [text for text, inasm in _instructions(path) if not inasm and re.search(r"\bm0\b", text)]
 
 
-def stats(path):
-    """{mode: dict(barriers, scratch_ops, compiler_vmcnt_waits, vgprs, scratch_bytes, by_interval)} for the three panel kernels."""
+# source -> (kernel name pattern with the template argument as group 1, the instantiations that must be present)
+KERNELS = {"ffn_fused.hip": (r"ffn_fused_kernelILi(\d+)E", (0, 1, 2)),
+           "qkv_attn_fused.hip": (r"qkv_attn_fused_kernelILi(\d+)E", (72, 96))}
+
+
+def stats(path, pattern=KERNELS["ffn_fused.hip"][0]):
+    """{template argument: dict(barriers, scratch_ops, compiler_vmcnt_waits, vgprs, scratch_bytes, by_interval)} per kernel instantiation."""
     text = open(path).read().split("\n")
-    starts = [(i, re.search(r"ffn_fused_kernelILi(\d)E", l).group(1)) for i, l in enumerate(text)
-              if re.match(r"^_ZN4veto.*ffn_fused_kernelILi\dE.*:", l)]
+    starts = [(i, re.search(pattern, l).group(1)) for i, l in enumerate(text)
+              if re.match(r"^_ZN4veto.*" + pattern + r".*:", l)]
     out = {}
     for i0, mode in starts:
         i1 = next(j for j in range(i0, len(text)) if "s_endpgm" in text[j])
@@ -171,32 +211,39 @@ def stats(path):
     return out
 
 
-def problems(path):
-    """Every finding of every check, as strings."""
+def problems(path, parse_failures=None, source="ffn_fused.hip", scratch_ok=()):
+    """Every finding of every check, as strings.  parse_failures: a list that receives "could not find / read" findings instead of the
+    result (a change in the compiler's output format is not a hazard: __graft_entry__.build() prints those and goes on).
+    scratch_ok: instantiations whose scratch use is reported by stats() but is not a finding."""
     out = list(hazards(path)) + list(unpadded(path))
     out += ["compiler instruction touches m0: %s" % t for t in m0_users(path)]
-    st = stats(path)
-    for mode in (0, 1, 2):
+    pattern, wanted = KERNELS[source]
+    st = stats(path, pattern)
+    for mode in wanted:
         if mode not in st:
-            out.append("kernel ffn_fused_kernel<%d> not found in %s" % (mode, path))
+            (out if parse_failures is None else parse_failures).append("kernel instantiation <%d> of %s not found in %s" % (mode, source, path))
             continue
         k = st[mode]
-        if k["scratch_ops"] or k["scratch_bytes"]:
+        if (k["scratch_ops"] or k["scratch_bytes"]) and mode not in scratch_ok:
             out.append("MODE %d: %d scratch instructions, %s bytes of scratch (a spill shares vmcnt with the LDS-DMA)" % (mode, k["scratch_ops"], k["scratch_bytes"]))
-        if k["vgprs"] is None or k["vgprs"] > MAX_VGPRS:
+        if k["vgprs"] is None:
+            (out if parse_failures is None else parse_failures).append("MODE %d: register count not found in %s" % (mode, path))
+        elif k["vgprs"] > MAX_VGPRS:
             out.append("MODE %d: %s VGPRs (two waves per SIMD need <= %d)" % (mode, k["vgprs"], MAX_VGPRS))
     return out
 
 
-def check(extra_flags=(), keep_dir=None):
-    """Compiles ffn_fused.hip to assembly and raises RuntimeError on any finding.  Returns the stats."""
+def check(extra_flags=(), keep_dir=None, parse_failures=None, source="ffn_fused.hip", scratch_ok=()):
+    """Compiles one of the audited sources (KERNELS) to assembly and raises RuntimeError on any finding.  Returns the stats.
+    What the audit covers: hazards around the inline-asm MFMAs (linear scan + one merge round at labels, see hazards()), their
+    s_nop pads, M0, scratch, register count.  It does not model taken-branch timing or LDS / memory ordering."""
     d = keep_dir or tempfile.mkdtemp(prefix="veto_asm_")
     try:
-        path = compile_asm(d, extra_flags)
-        bad = problems(path)
+        path = compile_asm(d, extra_flags, source)
+        bad = problems(path, parse_failures, source, scratch_ok)
         if bad:
-            raise RuntimeError("generated code of ffn_fused.hip fails its audit (%d findings):\n  %s" % (len(bad), "\n  ".join(bad[:20])))
-        return stats(path)
+            raise RuntimeError("generated code of %s fails its audit (%d findings):\n  %s" % (source, len(bad), "\n  ".join(bad[:20])))
+        return stats(path, KERNELS[source][0])
     finally:
         if keep_dir is None:
             shutil.rmtree(d, ignore_errors=True)

@@ -119,14 +119,13 @@ __global__ __launch_bounds__(128, TAB ? 2 : 3) void attention_mfma_kernel(AttnAr
   // 14 976 B instead of 22 272 B at DH = 96: the kernel is bound by the bytes it has in flight (measured at DH = 72 by padding the LDS:
   // 4 / 6 / 8 waves per CU = 2.55 / 1.97 / 1.72 ms for the step's three launches; nothing beyond 8), and the six-head configuration
   // (DH = 96: the reference's shipped architecture) went from 6 to 10 waves per CU with this layout.  A V^T plane holds DH rows; the
-  // MFMA tiles read NT * 32 rows, i.e. past it into whatever follows (the other plane, the output rows): those are output columns
-  // >= DH, which are dropped, and a contraction never mixes columns.  (The table form of layer 0 keeps 2 waves per SIMD: at 3 it
+  // MFMA tiles cover NT * 32 output columns: the lanes of columns >= DH re-read row 0 (their results are dropped, and a contraction
+  // never mixes columns).  (The table form of layer 0 keeps 2 waves per SIMD: at 3 it
   // spills, and the spill costs more than the occupancy gives.)
   constexpr int VT_PLANE = DH * VROW;
   constexpr int O_BYTES = kTokens * DH * 4;
   constexpr int PHASE2 = 2 * VT_PLANE + O_BYTES;
   constexpr int WAVE_LDS = (4 * QK_PLANE > PHASE2 ? 4 * QK_PLANE : PHASE2) + 15 & ~15;
-  static_assert(VT_PLANE + NT * 32 * VROW <= WAVE_LDS, "the over-read of the last PV tile stays inside the wave's region");
   constexpr int CH = DH / 8;                // 8-element chunks per row
   constexpr int PER_MAT = kTokens * CH;
   constexpr int ROUNDS = (3 * PER_MAT + 63) / 64;
@@ -303,6 +302,8 @@ __global__ __launch_bounds__(128, TAB ? 2 : 3) void attention_mfma_kernel(AttnAr
 #pragma unroll
   for (int n = 0; n < NT; ++n) {
     const int d = 32 * n + r;
+    const int dv = d < DH ? d : 0;   // V^T row this lane reads: output columns >= DH are dropped below; their lanes re-read row 0 instead of
+                                     // whatever lies behind the plane (never-initialised bytes, possibly NaN / Inf patterns)
     f32x16 o;
 #pragma unroll
     for (int t = 0; t < 16; ++t) o[t] = 0.f;
@@ -310,13 +311,13 @@ __global__ __launch_bounds__(128, TAB ? 2 : 3) void attention_mfma_kernel(AttnAr
     for (int s = 0; s < 2; ++s) {
       bf16x4 h0, h1, l0, l1;
       if (s == 0) {
-        h0 = *(const bf16x4*)(vt_hi + d * VROW + 8 * h);
-        h1 = *(const bf16x4*)(vt_hi + d * VROW + 16 + 8 * h);
-        l0 = *(const bf16x4*)(vt_lo + d * VROW + 8 * h);
-        l1 = *(const bf16x4*)(vt_lo + d * VROW + 16 + 8 * h);
+        h0 = *(const bf16x4*)(vt_hi + dv * VROW + 8 * h);
+        h1 = *(const bf16x4*)(vt_hi + dv * VROW + 16 + 8 * h);
+        l0 = *(const bf16x4*)(vt_lo + dv * VROW + 8 * h);
+        l1 = *(const bf16x4*)(vt_lo + dv * VROW + 16 + 8 * h);
       } else {  // keys 16..19 live in lane half 0; everything else of this k-step is padding
-        h0 = *(const bf16x4*)(vt_hi + d * VROW + 32);
-        l0 = *(const bf16x4*)(vt_lo + d * VROW + 32);
+        h0 = *(const bf16x4*)(vt_hi + dv * VROW + 32);
+        l0 = *(const bf16x4*)(vt_lo + dv * VROW + 32);
         if (h) { h0 = z4; l0 = z4; }
         h1 = z4;
         l1 = z4;

@@ -416,7 +416,7 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs g) {
     const int row0 = panel * FR + wm * 32 + r;           // + m * 16
     float* red = (float*)(smem + 2 * kSlot);             // [pass][wave][m][row] floats
     float* gb = (float*)(smem + 2 * kSlot + 4096);       // [gamma 576 | beta 576 | MID: bias 576]
-    const bool ln = MID || (g.ln_out && g.ln_w);
+    const bool ln = MID || ((g.ln_out || (MODE == 2 && g.ln1_out)) && g.ln_w);
     const float* bias = (const float*)(smem + kB2Off);
     const int tl = w * 64 + lane_e;                      // (the thread id, re-derived: see lane_now)
     if constexpr (MID) {
@@ -506,7 +506,7 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs g) {
         asm volatile("" : "+v"(nmean[m]), "+v"(rstd2[m]));   // (also keeps the compiler from carrying the 144 differences x - mean of
                                                              // pass 2 into the loop below: it did, and spilled them)
         const int row = row0 + m * 16;
-        lrow[m] = (gchar_t*)(g.ln_out + (size_t)(row < g.M ? row : g.M - 1) * kRow1 + mixed_h_offset(col0));
+        lrow[m] = (gchar_t*)((!MID && MODE == 2 && g.ln1_out ? g.ln1_out : g.ln_out) + (size_t)(row < g.M ? row : g.M - 1) * kRow1 + mixed_h_offset(col0));
         asm volatile("" : "+v"(lrow[m]));
       }
 #pragma unroll

@@ -73,6 +73,8 @@ struct FfnArgs {
   const float* ln_w;
   const float* ln_b;
   char* ln_out;
+  char* ln1_out;         // launch_layer_tail only, optional: where the final LayerNorm rows (ln_w / ln_b) go instead of ln_out -- with the
+                         // fused QKV + attention launch the attention output (a) and the next layer's LayerNorm1 rows live in different buffers
   // launch_layer_tail only: the attention out projection in front of the FeedForward -- x1 = resid + a . wo^T + bo stays in
   // registers, lnm_w / lnm_b (LayerNorm2) turn it into the FeedForward's input rows, written to ln_out (= a, in place)
   const char* wo;        // [576, 4*576 B] mixed weight rows, exponent expo
@@ -200,6 +202,21 @@ struct AttnArgs {
 };
 hipError_t launch_attention(const AttnArgs& a, hipStream_t s);
 bool attention_reads_tables(int heads);   // whether launch_attention takes the per-object form for this head count
+
+// QKV projection + attention of a middle layer in one launch (qkv_attn_fused.hip; VETO_MIXED, head widths 72 / 96): a = LayerNorm1 rows
+// (mixed, [rows padded to qkv_attn_rows_padded(n_pair), 4*576 B]), w = Wqkv as mixed weight rows [1728, 4*576 B] with its e4m3 exponent
+// w_exp (device int), o = attention output rows (mixed, row = 19 * pair + token; NOT the buffer a points to: every head's tile reads all
+// of a pair group's rows)
+struct QkvAttnArgs {
+  const char* a;
+  const char* w;
+  const int* w_exp;
+  char* o;
+  int n_pair, heads;
+};
+bool qkv_attn_fused_supports(int heads);
+size_t qkv_attn_rows_padded(int n_pair);
+hipError_t launch_qkv_attn_fused(const QkvAttnArgs& g, hipStream_t s);
 // Folded CLS-only attention of the last layer: x = residual stream [n_pair*19, 576] (LayerNorm1 with ln_w / ln_b is applied
 // inside), u fp32 [n_pair, heads*576] (= LN1(x_0) . Mcat), abar split rows [n_pair, 2*heads*576] (probability-weighted
 // token means per head)

@@ -800,6 +800,9 @@ hipError_t launch_qkv0_combine(const float* sw, const float* ow, const float* st
 // Saturation audit of mixed rows (VETO_MIXED activations, common.h; veto_forward_saturation): counts, over `rows` rows of K elements
 // (row r at base + r * stride bytes), the fp16 values at +-65504 and the e4m3 bytes at +-448 of the value plane (Y) and of the
 // residual plane (X).  A thread takes 16 bytes at a time; counters = {elements, fp16, value plane, residual plane}.
+// The counts are UPPER BOUNDS of the clamped elements: an encoding at the clamp also holds the values that merely round to it
+// (|a| in [432, 464) for e4m3, the last fp16 binade's top), and the NaN / Inf encodings (fp16 exponent all ones, e4m3 0x7f) are
+// counted with them -- a NaN operand is the case that actually breaks a result and must not read as "no saturation".
 __global__ __launch_bounds__(256) void count_saturation_kernel(const char* base, long stride, int rows, int K, unsigned long long* counters) {
   const int per_row = K / 4;                      // 16-byte pieces of a row (4 K bytes)
   const long total = (long)rows * per_row;
@@ -810,15 +813,15 @@ __global__ __launch_bounds__(256) void count_saturation_kernel(const char* base,
     if ((c & 15) < 8) {                           // the fp16 half of a 256-byte block
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        nf += (v[e] & 0x7fffu) == 0x7bffu;
-        nf += ((v[e] >> 16) & 0x7fffu) == 0x7bffu;
+        nf += (v[e] & 0x7fffu) >= 0x7bffu;
+        nf += ((v[e] >> 16) & 0x7fffu) >= 0x7bffu;
       }
     } else {                                      // groups of 8 bytes: 4 x X (residual), 4 x Y (value)
 #pragma unroll
       for (int e = 0; e < 4; ++e)
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
-          const unsigned hit = ((v[e] >> (8 * b)) & 0x7fu) == 0x7eu;
+          const unsigned hit = ((v[e] >> (8 * b)) & 0x7fu) >= 0x7eu;
           if (e & 1) nv += hit; else nr += hit;
         }
     }

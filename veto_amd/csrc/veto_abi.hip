@@ -96,7 +96,18 @@ struct veto_handle_s {
   // generation of the derived weight operands (bumped by every finalize_weights) and, per training workspace, the generation its
   // saved activations were computed with: veto_backward refuses a workspace whose forward saw other weights
   uint64_t weight_gen = 0;
+  // (a handful of workspaces at most: a training loop re-uses one; the table is cleared by every weight upload and bounded besides)
+  static constexpr size_t kMaxTrainWorkspaces = 8;
   std::map<const void*, uint64_t> train_gen;
+  void stamp_train_workspace(const void* ws) {
+    if (train_gen.size() >= kMaxTrainWorkspaces && !train_gen.count(ws)) {   // evict the entry of the oldest generation
+      auto old = train_gen.begin();
+      for (auto it = train_gen.begin(); it != train_gen.end(); ++it)
+        if (it->second < old->second) old = it;
+      train_gen.erase(old);
+    }
+    train_gen[ws] = weight_gen;
+  }
   std::vector<LayerW> layers;
   SplitW patch_w = nullptr;
   // last layer, folded CLS attention (attention.hip): Mcat [heads*576, 2*576], Ncat [576, 2*heads*576], and their fp32 staging
@@ -114,10 +125,11 @@ struct veto_handle_s {
   float* loc_wt = nullptr;
   float* cls_wt = nullptr;
   float* head_wt = nullptr;
-  // veto_forward_saturation: device counters [layers][VETO_SAT_SITES][4]; `sat` is non-null only inside that call and makes
-  // veto_forward take the launch-per-stage form of the mixed path (every mixed-row operand exists in memory) and count behind every producer
+  // veto_forward_saturation: device counters [layers][VETO_SAT_SITES][4], allocated by veto_create (VETO_MIXED handles).  The call
+  // hands them to forward_impl as an argument -- no handle state changes, so a concurrent veto_forward on the same handle is unaffected --
+  // and forward_impl then takes the launch-per-stage form of the mixed path (every mixed-row operand exists in memory) and counts
+  // behind every producer
   unsigned long long* sat_buf = nullptr;
-  unsigned long long* sat = nullptr;
   // profiling
   bool prof_on = false;
   std::vector<std::string> prof_names;
@@ -263,7 +275,9 @@ Workspace carve(char* base, int n_obj, int n_pair, int chunk) {
     return ptr;
   };
   const size_t prow = (size_t)gemm_rows_padded(n_obj * 16);
-  const size_t mpad = (size_t)gemm_rows_padded(chunk * kTokens);
+  // (the fused QKV + attention launch reads whole tiles of 16 pairs: the activation rows are padded to those too)
+  const size_t tile_rows = qkv_attn_rows_padded(chunk);
+  const size_t mpad = (size_t)gemm_rows_padded((int)(tile_rows > (size_t)chunk * kTokens ? tile_rows : (size_t)chunk * kTokens));
   const size_t cpad = (size_t)gemm_rows_padded(chunk);
   w.subj = (int32_t*)take((size_t)n_pair * 4);
   w.obj = (int32_t*)take((size_t)n_pair * 4);
@@ -451,6 +465,10 @@ int veto_create(const veto_config_t* cfg, veto_handle_t* out) {
   h->fold_dhp = fold_dhp;
   h->q0_w = (__bf16*)(h->derived + o_q0w);
   h->q0_vec = (float*)(h->derived + o_q0v);
+  if (cfg->precision == VETO_MIXED) {
+    e = hipMalloc((void**)&h->sat_buf, (size_t)L * VETO_SAT_SITES * 4 * sizeof(unsigned long long));
+    if (e != hipSuccess) { (void)hipFree(h->raw); (void)hipFree(h->derived); delete h; return fail(VETO_ERR_HIP, "hipMalloc(saturation counters): %s", hipGetErrorString(e)); }
+  }
   *out = h;
   return VETO_OK;
 }
@@ -495,8 +513,17 @@ size_t veto_workspace_bytes(veto_handle_t h, int32_t n_obj, int32_t n_pair) {
   return carve(nullptr, n_obj, n_pair, chunk).total;
 }
 
+static int forward_impl(veto_handle_t h, void* stream, const veto_inputs_t* in, void* workspace, size_t workspace_bytes, float* out_logits,
+                        const veto_debug_outputs_t* dbg, unsigned long long* sat);
+
 int veto_forward(veto_handle_t h, void* stream, const veto_inputs_t* in, void* workspace,
                  size_t workspace_bytes, float* out_logits, const veto_debug_outputs_t* dbg) {
+  return forward_impl(h, stream, in, workspace, workspace_bytes, out_logits, dbg, nullptr);
+}
+
+// sat != nullptr (veto_forward_saturation): device counters [layers][VETO_SAT_SITES][4]
+static int forward_impl(veto_handle_t h, void* stream, const veto_inputs_t* in, void* workspace, size_t workspace_bytes, float* out_logits,
+                        const veto_debug_outputs_t* dbg, unsigned long long* sat) {
   if (!h || !in || !out_logits) return fail(VETO_ERR_INVALID, "null argument");
   if (in->struct_size != (int32_t)sizeof(veto_inputs_t)) return fail(VETO_ERR_INVALID, "veto_inputs_t size mismatch");
   if (dbg && dbg->struct_size != (int32_t)sizeof(veto_debug_outputs_t)) return fail(VETO_ERR_INVALID, "veto_debug_outputs_t size mismatch");
@@ -575,13 +602,20 @@ int veto_forward(veto_handle_t h, void* stream, const veto_inputs_t* in, void* w
   // the parity tests compare against) splits it into the out projection + LayerNorm2 launch and the FeedForward + LayerNorm1 launch
   // of the same kernel.  VETO_PRECISE / VETO_FAST take the launch-per-Linear GEMMs and LayerNorm launches.
   static const bool tail_off = env_knob_is("VETO_TAIL_FUSED", "0");
-  const bool tail_fused = !tail_off && !h->sat;
-  const bool panel = !h->sat;        // (the saturation audit needs the LayerNorm2 rows and the hidden activation in memory)
+  const bool tail_fused = !tail_off && !sat;
+  const bool panel = !sat;        // (the saturation audit needs the LayerNorm2 rows and the hidden activation in memory)
   auto count_sat = [&](int layer, int site, const void* rows, long stride_bytes, int n_rows, int K) -> hipError_t {
-    if (!h->sat) return hipSuccess;
-    return launch_count_saturation(rows, stride_bytes, n_rows, K, h->sat + ((size_t)layer * VETO_SAT_SITES + site) * 4, s);
+    if (!sat) return hipSuccess;
+    return launch_count_saturation(rows, stride_bytes, n_rows, K, sat + ((size_t)layer * VETO_SAT_SITES + site) * 4, s);
   };
   static const bool qkv_f24_off = env_knob_is("VETO_QKV_F24", "0");
+  // middle layers: QKV projection + attention as ONE launch (qkv_attn_fused.hip): q / k / v never reach memory.  The attention output
+  // then lives in ws.big (every head's tile reads all rows of ws.a), the layer tail takes it from there and writes the next layer's
+  // LayerNorm1 rows back to ws.a.  VETO_QKV_ATTN_FUSED=0 (a knob the parity tests compare against): the two launches.
+  static const bool qa_off = env_knob_is("VETO_QKV_ATTN_FUSED", "0"), qa_force = env_knob_is("VETO_QKV_ATTN_FUSED", "1");
+  // (six heads: a 304 x 288 tile needs 180 accumulator registers and the kernel spills inside its main loop: correct -- the parity tests
+  // run it with VETO_QKV_ATTN_FUSED=1 -- but slower than the two launches, which stay the default there)
+  const bool qa_fused = mixed && mixed_out && tail_fused && !qa_off && qkv_attn_fused_supports(H) && (kDim / H == 72 || qa_force);
   if (qkv0_tables) {
     const int R = n_obj * 16;
     HIP_TRY(launch_centre_split(ws.patch_tab, ws.ptab_split, R, s));
@@ -619,6 +653,7 @@ int veto_forward(veto_handle_t h, void* stream, const veto_inputs_t* in, void* w
       const bool last = (l == L - 1);
       int rc;
       bool qkv_f24 = false;
+      bool attn_in_big = false;      // this layer's attention output is in ws.big (fused QKV + attention launch)
       const bool fold = last && fold_last;
       if (fold) {
         // last layer, folded (attention.hip): u = a_0 . Mcat on the CLS rows, per-pair scores / softmax / weighted token means,
@@ -673,6 +708,13 @@ int veto_forward(veto_handle_t h, void* stream, const veto_inputs_t* in, void* w
                         DropSite(), mixed ? w.exp_m + 0 : nullptr);
           if (rc) return rc;
         }
+      } else if (!last && qa_fused && l > 0) {
+        QkvAttnArgs q{};
+        q.a = (const char*)ws.a; q.w = (const char*)w.qkv_m; q.w_exp = w.exp_m + 0; q.o = ws.big; q.n_pair = np; q.heads = H;
+        ProfScope ps(h, s, "qkv_attn_fused", 2.0 * M * 3.0 * kDim * kDim + 4.0 * np * kTokens * kTokens * kDim,
+                     (double)M * kDim * 8 + 3.0 * kDim * kDim * 4);
+        HIP_TRY(launch_qkv_attn_fused(q, s));
+        attn_in_big = true;
       } else if (!last) {
         const bool mq = mixed && l > 0;   // layer 0's LayerNorm'ed rows come from token assembly (split rows)
         // q / k / v as 3-byte floats between this GEMM and the attention kernel (common.h; VETO_QKV_F24=0: fp32)
@@ -690,7 +732,7 @@ int veto_forward(veto_handle_t h, void* stream, const veto_inputs_t* in, void* w
                       kDim, EPI_F32, (long)kTokens * 2 * kDim, 0);
         if (rc) return rc;
       }
-      if (!fold) {
+      if (!fold && !attn_in_big) {
         AttnArgs a{};
         a.qkv = qkv; a.n_pair = np; a.heads = H; a.cls_only = last ? 1 : 0;
         a.qkv_f24 = qkv_f24 ? 1 : 0;
@@ -716,6 +758,7 @@ int veto_forward(veto_handle_t h, void* stream, const veto_inputs_t* in, void* w
           f.a = (const char*)ws.a; f.wo = (const char*)w.out_m; f.bo = w.out_b; f.expo = w.exp_m + 1; f.lnm_w = w.ln2_w; f.lnm_b = w.ln2_b;
           f.w1 = (const char*)w.fc1_m; f.w2 = (const char*)w.fc2_m; f.b1 = w.fc1_b; f.b2 = w.fc2_b; f.exp1 = w.exp_m + 2; f.exp2 = w.exp_m + 3;
           f.resid = ws.x; f.out = ws.x; f.ldr = kDim; f.ldo = kDim; f.M = M; f.ln_out = (char*)ws.a;
+          if (attn_in_big) { f.a = ws.big; f.ln_out = ws.big; f.ln1_out = (char*)ws.a; }
           if (ffn_ln_next) { f.ln_w = h->layers[l + 1].ln1_w; f.ln_b = h->layers[l + 1].ln1_b; }
           ProfScope ps(h, s, "layer_tail_fused", 2.0 * M * (double)kDim * kDim + 2.0 * 2.0 * M * (double)kDim * 2 * kDim,
                        (double)M * kDim * 16 + 5.0 * kDim * kDim * 4);
@@ -810,11 +853,9 @@ int veto_forward_saturation(veto_handle_t h, void* stream, const veto_inputs_t* 
   if (capacity < n) return fail(VETO_ERR_INVALID, "counts holds %d entries, need layers * VETO_SAT_SITES = %d", capacity, n);
   hipStream_t s = (hipStream_t)stream;
   HIP_TRY(hipSetDevice(h->cfg.device));
-  if (!h->sat_buf) HIP_TRY(hipMalloc((void**)&h->sat_buf, (size_t)n * 4 * sizeof(unsigned long long)));
+  if (!h->sat_buf) return fail(VETO_ERR_INVALID, "no saturation counters (handle not created in VETO_MIXED)");
   HIP_TRY(hipMemsetAsync(h->sat_buf, 0, (size_t)n * 4 * sizeof(unsigned long long), s));
-  h->sat = h->sat_buf;
-  const int rc = veto_forward(h, stream, in, workspace, workspace_bytes, out_logits, nullptr);
-  h->sat = nullptr;
+  const int rc = forward_impl(h, stream, in, workspace, workspace_bytes, out_logits, nullptr, h->sat_buf);
   if (rc != VETO_OK) return rc;
   std::vector<unsigned long long> host((size_t)n * 4);
   HIP_TRY(hipMemcpyAsync(host.data(), h->sat_buf, host.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
@@ -1118,7 +1159,7 @@ int veto_forward_train(veto_handle_t h, void* stream, const veto_inputs_t* in, c
     HIP_TRY(launch_layernorm(xnext, kDim, h->layers[l + 1].ln1_w, h->layers[l + 1].ln1_b, ws.layers[l + 1].a1, M, s));
   }
   HIP_TRY(launch_head(ws.xout, h->head_wt, h->p("rel_out.bias"), out_logits, n_pair, n_out, s, (long)kDim));
-  h->train_gen[workspace] = h->weight_gen;
+  h->stamp_train_workspace(workspace);
   return VETO_OK;
 }
 
@@ -1834,6 +1875,66 @@ int veto_debug_layer_tail(void* stream, const float* a, const float* wo, const f
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
   }
+  return VETO_OK;
+}
+
+// Test / bench hook of the fused QKV + attention launch: a = LayerNorm1 rows fp32 [19 n_pair, 576], wqkv fp32 [1728, 576]; out_rows receives
+// the attention output as mixed rows [19 n_pair, 4*576 B].  mode 1 = qkv_attn_fused.hip, mode 0 = the two launches it replaces (QKV GEMM
+// with 3-byte q / k / v + attention_mfma_kernel).
+size_t veto_debug_qkv_attn_workspace_bytes(int32_t n_pair) {
+  if (n_pair <= 0) return 0;
+  const size_t tile_rows = qkv_attn_rows_padded(n_pair), m = (size_t)n_pair * kTokens;
+  const size_t mp = (size_t)gemm_rows_padded((int)(tile_rows > m ? tile_rows : m));
+  return 2 * align_up(mp * kDim * 4, 256) + align_up(mp * 3 * kDim * 3, 256) + align_up((size_t)3 * kDim * kDim * 4, 256) + 256;
+}
+
+int veto_debug_qkv_attn(void* stream, const float* a, const float* wqkv, int32_t n_pair, int32_t heads, int32_t mode, int32_t reps,
+                        float* ms_per_rep, void* workspace, size_t workspace_bytes, void* out_rows) {
+  if (!a || !wqkv || !workspace || !out_rows) return fail(VETO_ERR_INVALID, "null argument");
+  if (n_pair <= 0 || reps <= 0 || (mode != 0 && mode != 1) || !qkv_attn_fused_supports(heads)) return fail(VETO_ERR_INVALID, "bad n_pair / reps / mode / heads");
+  if (workspace_bytes < veto_debug_qkv_attn_workspace_bytes(n_pair)) return fail(VETO_ERR_WORKSPACE, "workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  const size_t tile_rows = qkv_attn_rows_padded(n_pair), m = (size_t)n_pair * kTokens;
+  const size_t mp = (size_t)gemm_rows_padded((int)(tile_rows > m ? tile_rows : m));
+  char* base = (char*)workspace;
+  __bf16* a_m = (__bf16*)base;
+  char* o_m = base + align_up(mp * kDim * 4, 256);
+  char* qkv = o_m + align_up(mp * kDim * 4, 256);
+  __bf16* w_m = (__bf16*)(qkv + align_up(mp * 3 * kDim * 3, 256));
+  int* exps = (int*)((char*)w_m + align_up((size_t)3 * kDim * kDim * 4, 256));
+  HIP_TRY(hipMemsetAsync(a_m, 0, mp * kDim * 4, s));
+  HIP_TRY(launch_mixed_act_rows(a, a_m, m, kDim, s));
+  HIP_TRY(launch_mixed_weight_rows(wqkv, w_m, (size_t)3 * kDim, kDim, exps, s));
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (ms_per_rep) {
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    HIP_TRY(hipEventRecord(e0, s));
+  }
+  for (int r = 0; r < reps; ++r) {
+    if (mode == 1) {
+      QkvAttnArgs q{};
+      q.a = (const char*)a_m; q.w = (const char*)w_m; q.w_exp = exps; q.o = o_m; q.n_pair = n_pair; q.heads = heads;
+      HIP_TRY(launch_qkv_attn_fused(q, s));
+    } else {
+      GemmArgs g{};
+      g.fmt = FMT_MIXED; g.w_exp = exps; g.a = a_m; g.w = w_m; g.c = (float*)qkv; g.M = (int)m; g.N = 3 * kDim; g.K = kDim; g.ldc = 3 * kDim;
+      HIP_TRY(launch_gemm_split(g, EPI_F24, 0, s));
+      AttnArgs t{};
+      t.qkv = (const float*)qkv; t.o = (__bf16*)o_m; t.n_pair = n_pair; t.heads = heads; t.cls_only = 0; t.qkv_f24 = 1; t.o_fmt = FMT_MIXED;
+      HIP_TRY(launch_attention(t, s));
+    }
+  }
+  if (ms_per_rep) {
+    HIP_TRY(hipEventRecord(e1, s));
+    HIP_TRY(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    *ms_per_rep = ms / reps;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+  }
+  HIP_TRY(hipMemcpyAsync(out_rows, o_m, m * kDim * 4, hipMemcpyDeviceToDevice, s));
   return VETO_OK;
 }
 

@@ -18,7 +18,7 @@ EXPORTS = [
     "veto_last_error", "veto_version", "veto_create", "veto_destroy", "veto_num_weights",
     "veto_weight_info", "veto_load_weights", "veto_workspace_bytes", "veto_forward", "veto_forward_saturation",
     "veto_enumerate_pairs", "veto_profile_enable", "veto_profile_collect", "veto_profile_entry",
-    "veto_profile_reset", "veto_debug_gemm", "veto_debug_gemm_workspace_bytes", "veto_debug_gemm_forms", "veto_debug_ffn", "veto_debug_ffn_workspace_bytes", "veto_debug_outproj", "veto_debug_outproj_workspace_bytes", "veto_debug_layer_tail", "veto_debug_layer_tail_workspace_bytes",
+    "veto_profile_reset", "veto_debug_gemm", "veto_debug_gemm_workspace_bytes", "veto_debug_gemm_forms", "veto_debug_ffn", "veto_debug_ffn_workspace_bytes", "veto_debug_outproj", "veto_debug_outproj_workspace_bytes", "veto_debug_layer_tail", "veto_debug_layer_tail_workspace_bytes", "veto_debug_qkv_attn", "veto_debug_qkv_attn_workspace_bytes",
     "veto_postprocess", "veto_postprocess_workspace_bytes", "veto_postprocess_meet", "veto_postprocess_vote",
     "veto_train_workspace_bytes", "veto_grad_floats", "veto_weight_offset", "veto_forward_train", "veto_backward",
     "veto_debug_attention_backward", "veto_debug_layernorm_backward", "veto_debug_layernorm_backward_workspace_bytes",
@@ -161,6 +161,10 @@ def load_library():
                                                                          c_void_p, c_void_p, c_void_p]
     lib.veto_debug_layer_tail_workspace_bytes.argtypes = [c_int32]
     lib.veto_debug_layer_tail_workspace_bytes.restype = c_size_t
+    lib.veto_debug_qkv_attn.argtypes = [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, POINTER(ctypes.c_float), c_void_p,
+                                        c_size_t, c_void_p]
+    lib.veto_debug_qkv_attn_workspace_bytes.argtypes = [c_int32]
+    lib.veto_debug_qkv_attn_workspace_bytes.restype = c_size_t
     lib.veto_debug_ffn_workspace_bytes.argtypes = [c_int32]
     lib.veto_debug_ffn_workspace_bytes.restype = c_size_t
     lib.veto_postprocess_workspace_bytes.argtypes = [c_int32, c_int32]

@@ -353,7 +353,8 @@ class _NativeForward:
             dbg.subj_inds, dbg.obj_inds = extras["subj_inds"].data_ptr(), extras["obj_inds"].data_ptr()
             dbg.tokens, dbg.cls = extras["tokens"].data_ptr(), extras["cls"].data_ptr()
         stream = torch.cuda.current_stream(device).cuda_stream
-        if self._count_saturation and bn_batch_stats is None and not debug:
+        # (the audit is of the VETO_MIXED operands: the ABI refuses it on a handle that computes in another mode)
+        if self._count_saturation and self._precision == native.VETO_MIXED and bn_batch_stats is None and not debug:
             self.last_saturation = eng.forward_saturation(stream, inp, self._workspace.data_ptr(), self._workspace.numel(), out.data_ptr())
         else:
             eng.forward(stream, inp, self._workspace.data_ptr(), self._workspace.numel(), out.data_ptr(), dbg)

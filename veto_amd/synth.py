@@ -268,3 +268,38 @@ def synthetic_relation_targets(seed=41, num_objs=(6, 40, 3, 1), num_rel_cls=51):
         np.fill_diagonal(rel, 0)
         out.append((boxes, rel.astype(np.int64)))
     return out
+
+
+# ---- ROI feature extraction fixtures ------------------------------------------------
+def roi_test_boxes(rng, n, W, H):
+    """n xyxy boxes on a W x H image: log-uniform sizes, some starting outside, and four fixed corner cases
+    (the whole image, mostly outside, sub-pixel, malformed x2 < x1)."""
+    xy = rng.uniform(-20, [W * 0.9, H * 0.9], size=(n, 2))
+    wh = np.exp(rng.uniform(np.log(2), np.log(max(W, H) * 1.2), size=(n, 2)))
+    b = np.concatenate([xy, xy + wh], 1).astype(np.float32)
+    b[0] = [0, 0, W - 1, H - 1]
+    b[1] = [W - 3, H - 3, W + 40, H + 40]
+    b[2] = [30.2, 40.7, 30.3, 40.8]
+    b[3] = [50, 60, 40, 30]
+    return b
+
+
+ROI_SINGLE_CASES = [(8, 2), (7, 2), (8, 1), (4, 4), (6, 0)]   # (pooled, sampling_ratio); 0 = adaptive grid (oracle only)
+
+
+def synthetic_roi_single(pooled, ratio, channels=37):
+    """One feature map [2, channels, 50, 84] at scale 1/16 and 23 ROI rows (image index, x1, y1, x2, y2)."""
+    rng = np.random.RandomState(pooled * 10 + ratio)
+    feat = rng.randn(2, channels, 50, 84).astype(np.float32)
+    boxes = roi_test_boxes(rng, 23, 84 * 16, 50 * 16)
+    rois = np.concatenate([rng.randint(0, 2, size=(23, 1)).astype(np.float32), boxes], 1)
+    return feat, rois
+
+
+def synthetic_roi_pyramid(channels=256, num_objs=(9, 17, 5), W=1024, H=640, seed=11):
+    """Four FPN levels (strides 4..32) + a stride-16 depth map for 3 images, and per-image xyxy boxes that cover all four levels."""
+    rng = np.random.RandomState(seed)
+    feats = [rng.randn(len(num_objs), channels, H >> (2 + l), W >> (2 + l)).astype(np.float32) for l in range(4)]
+    depth = rng.randn(len(num_objs), channels, H >> 4, W >> 4).astype(np.float32)
+    boxes = [roi_test_boxes(rng, n, W, H) for n in num_objs]
+    return feats, depth, boxes, (W, H)
