@@ -612,10 +612,8 @@ static int forward_impl(veto_handle_t h, void* stream, const veto_inputs_t* in, 
   // middle layers: QKV projection + attention as ONE launch (qkv_attn_fused.hip): q / k / v never reach memory.  The attention output
   // then lives in ws.big (every head's tile reads all rows of ws.a), the layer tail takes it from there and writes the next layer's
   // LayerNorm1 rows back to ws.a.  VETO_QKV_ATTN_FUSED=0 (a knob the parity tests compare against): the two launches.
-  static const bool qa_off = env_knob_is("VETO_QKV_ATTN_FUSED", "0"), qa_force = env_knob_is("VETO_QKV_ATTN_FUSED", "1");
-  // (six heads: a 304 x 288 tile needs 180 accumulator registers and the kernel spills inside its main loop: correct -- the parity tests
-  // run it with VETO_QKV_ATTN_FUSED=1 -- but slower than the two launches, which stay the default there)
-  const bool qa_fused = mixed && mixed_out && tail_fused && !qa_off && qkv_attn_fused_supports(H) && (kDim / H == 72 || qa_force);
+  static const bool qa_off = env_knob_is("VETO_QKV_ATTN_FUSED", "0");
+  const bool qa_fused = mixed && mixed_out && tail_fused && !qa_off && qkv_attn_fused_supports(H);
   if (qkv0_tables) {
     const int R = n_obj * 16;
     HIP_TRY(launch_centre_split(ws.patch_tab, ws.ptab_split, R, s));
