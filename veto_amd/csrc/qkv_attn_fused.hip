@@ -50,9 +50,10 @@
 #endif
 // the wait states in front of every inline-asm MFMA (see mma() below); -DQA_MMA_NOP='""' builds the kernel WITHOUT them: the negative
 // control of tests/test_ffn_asm.py
-// 0: no cooperative L2 prefetch (A/B)
-#ifndef QA_L2_PREFETCH
-#define QA_L2_PREFETCH 1
+// activation pieces the lower half issues beside the weight pieces (three weight images; measured: 4 / 10 / 16 within 1 % of one another,
+// 0 -- the upper half issues every activation piece -- 6 % slower)
+#ifndef QA_ASPLIT
+#define QA_ASPLIT 10
 #endif
 #ifdef QA_NO_PADS
 #define QA_MMA_NOP ""
@@ -114,11 +115,6 @@ struct Geo {
 __device__ __forceinline__ void glds16(const char* base, unsigned voff, unsigned lds_addr) {
   if (QA_ABLATE & 1) return;
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_addr), "v"(voff), "s"(base) : "memory");
-}
-// L2 prefetch: 64 lanes touch 64 cache lines (one dword each, LDS-DMA'd into a 256-byte dump area that nothing reads)
-__device__ __forceinline__ void glds4(const char* base, unsigned voff, unsigned lds_addr) {
-  if (QA_ABLATE & 1) return;
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 4\n\tglobal_load_lds_dword %1, %2" ::"s"(lds_addr), "v"(voff), "s"(base) : "memory");
 }
 __device__ __forceinline__ void wg_barrier() {
   asm volatile("" ::: "memory");
@@ -238,11 +234,7 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_fused_kernel(QkvAttnArgs g) {
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
   const int wl = w & 3;
   const bool lower = w < 4;
-#ifdef QA_ASPLIT
-  constexpr int kASplit = NWB == 3 ? QA_ASPLIT : 0;                                // (A/B knob of tools/variants.sh; even)
-#else
-  constexpr int kASplit = NWB == 3 ? (APIECES - G::WPIECES) / 2 / 2 * 2 : 0;     // (even: a piece's swizzle parity is its index's)
-#endif
+  constexpr int kASplit = NWB == 3 ? QA_ASPLIT : 0;      // (even: a piece's swizzle parity is its index's)
   const int a_begin = lower ? 0 : kASplit, a_end = lower ? kASplit : APIECES;    // this wave's activation pieces: a_begin + wl + 4 k < a_end
   const int rr = lane >> 3;
   const int r16 = ((wl & 1) << 3) + rr;                                  // row inside its 16-row block (wl + 4 i keeps the parity)
@@ -255,14 +247,12 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_fused_kernel(QkvAttnArgs g) {
   struct TileSrc {
     const char* a;      // first activation row of the tile's pair group
     const char* w;      // first weight row of the tile's head: q rows; k rows 576 rows on, v rows 1152 rows on
-    int head;
   };
   auto tile_src = [&](int tile) {
     TileSrc t;
     const int group = tile / H, head = tile - group * H;
     t.a = g.a + (size_t)group * ((size_t)TM * kRowB);
     t.w = g.w + (size_t)(head * DH) * kRowB;
-    t.head = head;
     return t;
   };
   // this wave's share of stage s of a tile: activation rows into image `buf` (0 / 1) / weight rows into image `buf` (0 .. NWB - 1)
@@ -281,39 +271,6 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_fused_kernel(QkvAttnArgs g) {
         const int mat = c / G::PM, cm = c - mat * G::PM;
         glds16(t.w + (size_t)(mat * kDim + 8 * cm) * kRowB + s * 128, voff_w, lds0 + (buf < 2 ? kABytes + buf * G::kPair : 2 * G::kPair) + c * 1024);
       }
-    }
-  };
-
-  // Cooperative L2 prefetch.  The eight workgroups that share a pair group's activation rows (its eight heads) and the per_xcd / H
-  // workgroups that share a head's weight rows run in step on one XCD, so all of them ask for a line within the same ~100 ns: one
-  // misses, the others wait on that miss, and EVERY piece comes back with Infinity-Cache / HBM latency -- at the ~250 requests a CU
-  // keeps in flight that is ~40 GB/s per CU whatever the kernel does (measured: 3 750 cycles per stage under every DMA schedule).
-  // Three stages ahead, each of them touches ITS share of those lines (an eighth of the activation rows: wave 0, a quarter of the
-  // weight rows: wave 1; one instruction each): the pieces issued two stages later are plain L2 hits.  Speed only: results do not
-  // depend on it (VETO_QA_PREFETCH=0 in the launcher's grid... compile-time QA_L2_PREFETCH=0 builds the kernel without it).
-  const int sharers_w = per_xcd / H;                    // workgroups of this XCD round with the same head (0: grid too small)
-  const bool pf_on = QA_L2_PREFETCH && sharers_w > 0 && per_xcd % H == 0 && w < 2;
-  constexpr int kPfA = TM / 8;                          // activation lines per workgroup (H == 8 sharers; fewer heads: the first ones)
-  const int pf_wlines = sharers_w > 0 ? (G::NCOL + sharers_w - 1) / sharers_w : 0;
-  unsigned pf_voff = 0;                                 // wave 1: its weight lines (fixed per workgroup); wave 0: per tile (head)
-  bool pf_lane = false;
-  if (pf_on && w == 1) {
-    const int wr = ((b >> 3) / H) * pf_wlines + lane;   // row of the head's q | k | v slice
-    pf_lane = lane < pf_wlines && wr < G::NCOL;
-    const int wr_c = pf_lane ? wr : 0, mat = wr_c / DH;
-    pf_voff = (unsigned)((mat * kDim + (wr_c - mat * DH)) * kRowB);
-  }
-  // (dump area: the rows of the first weight image behind its last loaded row where the image has such rows -- never under an attention
-  // region --, else the spare bytes behind the images, which the regions do cover: every prefetch is waited for in front of the attention)
-  constexpr int kDump = G::WROWS * 128 - G::WPIECES * 1024 >= 512 ? G::w_buf(0) + G::WPIECES * 1024 : 2 * G::kPair + (NWB == 3 ? G::kWBytes : 0);
-  static_assert(kDump + 512 <= kLdsTotal, "prefetch dump area");
-  const unsigned pf_dump = lds0 + kDump + (w & 1) * 256;
-  auto prefetch = [&](const TileSrc& t, int head, int s) {
-    if (w == 0) {
-      const int row = head * kPfA + lane;
-      if (lane < kPfA && row < TM) glds4(t.a + s * 128, (unsigned)(row * kRowB), pf_dump);
-    } else if (pf_lane) {
-      glds4(t.w + s * 128, pf_voff, pf_dump);
     }
   };
 
@@ -340,11 +297,6 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_fused_kernel(QkvAttnArgs g) {
   // DMA instructions of this wave that may still be in flight at the top of the next interval: its pieces of a stage BEHIND the one that
   // interval multiplies (with two weight images the weight pieces are for the very next stage: none of them; they are issued first)
   int younger = n_acts + (NWB == 3 ? n_weights : 0);
-  const int n_pf = pf_on ? 1 : 0;                // (a wave's prefetch instruction is its youngest of the interval: it may stay in flight)
-  if (pf_on) {
-    prefetch(src_next, src_next.head, 2);
-    younger += 1;
-  }
   bool stage0_landed = false;    // (behind the attention phase: the stage was waited for in front of it)
   int wb = 0;                    // weight image of the current stage: s % NWB
 
@@ -425,11 +377,6 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_fused_kernel(QkvAttnArgs g) {
         }
         if (do_w) issue_weights(tw, st_w, wb2);
         if (do_a) issue_acts(ta, st_a, s & 1);
-        if (pf_on) {      // (wave-uniform; behind this wave's pieces: the youngest request of the interval)
-          const int sp = s + 3;
-          if (sp < kStages) prefetch(src, src.head, sp);
-          else if (has_next) prefetch(src_next, src_next.head, sp - kStages);
-        }
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -451,7 +398,7 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_fused_kernel(QkvAttnArgs g) {
         }
       }
       if (!lower && do_a) issue_acts(ta, st_a, s & 1);
-      younger = (do_a ? n_acts : 0) + (NWB == 3 && do_w ? n_weights : 0) + ((s + 3 < kStages || has_next) ? n_pf : 0);
+      younger = (do_a ? n_acts : 0) + (NWB == 3 && do_w ? n_weights : 0);
       wb = wb + 1 == NWB ? 0 : wb + 1;
       QST(t2);
       QACC(s_wait, t3, t0); QACC(s_bar1, t1, t3); QACC(s_main, t2, t1);
