@@ -371,7 +371,51 @@ def extra_lines(args, dev, batch, sd):
         out["precision_" + prec] = {"dtype": DTYPE_OF[prec], "pairs_per_s": n_pairs / dt, "ms_per_step": dt * 1e3,
                                     "logit_max_abs_err_image0": float((lg[:ppi] - ref).abs().max())}
         del m
+    out["train"] = train_line(args, dev, batch, sd)
     return out
+
+
+def train_line(args, dev, batch, sd, steps=3):
+    """One training step of the same architecture on the same batch (BASELINE configs 3-5 are training configs): veto_forward_train +
+    veto_ce_loss + veto_backward through autograd (every layer on all 19 tokens, activations kept, 3-term split-bf16 operands -- none of
+    the inference path's fused kernels), SGD step outside the timed forward / backward spans.  A driver-observed number, no tuning
+    target of this round.  Reference: roi_relation_predictors.py:4129-4136, tools/relation_train_net.py:372-380."""
+    from veto_amd import synth, testing
+    from veto_amd.pairs import prepare_test_pairs
+    torch.cuda.empty_cache()
+    model = testing.make_predictor(testing.make_config(args.layers, args.heads), sd, dev).train()
+    props = testing.make_proposals(batch, "predcls", dev)
+    pairs = prepare_test_pairs(dev, props)
+    n = sum(int(p.shape[0]) for p in pairs)
+    labels = torch.from_numpy(synth.integers(5, "bench.labels", (n,), 0, 51)).to(dev)
+    rel_labels = list(labels.split([int(p.shape[0]) for p in pairs]))
+    kw = dict(roi_features=torch.from_numpy(batch["roi_features"]).to(dev), roi_depth_features=torch.from_numpy(batch["roi_depth_features"]).to(dev))
+    opt = torch.optim.SGD(model.parameters(), lr=1e-4)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    t_f = t_b = wall = 0.0
+    loss = None
+    for i in range(steps + 1):            # one warm-up step (allocates the cached 36 GB activation workspace)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        opt.zero_grad(set_to_none=True)
+        ev[0].record()
+        loss = model(props, pairs, rel_labels, None, **kw)[2]["rel_loss"]
+        ev[1].record()
+        loss.backward()
+        ev[2].record()
+        opt.step()
+        torch.cuda.synchronize(dev)
+        if i > 0:
+            wall += time.perf_counter() - t0
+            t_f += ev[0].elapsed_time(ev[1])
+            t_b += ev[1].elapsed_time(ev[2])
+    peak = torch.cuda.max_memory_allocated(dev) / 2 ** 30
+    del model, opt
+    torch.cuda.empty_cache()
+    return {"workload": "one training step (forward + weighted-CE loss + backward + SGD) of the headline architecture on the same 12 x %d batch, "
+                        "dropout at the reference's rates" % args.objs, "steps": steps, "ms_per_step": wall / steps * 1e3,
+            "pairs_per_s": n / (wall / steps), "forward_ms": t_f / steps, "backward_ms": t_b / steps, "loss": float(loss.detach()),
+            "peak_memory_gb": round(peak, 1), "dtype": "bf16x3 (split-bf16 MFMA, fp32 accumulate)"}
 
 
 def usable_cores():

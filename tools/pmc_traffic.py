@@ -18,7 +18,10 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # launches of gemm_split_ps_kernel inside one forward step of the L4 / mixed workload, in order (round 3: the FeedForward
 # Linears of the three full layers are the ffn_fused_kernel launches, labelled by kernel name below)
-GEMM_ORDER_L4 = ["gemm_patch", "gemm_qkv0_tab", "gemm_qkv0_tab", "gemm_qkv0_lc", "gemm_qkv0_lc", "gemm_qkv", "gemm_qkv",
+GEMM_ORDER_L4_TWO_LAUNCH = ["gemm_patch", "gemm_qkv0_tab", "gemm_qkv0_tab", "gemm_qkv0_lc", "gemm_qkv0_lc", "gemm_qkv", "gemm_qkv",
+                            "gemm_q_cls", "gemm_u_cls", "gemm_v_cls", "gemm_out_cls", "gemm_fc1_cls", "gemm_fc2_cls"]
+# round 5: the QKV projections of the middle layers run inside qkv_attn_fused_kernel (labelled by kernel name below)
+GEMM_ORDER_L4 = ["gemm_patch", "gemm_qkv0_tab", "gemm_qkv0_tab", "gemm_qkv0_lc", "gemm_qkv0_lc",
                  "gemm_q_cls", "gemm_u_cls", "gemm_v_cls", "gemm_out_cls", "gemm_fc1_cls", "gemm_fc2_cls"]
 
 
@@ -50,15 +53,18 @@ def per_label(steps):
     acc = collections.defaultdict(list)
     for s in steps:
         gi = 0
+        order = GEMM_ORDER_L4 if any("qkv_attn_fused_kernel" in name for name, _, _ in s) else GEMM_ORDER_L4_TWO_LAUNCH
         for name, v, us in s:
             if "gemm_split_ps_kernel" in name:
-                label = GEMM_ORDER_L4[gi] if gi < len(GEMM_ORDER_L4) else "gemm_%d" % gi
+                label = order[gi] if gi < len(order) else "gemm_%d" % gi
                 gi += 1
             else:
                 label = name.replace("void ", "").replace("veto::", "").replace("(anonymous namespace)::", "")
                 label = re.split(r"[<(]", label)[0].strip() or name[:40]
                 if label == "ffn_fused_kernel":  # the names bench.py's per-kernel timers use: MODE 0 FeedForward, MODE 1 out projection
                     label = {"0": "ffn_fused", "1": "out_ln_fused", "2": "layer_tail_fused"}[re.search(r"ffn_fused_kernel<(\d)>", name).group(1)]
+                if label == "qkv_attn_fused_kernel":
+                    label = "qkv_attn_fused"
                 if "attention_mfma_kernel" in name:          # the table form of layer 0 is its own instantiation
                     label += "_tab" if re.search(r"attention_mfma_kernel<\d+, *(true|1)", name) else ""
             acc[label].append((v, us))
@@ -83,14 +89,15 @@ def main():
         if k in busy and gui.get(k, (0,))[0] > 0:
             # SQ_VALU_MFMA_BUSY_CYCLES sums the 1024 SIMDs; GRBM_GUI_ACTIVE sums the 8 XCDs' clocks over the dispatch
             kernels[k]["mfma_busy"] = round(busy[k][0] / 1024.0 / (gui[k][0] / 8.0), 4)
-    att = {k: v for k, v in kernels.items() if "attention" in k}
+    att = {k: v for k, v in kernels.items() if "attention" in k or "attn" in k}
     doc = {"_comment": "per-launch HBM bytes (2 * FETCH_SIZE + WRITE_SIZE, KiB -> bytes; gfx950 FETCH correction of the micro-architecture "
                        "guide) and MFMA-busy fraction (SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs / kernel cycles) from the rocprofv3 --pmc passes "
                        "of profile tag %s (profiles/%s_pmc_*.txt); written by tools/pmc_traffic.py" % (tag, tag),
            "tag": tag, "workload": workload, "kernels": kernels,
            "attention": {"note": "MFMA utilisation of the attention contractions (north_star): busy fraction of the attention kernels, and of "
                                  "the dominant GEMM for comparison", "kernels": {k: v.get("mfma_busy") for k, v in att.items()},
-                         "gemm_qkv_mfma_busy": kernels.get("gemm_qkv", {}).get("mfma_busy")}}
+                         "gemm_qkv_mfma_busy": kernels.get("gemm_qkv", {}).get("mfma_busy"),
+                         "layer_tail_mfma_busy": kernels.get("layer_tail_fused", {}).get("mfma_busy")}}
     json.dump(doc, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
     for k, v in kernels.items():
         print("%-34s x%d  hbm %8.1f MB  mfma_busy %s" % (k, v["launches_per_step"], v["hbm_bytes_per_launch"] / 1e6, v.get("mfma_busy")))

@@ -15,14 +15,17 @@ ORDER_L4_UNFUSED = ["gemm_patch", "gemm_qkv0_tab (S)", "gemm_qkv0_tab (O)", "gem
 ORDER_L4_PRODUCTS = ["gemm_patch", "gemm_qkv0_tab (S)", "gemm_qkv0_tab (O)", "gemm_qkv0_lc (t17)", "gemm_qkv0_lc (t18)", "gemm_qkv", "gemm_qkv",
                      "gemm_u_cls", "gemm_out_cls", "gemm_fc1_cls", "gemm_fc2_cls"]
 # ... and the folded last layer runs its two products as four block-structured GEMMs (VETO_FOLD_BLOCKS=0: the list above)
-ORDER_L4 = ["gemm_patch", "gemm_qkv0_tab (S)", "gemm_qkv0_tab (O)", "gemm_qkv0_lc (t17)", "gemm_qkv0_lc (t18)", "gemm_qkv", "gemm_qkv",
+ORDER_L4_TWO_LAUNCH = ["gemm_patch", "gemm_qkv0_tab (S)", "gemm_qkv0_tab (O)", "gemm_qkv0_lc (t17)", "gemm_qkv0_lc (t18)", "gemm_qkv", "gemm_qkv",
+                       "gemm_q_cls", "gemm_u_cls", "gemm_v_cls", "gemm_out_cls", "gemm_fc1_cls", "gemm_fc2_cls"]
+# round 5: the QKV projections of the middle layers run inside qkv_attn_fused_kernel (listed separately below; VETO_QKV_ATTN_FUSED=0: the list above)
+ORDER_L4 = ["gemm_patch", "gemm_qkv0_tab (S)", "gemm_qkv0_tab (O)", "gemm_qkv0_lc (t17)", "gemm_qkv0_lc (t18)",
             "gemm_q_cls", "gemm_u_cls", "gemm_v_cls", "gemm_out_cls", "gemm_fc1_cls", "gemm_fc2_cls"]
 
 
 def main(path):
     rows = list(csv.DictReader(open(path)))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    steps, cur, ffn, outp, tail = [], None, [], [], []
+    steps, cur, ffn, outp, tail, qa = [], None, [], [], [], []
     for r in rows:
         name = r["Kernel_Name"]
         if "pair_indices_kernel" in name:
@@ -31,6 +34,8 @@ def main(path):
         elif cur is not None and "gemm_split_ps_kernel" in name:
             inst = re.search(r"gemm_split_ps_kernel<([^>]*)>", name).group(1)
             cur.append((inst, (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3))
+        elif cur is not None and "qkv_attn_fused_kernel" in name:
+            qa.append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
         elif cur is not None and "ffn_fused_kernel<0>" in name:
             ffn.append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
         elif cur is not None and "ffn_fused_kernel<1>" in name:
@@ -43,8 +48,10 @@ def main(path):
     for s in steps:
         for i, (inst, us) in enumerate(s):
             acc[(i, inst)].append(us)
-    order = next((o for o in (ORDER_L4, ORDER_L4_PRODUCTS, ORDER_L4_UNFUSED) if n == len(o)), None)
+    order = next((o for o in (ORDER_L4, ORDER_L4_TWO_LAUNCH, ORDER_L4_PRODUCTS, ORDER_L4_UNFUSED) if n == len(o) and (o is not ORDER_L4_PRODUCTS or not qa)), None)
     print("%d forward steps, %d GEMM launches each (4-layer order: %s)" % (len(steps), n, "yes" if order else "n/a"))
+    if qa:
+        print("  qkv_attn_fused_kernel (QKV projection + attention of a middle layer): %d launches, mean %8.1f us  (min %8.1f, max %8.1f)" % (len(qa), sum(qa) / len(qa), min(qa), max(qa)))
     if ffn:
         print("  ffn_fused_kernel<0> (FeedForward): %d launches, mean %8.1f us  (min %8.1f, max %8.1f)" % (len(ffn), sum(ffn) / len(ffn), min(ffn), max(ffn)))
     if tail:
