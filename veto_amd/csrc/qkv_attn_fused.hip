@@ -137,7 +137,8 @@ __device__ __forceinline__ uint32_t pk_bf16(float a, float b) {
 __device__ __forceinline__ void split4(const f32x4& v, u32x2& hi, u32x2& lo) {
 #pragma unroll
   for (int p = 0; p < 2; ++p) {
-    const uint32_t h = pk_bf16(v[2 * p], v[2 * p + 1]);
+    uint32_t h = pk_bf16(v[2 * p], v[2 * p + 1]);
+    asm("" : "+v"(h));      // (opaque: the compiler otherwise converts the first value a second time, alone, to get its high half)
     const float l0 = v[2 * p] - __uint_as_float(h << 16), l1 = v[2 * p + 1] - __uint_as_float(h & 0xffff0000u);
     hi[p] = h;
     lo[p] = pk_bf16(l0, l1);
@@ -540,7 +541,8 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_fused_kernel(QkvAttnArgs g) {
 #pragma unroll
         for (int t = 0; t < 16; t += 2) {
           const float a0 = p[t] * inv, a1 = p[t + 1] * inv;
-          const uint32_t h2 = pk_bf16(a0, a1);
+          uint32_t h2 = pk_bf16(a0, a1);
+          asm("" : "+v"(h2));
           const uint32_t l2 = pk_bf16(a0 - __uint_as_float(h2 << 16), a1 - __uint_as_float(h2 & 0xffff0000u));
           ((uint32_t*)&ph[t >> 3])[(t & 7) >> 1] = h2;
           ((uint32_t*)&pl[t >> 3])[(t & 7) >> 1] = l2;
@@ -586,11 +588,15 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_fused_kernel(QkvAttnArgs g) {
             o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ph[s], vl, o, 0, 0, 0);
             o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ph[s], vh, o, 0, 0, 0);
           }
-          if (d < DH) {
+          // register t holds query (t & 3) + 8 (t >> 2) + 4 h: t < 8 always a token, t = 8..10 only in the lower half wave (16..18), t >= 11 never
+          // (two predicated regions per tile instead of one per register: every `if` is an exec-mask save / restore and a branch)
+          if (32 * n + 32 <= DH || d < DH) {
+            float* op = o_lds + 4 * hh * DH + d;
 #pragma unroll
-            for (int t = 0; t < 16; ++t) {
-              const int i = (t & 3) + 8 * (t >> 2) + 4 * hh;
-              if (i < kTokens) o_lds[i * DH + d] = o[t];
+            for (int t = 0; t < 8; ++t) op[((t & 3) + 8 * (t >> 2)) * DH] = o[t];
+            if (!hh) {
+#pragma unroll
+              for (int t = 8; t < 11; ++t) op[((t & 3) + 8 * (t >> 2)) * DH] = o[t];
             }
           }
         }
