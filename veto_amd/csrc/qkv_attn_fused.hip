@@ -44,7 +44,7 @@
 #include <cstdlib>
 
 // timing ablations (tools/variants.sh; results are WRONG with any of them set): 1 = no DMA, 2 = no attention phase (nothing is stored),
-// 4 = no MFMAs in the main loop, 8 = no output stores
+// 4 = no MFMAs in the main loop, 8 = no output stores, 16 = no fragment reads in the main loop (the MFMAs run on whatever the registers hold)
 #ifndef QA_ABLATE
 #define QA_ABLATE 0
 #endif
@@ -358,6 +358,12 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_fused_kernel(QkvAttnArgs g) {
       const int st_a = sa2 < kStages ? sa2 : 0, st_w = sw2 < kStages ? sw2 : 0;
       const int wb2 = NWB == 3 ? (wb == 0 ? 2 : wb - 1) : (wb ^ 1);      // (s + 2) % 3 / (s + 1) % 2
       i32x4 fa0[MB], fa1[MB], fw0[2], fw1[2];
+      if (QA_ABLATE & 16) {
+#pragma unroll
+        for (int m = 0; m < MB; ++m) { fa0[m] = fa1[m] = i32x4{0, 0, 0, 0}; asm volatile("" : "+v"(fa0[m]), "+v"(fa1[m])); }
+        fw0[0] = fw1[0] = fw0[1] = fw1[1] = i32x4{0, 0, 0, 0};
+        asm volatile("" : "+v"(fw0[0]), "+v"(fw1[0]), "+v"(fw0[1]), "+v"(fw1[1]));
+      } else {
 #pragma unroll
       for (int m = 0; m < MB; ++m) {
         fa0[m] = *(const i32x4*)(sa + a_off + m * 2048);
@@ -365,6 +371,7 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_fused_kernel(QkvAttnArgs g) {
       }
       fw0[0] = *(const i32x4*)(sw + w_off);
       fw1[0] = *(const i32x4*)(sw + (w_off ^ 64));
+      }
       __builtin_amdgcn_sched_barrier(0);
       if (lower) {
         // early release of the activation image: every wave has its fragments in registers.  (The barrier comes in front of the weight
@@ -382,7 +389,7 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_fused_kernel(QkvAttnArgs g) {
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int n = 0; n < NB; ++n) {
-        if (n + 1 < NB) {
+        if (n + 1 < NB && !(QA_ABLATE & 16)) {
           fw0[(n + 1) & 1] = *(const i32x4*)(sw + w_off + (n + 1) * 2048);
           fw1[(n + 1) & 1] = *(const i32x4*)(sw + ((w_off + (n + 1) * 2048) ^ 64));
         }
