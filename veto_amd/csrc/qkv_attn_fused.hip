@@ -237,11 +237,24 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_fused_kernel(QkvAttnArgs g) {
   const bool lower = w < 4;
   constexpr int kASplit = NWB == 3 ? QA_ASPLIT : 0;      // (even: a piece's swizzle parity is its index's)
   const int a_begin = lower ? 0 : kASplit, a_end = lower ? kASplit : APIECES;    // this wave's activation pieces: a_begin + wl + 4 k < a_end
-  const int rr = lane >> 3;
-  const int r16 = ((wl & 1) << 3) + rr;                                  // row inside its 16-row block (wl + 4 i keeps the parity)
-  const int slot16 = ((lane & 7) ^ ((r16 >> 1) & 7)) << 4;               // source-side swizzle (the LDS side is lane-linear)
-  const unsigned voff_a = (unsigned)((wl * 8 + rr) * kRowB + slot16);
-  const unsigned voff_w = (unsigned)(rr * kRowB + slot16);
+  // Lane-dependent offsets are re-derived from the lane id where they are used (laundered through an empty asm: a few vector instructions
+  // per stage) instead of living in registers through the main loop: at 180 accumulators (six heads) the allocator spills exactly those,
+  // and a scratch reload inside the main loop waits for vmcnt(0), i.e. drains the wave's DMA queue.
+  // (eight heads: 140 accumulators leave room; re-deriving there measured 4 % SLOWER -- the address arithmetic lands in front of the
+  // fragment reads of every stage --, so the offsets stay loop-invariant and the compiler keeps them in registers)
+  constexpr bool kRederive = NB * MB * 4 > 160;
+  auto lane_now = [&]() {
+    int l = lane;
+    if (kRederive) asm volatile("" : "+v"(l));
+    return l;
+  };
+  // per-lane source offset of a piece: row (lane >> 3) of its 8, 16-byte slot (lane & 7) XOR-swizzled with the row's position in its 16-row block
+  auto piece_voff = [&](int l, int first_row) {
+    const int rr = l >> 3;
+    const int r16 = ((wl & 1) << 3) + rr;                                // (wl + 4 i keeps the parity)
+    const int slot16 = ((l & 7) ^ ((r16 >> 1) & 7)) << 4;                // source-side swizzle (the LDS side is lane-linear)
+    return (unsigned)((first_row + rr) * kRowB + slot16);
+  };
   constexpr int NPA = (APIECES - kASplit + 3) / 4, NPW = (G::WPIECES + 3) / 4;      // pieces per wave at most
   const int n_acts = a_end - a_begin > wl ? (a_end - a_begin - wl + 3) / 4 : 0;
   const int n_weights = lower ? (G::WPIECES - wl + 3) / 4 : 0;
@@ -258,6 +271,7 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_fused_kernel(QkvAttnArgs g) {
   };
   // this wave's share of stage s of a tile: activation rows into image `buf` (0 / 1) / weight rows into image `buf` (0 .. NWB - 1)
   auto issue_acts = [&](const TileSrc& t, int s, int buf) {
+    const unsigned voff_a = piece_voff(lane_now(), wl * 8);
 #pragma unroll
     for (int k = 0; k < NPA; ++k)
       if (a_begin + wl + 4 * k < a_end)
@@ -265,6 +279,7 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_fused_kernel(QkvAttnArgs g) {
   };
   auto issue_weights = [&](const TileSrc& t, int s, int buf) {
     if (!lower) return;
+    const unsigned voff_w = piece_voff(lane_now(), 0);
 #pragma unroll
     for (int k = 0; k < NPW; ++k) {
       const int c = wl + 4 * k;          // piece c of the head's q | k | v rows: matrix c / PM, rows 8 (c % PM) .. of that matrix's head slice
@@ -276,10 +291,6 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_fused_kernel(QkvAttnArgs g) {
   };
 
   // ---- MFMA side ---------------------------------------------------------------------------------------------------------------
-  const int fr = lane & 15, fq = lane >> 4;
-  const int frag_off = fr * 128 + ((fq ^ ((fr >> 1) & 7)) << 4);
-  const int a_off = (wm * MB) * 2048 + frag_off;                       // + m * 2048
-  const int w_off = (wn * NB) * 2048 + frag_off;                       // + n * 2048
   const int mix_scale = (127 - kMixActExp - __builtin_amdgcn_readfirstlane(*g.w_exp)) * 0x01010101;
 
   unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0, t_begin = 0, s_wait = 0, s_bar1 = 0, s_frag = 0, s_bar2 = 0, s_main = 0, s_att = 0;
@@ -357,6 +368,11 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_fused_kernel(QkvAttnArgs g) {
       const TileSrc& tw = sw2 < kStages ? src : src_next;
       const int st_a = sa2 < kStages ? sa2 : 0, st_w = sw2 < kStages ? sw2 : 0;
       const int wb2 = NWB == 3 ? (wb == 0 ? 2 : wb - 1) : (wb ^ 1);      // (s + 2) % 3 / (s + 1) % 2
+      const int lane_s = lane_now();
+      const int fr = lane_s & 15, fq = lane_s >> 4;
+      const int frag_off = fr * 128 + ((fq ^ ((fr >> 1) & 7)) << 4);
+      const int a_off = (wm * MB) * 2048 + frag_off;                       // + m * 2048
+      const int w_off = (wn * NB) * 2048 + frag_off;                       // + n * 2048
       i32x4 fa0[MB], fa1[MB], fw0[2], fw1[2];
       if (QA_ABLATE & 16) {
 #pragma unroll
