@@ -290,6 +290,26 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_fused_kernel(QkvAttnArgs g) {
     }
   };
 
+  // Fragment addresses.  Eight heads: one base register per image and 64-byte half (ten registers), so that every fragment read of the main
+  // loop is base + immediate offset (the images lie beyond the 64 KiB an offset field reaches from one base) -- no vector arithmetic in front
+  // of the reads that open a stage; the stage loop is unrolled six times (2 activation x 3 weight images) so that the image indices are
+  // compile-time.  Six heads: re-derived per stage (see lane_now).
+  int ab_[2], ab64_[2], wv_[3], wv64_[3];
+  {
+    const int fr0 = lane & 15, fq0 = lane >> 4;
+    const int fo0 = fr0 * 128 + ((fq0 ^ ((fr0 >> 1) & 7)) << 4);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      ab_[i] = G::a_buf(i) + (wm * MB) * 2048 + fo0;
+      ab64_[i] = ab_[i] ^ 64;
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      wv_[j] = G::w_buf(j < NWB ? j : 0) + (wn * NB) * 2048 + fo0;
+      wv64_[j] = wv_[j] ^ 64;
+    }
+  }
+
   // ---- MFMA side ---------------------------------------------------------------------------------------------------------------
   const int mix_scale = (127 - kMixActExp - __builtin_amdgcn_readfirstlane(*g.w_exp)) * 0x01010101;
 
@@ -310,7 +330,6 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_fused_kernel(QkvAttnArgs g) {
   // interval multiplies (with two weight images the weight pieces are for the very next stage: none of them; they are issued first)
   int younger = n_acts + (NWB == 3 ? n_weights : 0);
   bool stage0_landed = false;    // (behind the attention phase: the stage was waited for in front of it)
-  int wb = 0;                    // weight image of the current stage: s % NWB
 
   for (int it = 0; it < my_tiles; ++it) {
     const int tile = tile_of(it);
@@ -348,16 +367,15 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_fused_kernel(QkvAttnArgs g) {
     };
     // One stage: this wave's 5 activation fragments are held, its NB weight fragments stream through two buffers; group n = the
     // reads of weight fragment n + 1, the MFMAs of fragment n, then one or two of this wave's DMA instructions.
-    auto stage = [&](auto kind_tag, int s) {
-      constexpr int KIND = decltype(kind_tag)::value;
+    auto stage = [&](auto kind_tag, auto ab_tag, auto wb_tag, int s) {
+      constexpr int KIND = decltype(kind_tag)::value, AB = decltype(ab_tag)::value, WB = decltype(wb_tag)::value;   // stage kind, s % 2, s % NWB
       QST(t0);
       if (!stage0_landed) wait_vm(younger);              // this wave's pieces of stage s have landed
       stage0_landed = false;
       QST(t3);
       wg_barrier();                                       // everybody's have; every wave is done with stage s - 1
       QST(t1);
-      const char* sa = smem + (s & 1) * G::kPair;
-      const char* sw = smem + (wb < 2 ? kABytes + wb * G::kPair : 2 * G::kPair);
+
       // what this interval issues: the activation rows of stage s + 2 into the image of stage s (released below), and the weight rows
       // of stage s + 2 into the third image (NWB == 3) or of stage s + 1 into the other image (NWB == 2).  Behind the tile's last stage
       // only the next tile's stage 0 may be in flight (the attention regions cover every other image): stage 1 follows the attention.
@@ -367,12 +385,19 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_fused_kernel(QkvAttnArgs g) {
       const TileSrc& ta = sa2 < kStages ? src : src_next;
       const TileSrc& tw = sw2 < kStages ? src : src_next;
       const int st_a = sa2 < kStages ? sa2 : 0, st_w = sw2 < kStages ? sw2 : 0;
-      const int wb2 = NWB == 3 ? (wb == 0 ? 2 : wb - 1) : (wb ^ 1);      // (s + 2) % 3 / (s + 1) % 2
-      const int lane_s = lane_now();
-      const int fr = lane_s & 15, fq = lane_s >> 4;
-      const int frag_off = fr * 128 + ((fq ^ ((fr >> 1) & 7)) << 4);
-      const int a_off = (wm * MB) * 2048 + frag_off;                       // + m * 2048
-      const int w_off = (wn * NB) * 2048 + frag_off;                       // + n * 2048
+      constexpr int wb2 = NWB == 3 ? (WB == 0 ? 2 : WB - 1) : (WB ^ 1);      // (s + 2) % 3 / (s + 1) % 2
+      int a_lo, a_hi, w_lo, w_hi;      // LDS byte offsets of this lane's first activation / weight fragment: first and second 64-byte half
+      if constexpr (kRederive) {
+        const int lane_s = lane_now();
+        const int fr = lane_s & 15, fq = lane_s >> 4;
+        const int frag_off = fr * 128 + ((fq ^ ((fr >> 1) & 7)) << 4);
+        a_lo = G::a_buf(AB) + (wm * MB) * 2048 + frag_off;
+        w_lo = G::w_buf(WB) + (wn * NB) * 2048 + frag_off;
+        a_hi = a_lo ^ 64;
+        w_hi = w_lo ^ 64;
+      } else {
+        a_lo = ab_[AB]; a_hi = ab64_[AB]; w_lo = wv_[WB]; w_hi = wv64_[WB];
+      }
       i32x4 fa0[MB], fa1[MB], fw0[2], fw1[2];
       if (QA_ABLATE & 16) {
 #pragma unroll
@@ -382,11 +407,11 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_fused_kernel(QkvAttnArgs g) {
       } else {
 #pragma unroll
       for (int m = 0; m < MB; ++m) {
-        fa0[m] = *(const i32x4*)(sa + a_off + m * 2048);
-        fa1[m] = *(const i32x4*)(sa + ((a_off + m * 2048) ^ 64));
+        fa0[m] = *(const i32x4*)(smem + a_lo + m * 2048);
+        fa1[m] = *(const i32x4*)(smem + a_hi + m * 2048);
       }
-      fw0[0] = *(const i32x4*)(sw + w_off);
-      fw1[0] = *(const i32x4*)(sw + (w_off ^ 64));
+      fw0[0] = *(const i32x4*)(smem + w_lo);
+      fw1[0] = *(const i32x4*)(smem + w_hi);
       }
       __builtin_amdgcn_sched_barrier(0);
       if (lower) {
@@ -400,14 +425,14 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_fused_kernel(QkvAttnArgs g) {
           QACC(s_frag, t4, t1); QACC(s_bar2, t5, t4);
         }
         if (do_w) issue_weights(tw, st_w, wb2);
-        if (do_a) issue_acts(ta, st_a, s & 1);
+        if (do_a) issue_acts(ta, st_a, AB);
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int n = 0; n < NB; ++n) {
         if (n + 1 < NB && !(QA_ABLATE & 16)) {
-          fw0[(n + 1) & 1] = *(const i32x4*)(sw + w_off + (n + 1) * 2048);
-          fw1[(n + 1) & 1] = *(const i32x4*)(sw + ((w_off + (n + 1) * 2048) ^ 64));
+          fw0[(n + 1) & 1] = *(const i32x4*)(smem + w_lo + (n + 1) * 2048);
+          fw1[(n + 1) & 1] = *(const i32x4*)(smem + w_hi + (n + 1) * 2048);
         }
 #pragma unroll
         for (int m = 0; m < MB; ++m) mma(kind_tag, acc[n][m], fw0[n & 1], fw1[n & 1], fa0[m], fa1[m], mix_scale);
@@ -421,15 +446,19 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_fused_kernel(QkvAttnArgs g) {
           QACC(s_bar2, t5, t4);
         }
       }
-      if (!lower && do_a) issue_acts(ta, st_a, s & 1);
+      if (!lower && do_a) issue_acts(ta, st_a, AB);
       younger = (do_a ? n_acts : 0) + (NWB == 3 && do_w ? n_weights : 0);
-      wb = wb + 1 == NWB ? 0 : wb + 1;
       QST(t2);
       QACC(s_wait, t3, t0); QACC(s_bar1, t1, t3); QACC(s_main, t2, t1);
     };
-    for (int s = 0; s < kStages; s += 2) {
-      stage(Tag<0>(), s);
-      stage(Tag<1>(), s + 1);
+    static_assert(kStages % 6 == 0, "the stage loop is unrolled over the 2 x 3 image indices");
+    for (int s = 0; s < kStages; s += 6) {
+      stage(Tag<0>(), Tag<0>(), Tag<0>(), s);
+      stage(Tag<1>(), Tag<1>(), Tag<1 % NWB>(), s + 1);
+      stage(Tag<0>(), Tag<0>(), Tag<2 % NWB>(), s + 2);
+      stage(Tag<1>(), Tag<1>(), Tag<3 % NWB>(), s + 3);
+      stage(Tag<0>(), Tag<0>(), Tag<4 % NWB>(), s + 4);
+      stage(Tag<1>(), Tag<1>(), Tag<5 % NWB>(), s + 5);
     }
 
     // ---- attention phase -----------------------------------------------------------------------------------------------------------
