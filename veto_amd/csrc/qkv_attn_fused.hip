@@ -44,6 +44,7 @@
 #include <cstdlib>
 
 // timing ablations (tools/variants.sh; results are WRONG with any of them set): 1 = no DMA, 2 = no attention phase (nothing is stored),
+// 32 = no scores / softmax, 64 = no P V and no output, 128 = no Q / K / V row writes, 256 = no accumulator conversion (attention-phase ablations),
 // 4 = no MFMAs in the main loop, 8 = no output stores, 16 = no fragment reads in the main loop (the MFMAs run on whatever the registers hold)
 #ifndef QA_ABLATE
 #define QA_ABLATE 0
@@ -130,20 +131,57 @@ __device__ __forceinline__ void lds_barrier() {
 // Four fp32 values -> bf16 hi and bf16 lo (x ~= hi + lo, common.h), both PACKED: {v0 | v1 << 16, v2 | v3 << 16}.  Written on dwords and
 // pinned by an empty asm: left to the vector types, the compiler keeps every 16-bit element of the 8 x 35 values in a register of its own
 // next to the packed form (the element-wise V^T stores below index them), and spills a few hundred registers.
+// Two fp32 values -> packed 16-bit hi and lo parts, x ~= hi + lo (the operands of the attention products: three MFMA terms hi hi + hi lo +
+// lo hi).  QA_F16_SPLIT (default): fp16 hi (11 significant bits) + fp16 lo: 22 bits in all, FOUR vector instructions per value pair
+// (v_cvt_pk_f16_f32, two v_fma_mix_f32 that read the packed halves in place, v_cvt_pk_f16_f32) -- the attention phase is bound by vector
+// instruction issue.  q / k / v are O(10) here (LayerNorm'ed rows times weights), far inside the fp16 range (the conversions saturate at
+// 65 504: MODE.FP16_OVFL is set), and a lo part below 2^-14 loses at most what a bf16 lo would have lost.  0: bf16 hi + bf16 lo (16 bits,
+// six instructions; the split of attention.hip).  The packed value is pinned by an empty asm: the compiler otherwise converts the first value
+// a second time, alone, to get at its half.
+#ifndef QA_F16_SPLIT
+#define QA_F16_SPLIT 1
+#endif
 __device__ __forceinline__ uint32_t pk_bf16(float a, float b) {
   const bf16x2 v = {(__bf16)a, (__bf16)b};
   return __builtin_bit_cast(uint32_t, v);
 }
+__device__ __forceinline__ void split2(float a, float b, uint32_t& hi, uint32_t& lo) {
+#if QA_F16_SPLIT
+  uint32_t h, l;
+  float l0, l1;
+  asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(h) : "v"(a), "v"(b));      // (volatile: reads MODE, see mixed_pack4 in common.h)
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l0) : "v"(h), "v"(a));
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(l1) : "v"(h), "v"(b));
+  asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(l) : "v"(l0), "v"(l1));
+  hi = h;
+  lo = l;
+#else
+  uint32_t h = pk_bf16(a, b);
+  asm("" : "+v"(h));
+  hi = h;
+  lo = pk_bf16(a - __uint_as_float(h << 16), b - __uint_as_float(h & 0xffff0000u));
+#endif
+}
+// Four fp32 values -> packed hi and lo: {v0 | v1 << 16, v2 | v3 << 16}.  Written on dwords and pinned by an empty asm: left to the vector
+// types, the compiler keeps every 16-bit element of the 8 x 35 values in a register of its own next to the packed form (the element-wise
+// stores of an earlier version indexed them), and spills a few hundred registers.
 __device__ __forceinline__ void split4(const f32x4& v, u32x2& hi, u32x2& lo) {
-#pragma unroll
-  for (int p = 0; p < 2; ++p) {
-    uint32_t h = pk_bf16(v[2 * p], v[2 * p + 1]);
-    asm("" : "+v"(h));      // (opaque: the compiler otherwise converts the first value a second time, alone, to get its high half)
-    const float l0 = v[2 * p] - __uint_as_float(h << 16), l1 = v[2 * p + 1] - __uint_as_float(h & 0xffff0000u);
-    hi[p] = h;
-    lo[p] = pk_bf16(l0, l1);
-  }
+  uint32_t h0, l0, h1, l1;
+  split2(v[0], v[1], h0, l0);
+  split2(v[2], v[3], h1, l1);
+  hi = u32x2{h0, h1};
+  lo = u32x2{l0, l1};
   asm volatile("" : "+v"(hi), "+v"(lo));
+}
+// one 32x32x16 MFMA term of the attention products on packed 16-bit operands (8 values = 4 dwords per lane)
+typedef _Float16 qa_f16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((ext_vector_type(16))) float qa_f32x16;
+__device__ __forceinline__ qa_f32x16 mfma16(const u32x4& a, const u32x4& b, const qa_f32x16& c) {
+#if QA_F16_SPLIT
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(qa_f16x8, a), __builtin_bit_cast(qa_f16x8, b), c, 0, 0, 0);
+#else
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+#endif
 }
 
 template <int I, int N, class F>
@@ -196,11 +234,11 @@ __device__ __forceinline__ void wait_vm(int n) {
 typedef short qa_s16x4 __attribute__((ext_vector_type(4)));
 typedef short qa_s16x8 __attribute__((ext_vector_type(8)));
 // two transposed LDS reads = one MFMA B fragment whose 8 contraction indices are image ROWS (4 + 4 tokens x 16 columns per 16-lane group)
-__device__ __forceinline__ bf16x8 lds_tr_pair(const char* p0, const char* p1) {
+__device__ __forceinline__ u32x4 lds_tr_pair(const char* p0, const char* p1) {
   const qa_s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) qa_s16x4*)p0);
   const qa_s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) qa_s16x4*)p1);
   const qa_s16x8 v = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
-  return __builtin_bit_cast(bf16x8, v);
+  return __builtin_bit_cast(u32x4, v);
 }
 
 template <int DH>
@@ -477,7 +515,10 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_fused_kernel(QkvAttnArgs g) {
 #pragma unroll
     for (int n = 0; n < NB; ++n)
 #pragma unroll
-      for (int m = 0; m < MB; ++m) split4(acc[n][m], ch[n][m], cl[n][m]);
+      for (int m = 0; m < MB; ++m) {
+        if (QA_ABLATE & 256) { ch[n][m] = u32x2{__float_as_uint(acc[n][m][0]), __float_as_uint(acc[n][m][1])}; cl[n][m] = u32x2{__float_as_uint(acc[n][m][2]), __float_as_uint(acc[n][m][3])}; }
+        else split4(acc[n][m], ch[n][m], cl[n][m]);
+      }
     AST(0);
 
     int lane_a = lane;
@@ -544,13 +585,14 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_fused_kernel(QkvAttnArgs g) {
           }
         }
       };
-      if (wn == 0) write_rows(Tag<0>(), Tag<0>()); else write_rows(Tag<1>(), Tag<0>());
+      if (!(QA_ABLATE & 128)) { if (wn == 0) write_rows(Tag<0>(), Tag<0>()); else write_rows(Tag<1>(), Tag<0>()); }
       AST(1);
       lds_barrier();
       AST(2);
       // -- S^T = K Q^T on region w: row = key j, column = query i (attention.hip) ----------------------------------------------------
-      bf16x8 ph[2], pl[2];
-      if (active) {
+      u32x4 ph[2], pl[2];
+      if (QA_ABLATE & 32) { ph[0] = ph[1] = pl[0] = pl[1] = u32x4{0u, 0u, 0u, 0u}; }
+      if (active && !(QA_ABLATE & 32)) {
         const char* q_hi = region;
         const char* q_lo = region + G::PLANE;
         const char* k_hi = region + 2 * G::PLANE;
@@ -562,15 +604,15 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_fused_kernel(QkvAttnArgs g) {
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
           const int off = rq * G::QP + (16 * s + 8 * hh) * 2;
-          bf16x8 kh = *(const bf16x8*)(k_hi + off), kl = *(const bf16x8*)(k_lo + off);
-          bf16x8 qh = *(const bf16x8*)(q_hi + off), ql = *(const bf16x8*)(q_lo + off);
+          u32x4 kh = *(const u32x4*)(k_hi + off), kl = *(const u32x4*)(k_lo + off);
+          u32x4 qh = *(const u32x4*)(q_hi + off), ql = *(const u32x4*)(q_lo + off);
           if (16 * s + 8 >= DH) {      // the upper half of the last k-step lies behind the row: zeros (both operands: 0 x NaN is NaN)
-            const bf16x8 z = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+            const u32x4 z = {0u, 0u, 0u, 0u};
             if (hh) { kh = z; kl = z; qh = z; ql = z; }
           }
-          st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl, qh, st, 0, 0, 0);
-          st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, ql, st, 0, 0, 0);
-          st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qh, st, 0, 0, 0);
+          st = mfma16(kl, qh, st);
+          st = mfma16(kh, ql, st);
+          st = mfma16(kh, qh, st);
         }
         // softmax over the keys of query (lane & 31): 16 registers here + 16 in lane ^ 32
         float p[16];
@@ -592,18 +634,16 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_fused_kernel(QkvAttnArgs g) {
         const float inv = __builtin_amdgcn_rcpf(sum);
 #pragma unroll
         for (int t = 0; t < 16; t += 2) {
-          const float a0 = p[t] * inv, a1 = p[t + 1] * inv;
-          uint32_t h2 = pk_bf16(a0, a1);
-          asm("" : "+v"(h2));
-          const uint32_t l2 = pk_bf16(a0 - __uint_as_float(h2 << 16), a1 - __uint_as_float(h2 & 0xffff0000u));
-          ((uint32_t*)&ph[t >> 3])[(t & 7) >> 1] = h2;
-          ((uint32_t*)&pl[t >> 3])[(t & 7) >> 1] = l2;
+          uint32_t h2, l2;
+          split2(p[t] * inv, p[t + 1] * inv, h2, l2);
+          ph[t >> 3][(t & 7) >> 1] = h2;      // (constant indices: the loop is unrolled)
+          pl[t >> 3][(t & 7) >> 1] = l2;
         }
       }
       AST(3);
       lds_barrier();         // every wave has read its Q / K images: the V images go over them
       AST(4);
-      if (wn == 0) write_rows(Tag<0>(), Tag<1>()); else write_rows(Tag<1>(), Tag<1>());
+      if (!(QA_ABLATE & 128)) { if (wn == 0) write_rows(Tag<0>(), Tag<1>()); else write_rows(Tag<1>(), Tag<1>()); }
       if (lane_a < 2 * (G::QP / 16)) {       // image row 19 of this wave's own region: the zero row (keys 19..31)
         const int pln = lane_a >= G::QP / 16;
         *(u32x4*)(region + pln * G::VPLANE + kTokens * G::QP + (lane_a - pln * (G::QP / 16)) * 16) = u32x4{0u, 0u, 0u, 0u};
@@ -613,7 +653,7 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_fused_kernel(QkvAttnArgs g) {
       AST(6);
       // -- O = P V: A operand = P^T accumulators, whose element e of k-step s is key 16 s + 8 (e >> 2) + 4 h + (e & 3); the B operand is
       // read in that order from the row-major V images (transposed reads: lane 16 g + 4 q + p supplies row q of the 4, 8-byte piece p)
-      if (active) {
+      if (active && !(QA_ABLATE & 64)) {
         const char* v_hi = region;
         const char* v_lo = region + G::VPLANE;
         float* o_lds = (float*)(region + 2 * G::VPLANE);   // [19][DH] fp32
@@ -634,11 +674,11 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_fused_kernel(QkvAttnArgs g) {
           for (int t = 0; t < 16; ++t) o[t] = 0.f;
 #pragma unroll
           for (int s = 0; s < 2; ++s) {
-            const bf16x8 vh = lds_tr_pair(v_hi + trow[s][0] + 64 * n, v_hi + trow[s][1] + 64 * n);
-            const bf16x8 vl = lds_tr_pair(v_lo + trow[s][0] + 64 * n, v_lo + trow[s][1] + 64 * n);
-            o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pl[s], vh, o, 0, 0, 0);
-            o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ph[s], vl, o, 0, 0, 0);
-            o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ph[s], vh, o, 0, 0, 0);
+            const u32x4 vh = lds_tr_pair(v_hi + trow[s][0] + 64 * n, v_hi + trow[s][1] + 64 * n);
+            const u32x4 vl = lds_tr_pair(v_lo + trow[s][0] + 64 * n, v_lo + trow[s][1] + 64 * n);
+            o = mfma16(pl[s], vh, o);
+            o = mfma16(ph[s], vl, o);
+            o = mfma16(ph[s], vh, o);
           }
           // register t holds query (t & 3) + 8 (t >> 2) + 4 h: t < 8 always a token, t = 8..10 only in the lower half wave (16..18), t >= 11 never
           // (two predicated regions per tile instead of one per register: every `if` is an exec-mask save / restore and a branch)
