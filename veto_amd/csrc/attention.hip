@@ -105,8 +105,18 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 // contiguous eighth of the items, so that an image's table rows meet in one L2, measured neutral.)
 // F24: q / k / v arrive as 3-byte floats (common.h): a chunk of 8 values is 24 bytes, and hi + lo of such a value is exact.
 template <int V> struct IntTag { static constexpr int value = V; };
+template <int I, int N, class F>
+__device__ __forceinline__ void att_static_for(F&& f) {
+  if constexpr (I < N) {
+    f(IntTag<I>());
+    att_static_for<I + 1, N>(f);
+  }
+}
+#ifndef TAB_SPLIT_LOADS
+#define TAB_SPLIT_LOADS 1      // 0: every chunk of the table form requested up front (round 4; two waves per SIMD)
+#endif
 template <int DH, bool TAB = false, bool F24 = false>
-__global__ __launch_bounds__(128, TAB ? 2 : 3) void attention_mfma_kernel(AttnArgs a) {
+__global__ __launch_bounds__(128, TAB && (!TAB_SPLIT_LOADS || DH > 72) ? 2 : 3) void attention_mfma_kernel(AttnArgs a) {
   static_assert(!(TAB && F24), "the per-object form reads fp32 tables");
   saturating_conversions_on();   // (the mixed-row output path converts without clamps, common.h)
   constexpr int DHP = (DH + 15) / 16 * 16;  // contraction extent of QK^T (zero padded)
@@ -159,8 +169,12 @@ __global__ __launch_bounds__(128, TAB ? 2 : 3) void attention_mfma_kernel(AttnAr
     tab_s = a.sw + (size_t)a.subj[pair] * kPatchTokens * (3 * kDim) + head * DH;
     tab_o = a.ow + (size_t)a.obj[pair] * kPatchTokens * (3 * kDim) + head * DH;
   }
-#pragma unroll
-  for (int r = 0; r < ROUNDS; ++r) {
+  // TAB: two table rows per chunk are twice the registers in flight, so the chunks go out in two groups: the rounds that hold a Q or K
+  // chunk now, the V-only rounds behind the Q / K conversion (their latency then lies under S^T and the softmax) -- the peak is ~110
+  // registers instead of 170 and the kernel runs three waves per SIMD without spilling (round 4 had two).
+  constexpr int kLateFrom = TAB_SPLIT_LOADS && TAB ? (2 * PER_MAT + 63) / 64 : ROUNDS;     // first round without a Q / K chunk
+  auto load_round = [&](auto r_tag) {
+    constexpr int r = decltype(r_tag)::value;
     const int e = lane + 64 * r;
     const int mat = e / PER_MAT, rem = e % PER_MAT, i = rem / CH, c = rem % CH;
     const bool need = e < 3 * PER_MAT && !(a.cls_only && mat == 0 && i > 0);
@@ -190,7 +204,8 @@ __global__ __launch_bounds__(128, TAB ? 2 : 3) void attention_mfma_kernel(AttnAr
       ld[r][0] = f32x4{0.f, 0.f, 0.f, 0.f};
       ld[r][1] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-  }
+  };
+  att_static_for<0, kLateFrom>(load_round);
   // Conversion of the loaded chunks into the bf16 hi / lo images.  PHASE 0: the Q and K chunks (and, TAB, the table arithmetic of
   // every chunk, so that only its result stays in registers); PHASE 1, behind S^T: the V chunks into the transposed images.
   auto convert = [&](auto phase_tag) {
@@ -198,11 +213,13 @@ __global__ __launch_bounds__(128, TAB ? 2 : 3) void attention_mfma_kernel(AttnAr
 #pragma unroll
     for (int r = 0; r < ROUNDS; ++r) {
       // (rounds that hold no chunk of this phase; TAB: phase 0 visits the V rounds too, for the table arithmetic)
-      if (PHASE == 0 ? (!TAB && 64 * r >= 2 * PER_MAT) : 64 * r + 63 < 2 * PER_MAT) continue;
+      if (PHASE == 0 ? ((!TAB || r >= kLateFrom) && 64 * r >= 2 * PER_MAT) : 64 * r + 63 < 2 * PER_MAT) continue;
       const int e = lane + 64 * r;
       if (e >= 3 * PER_MAT) continue;
       const int mat = e / PER_MAT, rem = e % PER_MAT, i = rem / CH, c = rem % CH;
-      if (PHASE == 0 && TAB && i >= 1 && i <= kPatchTokens) {     // rstd (SW + OW) + c2 (c2: 3 * DH floats per head, L1-resident)
+      // (the table arithmetic of a round runs in the phase that first sees the round's data: phase 0 for the early rounds -- their V chunks
+      // included, so that only the result stays in registers --, phase 1 for the late ones)
+      if ((PHASE == 0 ? r < kLateFrom : r >= kLateFrom) && TAB && i >= 1 && i <= kPatchTokens) {     // rstd (SW + OW) + c2 (c2: 3 * DH floats per head, L1-resident)
         const float* c2 = a.vec + head * DH + mat * kDim + c * 8;
         const f32x4 c20 = *(const f32x4*)c2, c21 = *(const f32x4*)(c2 + 4);
         ld[r][0] = rs[TAB ? r : 0] * (ld[r][0] + ldb[TAB ? r : 0][0]) + c20;
@@ -236,6 +253,7 @@ __global__ __launch_bounds__(128, TAB ? 2 : 3) void attention_mfma_kernel(AttnAr
     }
   };
   convert(IntTag<0>());
+  att_static_for<kLateFrom, ROUNDS>(load_round);      // (TAB: the V-only rounds; in flight under S^T)
   if (DHP > DH) {  // zero the contraction padding of the Q / K rows
     for (int idx = lane; idx < 4 * kTokens; idx += 64) {
       char* dst = base + (idx / kTokens) * QK_PLANE + (idx % kTokens) * RB + DH * 2;
