@@ -53,6 +53,11 @@
 // control of tests/test_ffn_asm.py
 // activation pieces the lower half issues beside the weight pieces (three weight images; measured: 4 / 10 / 16 within 1 % of one another,
 // 0 -- the upper half issues every activation piece -- 6 % slower)
+// weight-fragment buffers of the main loop: fragment n + QA_WBUF - 1 is requested while fragment n is multiplied (3 measured equal to 2: 1.315 vs 1.304-1.314 ms; six heads have
+// no registers for a third buffer)
+#ifndef QA_WBUF
+#define QA_WBUF 2
+#endif
 #ifndef QA_ASPLIT
 #define QA_ASPLIT 10
 #endif
@@ -436,20 +441,24 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_fused_kernel(QkvAttnArgs g) {
       } else {
         a_lo = ab_[AB]; a_hi = ab64_[AB]; w_lo = wv_[WB]; w_hi = wv64_[WB];
       }
-      i32x4 fa0[MB], fa1[MB], fw0[2], fw1[2];
+      constexpr int WBUF = kRederive ? 2 : QA_WBUF;
+      i32x4 fa0[MB], fa1[MB], fw0[WBUF], fw1[WBUF];
       if (QA_ABLATE & 16) {
 #pragma unroll
         for (int m = 0; m < MB; ++m) { fa0[m] = fa1[m] = i32x4{0, 0, 0, 0}; asm volatile("" : "+v"(fa0[m]), "+v"(fa1[m])); }
-        fw0[0] = fw1[0] = fw0[1] = fw1[1] = i32x4{0, 0, 0, 0};
-        asm volatile("" : "+v"(fw0[0]), "+v"(fw1[0]), "+v"(fw0[1]), "+v"(fw1[1]));
+#pragma unroll
+        for (int i = 0; i < WBUF; ++i) { fw0[i] = fw1[i] = i32x4{0, 0, 0, 0}; asm volatile("" : "+v"(fw0[i]), "+v"(fw1[i])); }
       } else {
 #pragma unroll
       for (int m = 0; m < MB; ++m) {
         fa0[m] = *(const i32x4*)(smem + a_lo + m * 2048);
         fa1[m] = *(const i32x4*)(smem + a_hi + m * 2048);
       }
-      fw0[0] = *(const i32x4*)(smem + w_lo);
-      fw1[0] = *(const i32x4*)(smem + w_hi);
+#pragma unroll
+      for (int i = 0; i < WBUF - 1; ++i) {
+        fw0[i] = *(const i32x4*)(smem + w_lo + i * 2048);
+        fw1[i] = *(const i32x4*)(smem + w_hi + i * 2048);
+      }
       }
       __builtin_amdgcn_sched_barrier(0);
       if (lower) {
@@ -468,12 +477,12 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_fused_kernel(QkvAttnArgs g) {
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int n = 0; n < NB; ++n) {
-        if (n + 1 < NB && !(QA_ABLATE & 16)) {
-          fw0[(n + 1) & 1] = *(const i32x4*)(smem + w_lo + (n + 1) * 2048);
-          fw1[(n + 1) & 1] = *(const i32x4*)(smem + w_hi + (n + 1) * 2048);
+        if (n + WBUF - 1 < NB && !(QA_ABLATE & 16)) {
+          fw0[(n + WBUF - 1) % WBUF] = *(const i32x4*)(smem + w_lo + (n + WBUF - 1) * 2048);
+          fw1[(n + WBUF - 1) % WBUF] = *(const i32x4*)(smem + w_hi + (n + WBUF - 1) * 2048);
         }
 #pragma unroll
-        for (int m = 0; m < MB; ++m) mma(kind_tag, acc[n][m], fw0[n & 1], fw1[n & 1], fa0[m], fa1[m], mix_scale);
+        for (int m = 0; m < MB; ++m) mma(kind_tag, acc[n][m], fw0[n % WBUF], fw1[n % WBUF], fa0[m], fa1[m], mix_scale);
         __builtin_amdgcn_sched_barrier(0);
         if (n == 0 && !lower && do_a) {
           // (the upper half joins the release barrier behind its first group: its fragments are in registers by then, and its matrix
