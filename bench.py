@@ -254,12 +254,13 @@ def main():
                     for k in ("attention", "attention_cls", "layernorm") if k in prof and prof[k]["bytes_per_launch"]}
         gather_bytes = prof["assemble_tokens"]["bytes_per_launch"]      # bytes the kernel writes, as the library accounts them
         gather_gbps = gather_bytes / (kern["assemble_tokens"]["avg_ms"] * 1e-3) / 1e9
-        traffic, attention_pmc = None, None
+        traffic, attention_pmc, tj_kernels = None, None, None
         try:  # PMC-derived numbers for THIS workload, written by tools/pmc_traffic.py from the profile tag named inside
             tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
             if tj.get("workload") == [args.images, args.objs, args.layers, args.heads, args.precision]:
                 traffic = tj["kernels"].get(dom, {}).get("hbm_bytes_per_launch")
                 attention_pmc = tj.get("attention")
+                tj_kernels = tj["kernels"]
         except (OSError, ValueError, KeyError):
             pass
         res = {
@@ -291,6 +292,15 @@ def main():
                                "with layer 0 in the per-object form, the row statistics and the split rows of two of the 19 tokens); "
                                "the per-object rows it gathers (gathered_bytes; moved_gbps counts them too) come from L2 / Infinity Cache"},
             "attention": attention_pmc,
+            # the fused QKV projection + attention launch of the middle layers (round 5): algorithmic FLOPs of the projection and of the
+            # attention contractions / its mean hipEvent duration, counted HBM bytes per launch from the same PMC passes
+            "qkv_attn": ({"kernel": "qkv_attn_fused", "ms_per_launch": round(kern["qkv_attn_fused"]["avg_ms"], 4),
+                          "achieved": kern["qkv_attn_fused"]["tflops"], "unit": "TFLOP/s", "peak": PEAK_BF16_TFLOPS,
+                          "frac": kern["qkv_attn_fused"]["tflops"] / PEAK_BF16_TFLOPS,
+                          "traffic": (tj_kernels or {}).get("qkv_attn_fused", {}).get("hbm_bytes_per_launch"),
+                          "algorithmic_bytes": prof["qkv_attn_fused"]["bytes_per_launch"],
+                          "mfma_busy": (tj_kernels or {}).get("qkv_attn_fused", {}).get("mfma_busy")}
+                         if "qkv_attn_fused" in kern else None),
             "gemm_all": {"kernel": "all GEMM launches of a step", "ms_per_step": round(gemm_ms, 4),
                          "achieved": gemm_flops / (gemm_ms * 1e-3) / 1e12, "unit": "TFLOP/s",
                          "frac": gemm_flops / (gemm_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS},
