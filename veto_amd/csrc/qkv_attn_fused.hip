@@ -12,8 +12,9 @@
 //   main loop    18 stages (9 blocks of 64 k's x {fp16 part, e4m3 part} of the VETO_MIXED operands, common.h); a stage is 128 bytes
 //                of every row: 38 KiB of activation rows + 27 / 36 KiB of weight rows, LDS-DMA'd (global_load_lds_dwordx4) with the
 //                source-side XOR swizzle of gemm_split_ps.hip.  No loader waves (twelve waves would cap the kernel at 168 registers,
-//                and the [304 x 3 DH] result needs 140 / 180 accumulator registers per lane): every wave issues its share of the DMA
-//                between its MFMA groups.  Two stages of 65 KiB are all the LDS holds, and a stage that is issued only when its slot is
+//                and the [304 x 3 DH] result needs 140 / 180 accumulator registers per lane): the waves issue the DMA themselves, and
+//                SIMD partners take turns -- waves 0-3 issue their share in front of their MFMA groups, waves 4-7 behind them (DMA
+//                side, below).  Two stages of 65 KiB are all the LDS holds, and a stage that is issued only when its slot is
 //                free gets ONE interval (~1 us) of flight against ~1.6 us from issue to landing with every CU streaming (measured:
 //                1 000 cycles of exposed wait per stage).  So the buffers are TWO activation images + THREE weight images, and an
 //                activation image is released EARLY: every wave holds its five activation fragments in registers for the whole
@@ -24,7 +25,7 @@
 //                Wave (wm, wn) of 4 x 2 owns row blocks 5 wm .. 5 wm + 4 (block 19 does not exist: wm = 3 multiplies a dummy whose
 //                result is never read -- its SIMD would idle otherwise) and column blocks NB wn .. NB wn + NB - 1.
 //   attention    behind the last stage the buffers are dead, except the first activation / weight image, which already holds the
-//                NEXT tile's first stage where the geometry allows: the waves convert their accumulators to packed bf16 hi / lo once,
+//                NEXT tile's first stage where the geometry allows: the waves convert their accumulators to packed fp16 hi / lo once,
 //                then twice (pairs in two batches of 8): the owners write the batch's Q / K rows into eight per-pair LDS regions in
 //                the image layout of attention_mfma_kernel, barrier, wave w runs that kernel's S^T = K Q^T + softmax on region w,
 //                barrier, the owners write the V rows over the Q / K images, barrier, wave w runs P V (V as the B operand through
@@ -49,23 +50,23 @@
 #ifndef QA_ABLATE
 #define QA_ABLATE 0
 #endif
-// the wait states in front of every inline-asm MFMA (see mma() below); -DQA_MMA_NOP='""' builds the kernel WITHOUT them: the negative
-// control of tests/test_ffn_asm.py
-// activation pieces the lower half issues beside the weight pieces (three weight images; measured: 4 / 10 / 16 within 1 % of one another,
-// 0 -- the upper half issues every activation piece -- 6 % slower)
-// weight-fragment buffers of the main loop: fragment n + QA_WBUF - 1 is requested while fragment n is multiplied (3 measured equal to 2: 1.315 vs 1.304-1.314 ms; six heads have
-// no registers for a third buffer)
-#ifndef QA_WBUF
-#define QA_WBUF 2
-#endif
-#ifndef QA_ASPLIT
-#define QA_ASPLIT 10
-#endif
+// the wait states in front of every inline-asm MFMA (see mma() below); -DQA_NO_PADS builds the kernel WITHOUT them: the negative control of
+// tests/test_ffn_asm.py
 #ifdef QA_NO_PADS
 #define QA_MMA_NOP ""
 #endif
 #ifndef QA_MMA_NOP
 #define QA_MMA_NOP "s_nop 1\n\t"
+#endif
+// activation pieces the lower half issues beside the weight pieces (three weight images; measured: 4 / 10 / 16 within 1 % of one another,
+// 0 -- the upper half issues every activation piece -- 6 % slower)
+#ifndef QA_ASPLIT
+#define QA_ASPLIT 10
+#endif
+// weight-fragment buffers of the main loop: fragment n + QA_WBUF - 1 is requested while fragment n is multiplied (3 measured equal to 2:
+// 1.315 vs 1.304-1.314 ms; six heads have no registers for a third buffer)
+#ifndef QA_WBUF
+#define QA_WBUF 2
 #endif
 
 namespace veto {
