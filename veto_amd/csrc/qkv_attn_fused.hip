@@ -23,7 +23,7 @@
 //                three and receives stage s + 2 too.  Everything gets two intervals of flight.  (Six heads: 36 KiB weight images,
 //                two of them: W(s + 1) has one interval.)
 //                Wave (wm, wn) of 4 x 2 owns row blocks 5 wm .. 5 wm + 4 (block 19 does not exist: wm = 3 multiplies a dummy whose
-//                result is never read -- its SIMD would idle otherwise) and column blocks NB wn .. NB wn + NB - 1.
+//                result is never read -- its SIMD would idle otherwise) and column blocks NB wn .. NB wn + NB - 1 (QA_COL_INTERLEAVE: 2 n + wn).
 //   attention    behind the last stage the buffers are dead, except the first activation / weight image, which already holds the
 //                NEXT tile's first stage where the geometry allows: the waves convert their accumulators to packed fp16 hi / lo once,
 //                then twice (pairs in two batches of 8): the owners write the batch's Q / K rows into eight per-pair LDS regions in
@@ -67,6 +67,12 @@
 // 1.315 vs 1.304-1.314 ms; six heads have no registers for a third buffer)
 #ifndef QA_WBUF
 #define QA_WBUF 2
+#endif
+// column blocks of the two wave columns: 0 = contiguous halves (wn = 0: q and the first part of k), 1 = interleaved (wave column wn owns the
+// blocks 2 n + wn: both columns hold a share of q, k AND v, so the row writes of the attention phase are spread over all eight waves --
+// measured 1.340-1.347 against 1.325-1.338 ms: the unbalanced row writes are not what the phase waits for)
+#ifndef QA_COL_INTERLEAVE
+#define QA_COL_INTERLEAVE 0
 #endif
 
 namespace veto {
@@ -257,6 +263,7 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_fused_kernel(QkvAttnArgs g) {
   const int lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = w & 3, wn = w >> 2;
+  constexpr int kColBase = QA_COL_INTERLEAVE ? 2048 : NB * 2048, kColStep = QA_COL_INTERLEAVE ? 4096 : 2048;   // LDS bytes: wave column, block n -> n + 1
   const int b = blockIdx.x;
   const int H = g.heads;
   const int groups = (g.n_pair + TP - 1) / TP;
@@ -349,7 +356,7 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_fused_kernel(QkvAttnArgs g) {
     }
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-      wv_[j] = G::w_buf(j < NWB ? j : 0) + (wn * NB) * 2048 + fo0;
+      wv_[j] = G::w_buf(j < NWB ? j : 0) + wn * kColBase + fo0;
       wv64_[j] = wv_[j] ^ 64;
     }
   }
@@ -436,7 +443,7 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_fused_kernel(QkvAttnArgs g) {
         const int fr = lane_s & 15, fq = lane_s >> 4;
         const int frag_off = fr * 128 + ((fq ^ ((fr >> 1) & 7)) << 4);
         a_lo = G::a_buf(AB) + (wm * MB) * 2048 + frag_off;
-        w_lo = G::w_buf(WB) + (wn * NB) * 2048 + frag_off;
+        w_lo = G::w_buf(WB) + wn * kColBase + frag_off;
         a_hi = a_lo ^ 64;
         w_hi = w_lo ^ 64;
       } else {
@@ -457,8 +464,8 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_fused_kernel(QkvAttnArgs g) {
       }
 #pragma unroll
       for (int i = 0; i < WBUF - 1; ++i) {
-        fw0[i] = *(const i32x4*)(smem + w_lo + i * 2048);
-        fw1[i] = *(const i32x4*)(smem + w_hi + i * 2048);
+        fw0[i] = *(const i32x4*)(smem + w_lo + i * kColStep);
+        fw1[i] = *(const i32x4*)(smem + w_hi + i * kColStep);
       }
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -479,8 +486,8 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_fused_kernel(QkvAttnArgs g) {
 #pragma unroll
       for (int n = 0; n < NB; ++n) {
         if (n + WBUF - 1 < NB && !(QA_ABLATE & 16)) {
-          fw0[(n + WBUF - 1) % WBUF] = *(const i32x4*)(smem + w_lo + (n + WBUF - 1) * 2048);
-          fw1[(n + WBUF - 1) % WBUF] = *(const i32x4*)(smem + w_hi + (n + WBUF - 1) * 2048);
+          fw0[(n + WBUF - 1) % WBUF] = *(const i32x4*)(smem + w_lo + (n + WBUF - 1) * kColStep);
+          fw1[(n + WBUF - 1) % WBUF] = *(const i32x4*)(smem + w_hi + (n + WBUF - 1) * kColStep);
         }
 #pragma unroll
         for (int m = 0; m < MB; ++m) mma(kind_tag, acc[n][m], fw0[n % WBUF], fw1[n % WBUF], fa0[m], fa1[m], mix_scale);
@@ -564,7 +571,7 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_fused_kernel(QkvAttnArgs g) {
           if (mine) {
             static_for_n<NB>([&](auto n_tag) {
               constexpr int n = decltype(n_tag)::value;
-              constexpr int c0 = 16 * (WN * NB + n);                             // first column of the block; this lane: c0 + 4 fq ..
+              constexpr int c0 = 16 * (QA_COL_INTERLEAVE ? 2 * n + WN : WN * NB + n);   // first column of the block; this lane: c0 + 4 fq ..
               constexpr int m_lo = c0 / DH, m_hi = (c0 + 15) / DH;               // matrix of the block's first / last column (3 = padding)
               auto in_phase = [](int mat) { return PHASE == 0 ? mat < 2 : mat == 2; };
               auto off_of = [](int mat) { return (PHASE == 0 ? mat * 2 * G::PLANE : 0) + (c0 - mat * DH) * 2; };   // (+ 8 fq: in rowp)
