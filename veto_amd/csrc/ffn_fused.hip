@@ -70,6 +70,13 @@
 #endif
 
 
+#ifndef FFN_PRIO
+#define FFN_PRIO 0
+#endif
+#ifndef FFN_PINGPONG
+#define FFN_PINGPONG 0
+#endif
+
 namespace veto {
 
 namespace {
@@ -166,6 +173,11 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs g) {
     return l;
   };
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+#if FFN_PRIO == 1
+  if (w >= 4) __builtin_amdgcn_s_setprio(1);
+#elif FFN_PRIO == 2
+  if (w < 4) __builtin_amdgcn_s_setprio(1);
+#endif
   const int wm = w >> 1, wn = w & 1;          // 4 x 2 waves: rows 32 wm .., of every 64 weight rows of a stage the 32 at 32 wn
   const int G = gridDim.x, b = blockIdx.x;
   const int my_panels = g.n_panels > b ? (g.n_panels - b + G - 1) / G : 0;   // panels b, b + G, ...
@@ -314,8 +326,17 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs g) {
     fw1[0] = *(lds_frag_t)(size_t)(w1);
     // the first two DMA instructions go out while the first fragments are on their way from the LDS (their issue back-pressure
     // and the LDS latency overlap instead of adding up); the others follow groups 0, 1, 2
+#if FFN_PINGPONG
+    // SIMD partners take turns (qkv_attn_fused.hip): waves 0-3 issue their whole DMA share in front of their MFMA groups, waves 4-7 (raised
+    // priority, FFN_PRIO 1) multiply first and issue behind them
+    if (w < 4) {
+#pragma unroll
+      for (int k = 0; k < 5; ++k) dma(k);
+    }
+#else
 #pragma unroll
     for (int k = 0; k < FFN_DMA_EARLY; ++k) dma(k);
+#endif
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
@@ -325,11 +346,20 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs g) {
       }
 #pragma unroll
       for (int m = 0; m < 2; ++m) mma(kind_tag, acc[i][m], fw0[i & 1], fw1[i & 1], fa0[m], fa1[m], scale);
+#if !FFN_PINGPONG
       dma(i + FFN_DMA_EARLY);
+#endif
       valu(i);
       mark(i);
       __builtin_amdgcn_sched_barrier(0);
     }
+#if FFN_PINGPONG
+    if (w >= 4) {
+#pragma unroll
+      for (int k = 0; k < 5; ++k) dma(k);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#endif
   };
   // The hidden images of block j of a chunk: blocks 0 and 2 in the dedicated area, block 1 in the activation parts of ring
   // slots 0 and 1 (idle between the last fc1 stage and the prefetch of the next chunk's first stages at positions 34 / 35), so

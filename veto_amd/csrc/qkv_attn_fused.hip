@@ -71,6 +71,13 @@
 // column blocks of the two wave columns: 0 = contiguous halves (wn = 0: q and the first part of k), 1 = interleaved (wave column wn owns the
 // blocks 2 n + wn: both columns hold a share of q, k AND v, so the row writes of the attention phase are spread over all eight waves --
 // measured 1.340-1.347 against 1.325-1.338 ms: the unbalanced row writes are not what the phase waits for)
+// wave priority in the main loop: 1 = the upper half (which multiplies first and issues its DMA share behind its MFMA groups) runs at priority 1,
+// i.e. wins the matrix pipe of its SIMD whenever both partners want it: it is through with its MFMAs early and its DMA issue falls under the
+// lower half's matrix work instead of behind the stage (1.27-1.29 -> 1.21-1.24 ms; level 3 equal; priority only while it multiplies 1.25; kept
+// through the attention phase 1.25); 2 = the lower half raised instead (null: 1.28); 0 = no priorities
+#ifndef QA_PRIO
+#define QA_PRIO 1
+#endif
 #ifndef QA_COL_INTERLEAVE
 #define QA_COL_INTERLEAVE 0
 #endif
@@ -306,7 +313,7 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_fused_kernel(QkvAttnArgs g) {
     const int slot16 = ((l & 7) ^ ((r16 >> 1) & 7)) << 4;                // source-side swizzle (the LDS side is lane-linear)
     return (unsigned)((first_row + rr) * kRowB + slot16);
   };
-  constexpr int NPA = (APIECES - kASplit + 3) / 4, NPW = (G::WPIECES + 3) / 4;      // pieces per wave at most
+  constexpr int NPA = ((APIECES - kASplit > kASplit ? APIECES - kASplit : kASplit) + 3) / 4, NPW = (G::WPIECES + 3) / 4;      // pieces per wave at most (either half)
   const int n_acts = a_end - a_begin > wl ? (a_end - a_begin - wl + 3) / 4 : 0;
   const int n_weights = lower ? (G::WPIECES - wl + 3) / 4 : 0;
   struct TileSrc {
@@ -507,6 +514,11 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_fused_kernel(QkvAttnArgs g) {
       QACC(s_wait, t3, t0); QACC(s_bar1, t1, t3); QACC(s_main, t2, t1);
     };
     static_assert(kStages % 6 == 0, "the stage loop is unrolled over the 2 x 3 image indices");
+#if QA_PRIO == 1
+    if (!lower) __builtin_amdgcn_s_setprio(1);
+#elif QA_PRIO == 2
+    if (lower) __builtin_amdgcn_s_setprio(1);
+#endif
     for (int s = 0; s < kStages; s += 6) {
       stage(Tag<0>(), Tag<0>(), Tag<0>(), s);
       stage(Tag<1>(), Tag<1>(), Tag<1 % NWB>(), s + 1);
@@ -517,6 +529,9 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_fused_kernel(QkvAttnArgs g) {
     }
 
     // ---- attention phase -----------------------------------------------------------------------------------------------------------
+#if QA_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
     QST(t0);
 #ifdef VETO_QA_STAMPS
     unsigned long long t_att = t0;
