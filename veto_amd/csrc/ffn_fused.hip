@@ -73,6 +73,9 @@
 #ifndef FFN_PRIO
 #define FFN_PRIO 0
 #endif
+#ifndef FFN_NT
+#define FFN_NT 0
+#endif
 #ifndef FFN_PINGPONG
 #define FFN_PINGPONG 0
 #endif
@@ -483,7 +486,13 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs g) {
 #pragma unroll
           for (int t = 0; t < 3; ++t)
 #pragma unroll
-            for (int i = 0; i < 6; ++i) *(f32x4*)(op + t * FC + (i >> 1) * 64 + (i & 1) * 16) = acc2[t][i][m];
+            for (int i = 0; i < 6; ++i) {
+#if FFN_NT & 1
+              __builtin_nontemporal_store(acc2[t][i][m], (f32x4*)(op + t * FC + (i >> 1) * 64 + (i & 1) * 16));
+#else
+              *(f32x4*)(op + t * FC + (i >> 1) * 64 + (i & 1) * 16) = acc2[t][i][m];
+#endif
+            }
         }
       }
     }
@@ -555,8 +564,16 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs g) {
             u32x2 h, xy;
             mixed_pack4(y, h, xy);
             if (row0 + m * 16 < g.M) {
+#if FFN_NT & 2
+              if constexpr (!MID) {
+                __builtin_nontemporal_store(h, (gu32x2_t*)(lrow[m] + mixed_h_offset(cofs)));
+                __builtin_nontemporal_store(xy, (gu32x2_t*)(lrow[m] + mixed_x_offset(cofs)));
+              } else
+#endif
+              {
               *(gu32x2_t*)(lrow[m] + mixed_h_offset(cofs)) = h;       // (col0 < 48 is a multiple of 4 and cofs % 64 is 0 or 16: both byte
               *(gu32x2_t*)(lrow[m] + mixed_x_offset(cofs)) = xy;      // offsets of column col0 + cofs are those of cofs plus 2 col0)
+              }
             }
           }
         }
