@@ -604,7 +604,11 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs g) {
             int row = panel * FR + wm * 32 + m * 16 + r;
             if (row >= g.M) row = g.M - 1;          // clamp: rows past the end are never stored
             if (FFN_ABLATE & 256) acc2[t][i][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+#if FFN_NT & 4
+            else acc2[t][i][m] = __builtin_nontemporal_load((const f32x4*)(g.resid + (size_t)row * g.ldr + wn * 32 + q * 4 + t * FC + (i >> 1) * 64 + (i & 1) * 16));
+#else
             else acc2[t][i][m] = *(const f32x4*)(g.resid + (size_t)row * g.ldr + wn * 32 + q * 4 + t * FC + (i >> 1) * 64 + (i & 1) * 16);
+#endif
           }
       if (it == 0) {
         if (FFN_ABLATE & 256) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
