@@ -119,6 +119,11 @@ __device__ __forceinline__ void glds16(const char* base, unsigned voff, unsigned
   if (FFN_ABLATE & 1) return;
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_addr), "v"(voff), "s"(base) : "memory");
 }
+// the same for rows that are read exactly once (the attention output rows of the out projection): non-temporal
+__device__ __forceinline__ void glds16_nt(const char* base, unsigned voff, unsigned lds_addr) {
+  if (FFN_ABLATE & 1) return;
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %1, %2 nt" ::"s"(lds_addr), "v"(voff), "s"(base) : "memory");
+}
 __device__ __forceinline__ void wg_barrier() {
   asm volatile("" ::: "memory");
   __builtin_amdgcn_s_barrier();
@@ -237,7 +242,11 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs g) {
   auto issue_out = [&](const char* a_panel, int ks, int t, int slot, int k) {
     const int kw = t == 0 ? k - 2 : k;
     if ((FFN_ABLATE & 32) && (ks & 1) && (t == 0 ? (k == 1 || k == 4) : k == 2)) return;
+#if FFN_NT & 8
+    if (t == 0 && k < 2) glds16_nt(a_panel + ks * 128 + k * 64 * kRow1, voff1, lds0 + w * 1024 + k * 8 * 1024);
+#else
     if (t == 0 && k < 2) glds16(a_panel + ks * 128 + k * 64 * kRow1, voff1, lds0 + w * 1024 + k * 8 * 1024);
+#endif
     else if (kw >= 0 && kw < 3)
       glds16(w_out + (size_t)t * ((size_t)FC * kRow1) + ks * 128 + kw * 64 * kRow1, voff1, lds0 + slot * kSlot + kAB + w * 1024 + kw * 8 * 1024);
   };
