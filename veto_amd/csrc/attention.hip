@@ -108,6 +108,8 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a, int dh, int 
 }
 
 typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef short att_s16x4 __attribute__((ext_vector_type(4)));
+typedef short att_s16x8 __attribute__((ext_vector_type(8)));
 
 // TAB: layer 0 in the per-object form -- q / k / v of the 16 patch tokens never exist in memory: their chunks are formed on load
 // from the two per-object table rows (L2 / Infinity Cache), the row's rstd and c2 (AttnArgs::sw ...).  (Giving each XCD a
@@ -128,27 +130,28 @@ template <int DH, bool TAB = false, bool F24 = false>
 __global__ __launch_bounds__(128, TAB && (!TAB_SPLIT_LOADS || DH > 72) ? 2 : 3) void attention_mfma_kernel(AttnArgs a) {
   static_assert(!(TAB && F24), "the per-object form reads fp32 tables");
   saturating_conversions_on();   // (the mixed-row output path converts without clamps, common.h)
-  constexpr int DHP = (DH + 15) / 16 * 16;  // contraction extent of QK^T (zero padded)
-  constexpr int RB = DHP * 2;               // bytes per row of the Q / K images (bf16)
+  constexpr int KS = (DH + 15) / 16;        // k-steps of QK^T (the upper half of the last one may lie behind the row: masked in registers)
+  // bytes per row of the Q / K / V images (bf16; round 5: no contraction padding).  The pitch decides the bank conflicts of the fragment reads
+  // (ds_read_b128: 16 rows per lane group, bank = (a / 4) mod 64): 144 B (DH = 72) puts the 16 rows of a group on 16 different bank quadruples;
+  // round 4's 160 B (rows padded to 80 values) put them on 8, and 192 B (DH = 96) on 4: 16 bytes of padding there.
+  constexpr int RB = DH * 2 + (DH % 32 == 0 ? 16 : 0);
   constexpr int NT = (DH + 31) / 32;        // 32-wide output tiles of PV
-  constexpr int VROW = 40;                  // bytes per row of the transposed V image: 20 keys (19 + one zero)
   constexpr int QK_PLANE = kTokens * RB;
-  // LDS of a wave, in two phases (round 4): the four Q / K images; then, once S^T = K Q^T has been issued, the two transposed V
-  // images and the fp32 output rows OVER them (V waits in registers meanwhile).  12 160 B instead of 19 840 B per wave at DH = 72,
-  // 14 976 B instead of 22 272 B at DH = 96: the kernel is bound by the bytes it has in flight (measured at DH = 72 by padding the LDS:
-  // 4 / 6 / 8 waves per CU = 2.55 / 1.97 / 1.72 ms for the step's three launches; nothing beyond 8), and the six-head configuration
-  // (DH = 96: the reference's shipped architecture) went from 6 to 10 waves per CU with this layout.  A V^T plane holds DH rows; the
-  // MFMA tiles cover NT * 32 output columns: the lanes of columns >= DH re-read row 0 (their results are dropped, and a contraction
-  // never mixes columns).  (The table form of layer 0 keeps 2 waves per SIMD: at 3 it
-  // spills, and the spill costs more than the occupancy gives.)
-  constexpr int VT_PLANE = DH * VROW;
+  // LDS of a wave, in two phases (round 4): the four Q / K images; then, once S^T = K Q^T has been issued, the two V images and the fp32
+  // output rows OVER them (V waits in registers meanwhile): the kernel is bound by the bytes it has in flight (measured at DH = 72 by padding
+  // the LDS: 4 / 6 / 8 waves per CU = 2.55 / 1.97 / 1.72 ms for the step's three launches; nothing beyond 8).  Round 5: V is stored ROW-MAJOR
+  // like Q and K (20 rows: row 19 is zero and stands in for keys 19..31) and read as the B operand of P V through ds_read_b64_tr_b16 in the
+  // key order an accumulator-operand has (the scheme of qkv_attn_fused.hip).  Rounds 1-4 scattered a TRANSPOSED image with 16 two-byte
+  // stores per chunk whose stride (320 B) put the lanes of a store on two banks: 54 % of the kernel's LDS cycles were bank conflicts
+  // (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE, profiles/r05_d_pmc_write.txt).
+  constexpr int V_PLANE = (kTokens + 1) * RB;
   constexpr int O_BYTES = kTokens * DH * 4;
-  constexpr int PHASE2 = 2 * VT_PLANE + O_BYTES;
-  constexpr int WAVE_LDS = (4 * QK_PLANE > PHASE2 ? 4 * QK_PLANE : PHASE2) + 15 & ~15;
+  constexpr int PHASE2 = 2 * V_PLANE + O_BYTES;
+  constexpr int WAVE_LDS = ((4 * QK_PLANE > PHASE2 ? 4 * QK_PLANE : PHASE2) + 64 + 15) & ~15;      // (+64: over-reads behind the last row stay inside)
   constexpr int CH = DH / 8;                // 8-element chunks per row
   constexpr int PER_MAT = kTokens * CH;
   constexpr int ROUNDS = (3 * PER_MAT + 63) / 64;
-  static_assert(DH % 8 == 0 && QK_PLANE % 16 == 0 && VT_PLANE % 16 == 0, "layout");
+  static_assert(DH % 8 == 0 && QK_PLANE % 16 == 0 && V_PLANE % 16 == 0, "layout");
   __shared__ __attribute__((aligned(16))) char smem[2 * WAVE_LDS];
 
   // A wave works on its own LDS region: no workgroup barrier anywhere (LDS operations of one wave complete in order; the two
@@ -163,8 +166,8 @@ __global__ __launch_bounds__(128, TAB && (!TAB_SPLIT_LOADS || DH > 72) ? 2 : 3) 
   char* q_lo = base + QK_PLANE;
   char* k_hi = base + 2 * QK_PLANE;
   char* k_lo = base + 3 * QK_PLANE;
-  char* vt_hi = base;                  // (second phase)
-  char* vt_lo = vt_hi + VT_PLANE;
+  char* v_hi = base;                   // (second phase)
+  char* v_lo = v_hi + V_PLANE;
 
   // ---- global -> registers (all loads in flight), then -> bf16 hi/lo LDS images ----------------
   f32x4 ld[ROUNDS][2];
@@ -253,23 +256,14 @@ __global__ __launch_bounds__(128, TAB && (!TAB_SPLIT_LOADS || DH > 72) ? 2 : 3) 
         *(bf16x8*)dst = hi;
         *(bf16x8*)(dst + QK_PLANE) = lo;
       } else {
-#pragma unroll
-        for (int t = 0; t < 8; ++t) {
-          *(__bf16*)(vt_hi + (c * 8 + t) * VROW + i * 2) = hi[t];
-          *(__bf16*)(vt_lo + (c * 8 + t) * VROW + i * 2) = lo[t];
-        }
+        char* dst = v_hi + i * RB + c * 16;
+        *(bf16x8*)dst = hi;
+        *(bf16x8*)(dst + V_PLANE) = lo;
       }
     }
   };
   convert(IntTag<0>());
   att_static_for<kLateFrom, ROUNDS>(load_round);      // (TAB: the V-only rounds; in flight under S^T)
-  if (DHP > DH) {  // zero the contraction padding of the Q / K rows
-    for (int idx = lane; idx < 4 * kTokens; idx += 64) {
-      char* dst = base + (idx / kTokens) * QK_PLANE + (idx % kTokens) * RB + DH * 2;
-#pragma unroll
-      for (int t = 0; t < (DHP - DH) / 2; ++t) *(uint32_t*)(dst + 4 * t) = 0u;
-    }
-  }
 
   // ---- S^T = K Q^T: row = key j, column = query i ----------------------------------------------
   const int r = lane & 31, h = lane >> 5;
@@ -278,10 +272,14 @@ __global__ __launch_bounds__(128, TAB && (!TAB_SPLIT_LOADS || DH > 72) ? 2 : 3) 
 #pragma unroll
   for (int t = 0; t < 16; ++t) st[t] = 0.f;
 #pragma unroll
-  for (int s = 0; s < DHP / 16; ++s) {
+  for (int s = 0; s < KS; ++s) {
     const int off = rr * RB + (16 * s + 8 * h) * 2;
-    const bf16x8 kh = *(const bf16x8*)(k_hi + off), kl = *(const bf16x8*)(k_lo + off);
-    const bf16x8 qh = *(const bf16x8*)(q_hi + off), ql = *(const bf16x8*)(q_lo + off);
+    bf16x8 kh = *(const bf16x8*)(k_hi + off), kl = *(const bf16x8*)(k_lo + off);
+    bf16x8 qh = *(const bf16x8*)(q_hi + off), ql = *(const bf16x8*)(q_lo + off);
+    if (16 * s + 8 >= DH) {      // the upper half of the last k-step lies behind the row: zeros (both operands: 0 x NaN is NaN)
+      const bf16x8 z = __builtin_bit_cast(bf16x8, u32x4{0u, 0u, 0u, 0u});
+      if (h) { kh = z; kl = z; qh = z; ql = z; }
+    }
     st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl, qh, st, 0, 0, 0);
     st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, ql, st, 0, 0, 0);
     st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qh, st, 0, 0, 0);
@@ -318,48 +316,51 @@ __global__ __launch_bounds__(128, TAB && (!TAB_SPLIT_LOADS || DH > 72) ? 2 : 3) 
   // ---- the V^T images over the Q / K images: every ds_read of those has returned (each was waited for in front of its MFMA, and a
   // wave's LDS operations complete in order)
   convert(IntTag<1>());
-  for (int d = lane; d < DH; d += 64) {  // key 19 of every V^T row is a finite zero
-    *(uint16_t*)(vt_hi + d * VROW + 38) = 0;
-    *(uint16_t*)(vt_lo + d * VROW + 38) = 0;
+  if (lane < 2 * (RB / 16)) {       // image row 19: the zero row (keys 19..31)
+    const int pln = lane >= RB / 16;
+    *(u32x4*)(base + pln * V_PLANE + kTokens * RB + (lane - pln * (RB / 16)) * 16) = u32x4{0u, 0u, 0u, 0u};
   }
 
-  // ---- O = P V: A operand = P^T accumulators; element e of k-step s is key 16s + 8(e>>2) + 4h + (e&3)
-  float* o_lds = (float*)(base + 2 * VT_PLANE);  // [19][DH] fp32, behind the V^T images
-  const bf16x4 z4 = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
-#pragma unroll
-  for (int n = 0; n < NT; ++n) {
-    const int d = 32 * n + r;
-    const int dv = d < DH ? d : 0;   // V^T row this lane reads: output columns >= DH are dropped below; their lanes re-read row 0 instead of
-                                     // whatever lies behind the plane (never-initialised bytes, possibly NaN / Inf patterns)
-    f32x16 o;
-#pragma unroll
-    for (int t = 0; t < 16; ++t) o[t] = 0.f;
+  // ---- O = P V: A operand = P^T accumulators, whose element e of k-step s is key 16 s + 8 (e >> 2) + 4 h + (e & 3); the B operand is read
+  // in that order from the row-major V images (transposed reads: lane 16 g + 4 q + p supplies row q of the 4, 8-byte piece p)
+  float* o_lds = (float*)(base + 2 * V_PLANE);  // [19][DH] fp32, behind the V images
+  {
+    const int g4 = lane >> 4, tq = (lane >> 2) & 3, tp = lane & 3;
+    int trow[2][2];
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      bf16x4 h0, h1, l0, l1;
-      if (s == 0) {
-        h0 = *(const bf16x4*)(vt_hi + dv * VROW + 8 * h);
-        h1 = *(const bf16x4*)(vt_hi + dv * VROW + 16 + 8 * h);
-        l0 = *(const bf16x4*)(vt_lo + dv * VROW + 8 * h);
-        l1 = *(const bf16x4*)(vt_lo + dv * VROW + 16 + 8 * h);
-      } else {  // keys 16..19 live in lane half 0; everything else of this k-step is padding
-        h0 = *(const bf16x4*)(vt_hi + dv * VROW + 32);
-        l0 = *(const bf16x4*)(vt_lo + dv * VROW + 32);
-        if (h) { h0 = z4; l0 = z4; }
-        h1 = z4;
-        l1 = z4;
-      }
-      const bf16x8 vh = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
-      const bf16x8 vl = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
-      o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pl[s], vh, o, 0, 0, 0);
-      o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ph[s], vl, o, 0, 0, 0);
-      o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ph[s], vh, o, 0, 0, 0);
+      const int ta0 = 16 * s + 4 * h + tq, ta1 = ta0 + 8;
+      trow[s][0] = (ta0 < kTokens ? ta0 : kTokens) * RB + (16 * (g4 & 1) + 4 * tp) * 2;
+      trow[s][1] = (ta1 < kTokens ? ta1 : kTokens) * RB + (16 * (g4 & 1) + 4 * tp) * 2;
     }
-    if (d < DH) {
+    auto tr_pair = [](const char* p0, const char* p1) {
+      const att_s16x4 x = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) att_s16x4*)p0);
+      const att_s16x4 y = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) att_s16x4*)p1);
+      return __builtin_bit_cast(bf16x8, (att_s16x8)__builtin_shufflevector(x, y, 0, 1, 2, 3, 4, 5, 6, 7));
+    };
 #pragma unroll
-      for (int t = 0; t < 16; ++t) {
-        const int i = (t & 3) + 8 * (t >> 2) + 4 * h;
-        if (i < kTokens) o_lds[i * DH + d] = o[t];
+    for (int n = 0; n < NT; ++n) {
+      const int d = 32 * n + r;
+      f32x16 o;
+#pragma unroll
+      for (int t = 0; t < 16; ++t) o[t] = 0.f;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const bf16x8 vh = tr_pair(v_hi + trow[s][0] + 64 * n, v_hi + trow[s][1] + 64 * n);
+        const bf16x8 vl = tr_pair(v_lo + trow[s][0] + 64 * n, v_lo + trow[s][1] + 64 * n);
+        o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pl[s], vh, o, 0, 0, 0);
+        o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ph[s], vl, o, 0, 0, 0);
+        o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ph[s], vh, o, 0, 0, 0);
+      }
+      // register t holds query (t & 3) + 8 (t >> 2) + 4 h: t < 8 always a token, t = 8..10 only in the lower half wave (16..18), t >= 11 never
+      if (32 * n + 32 <= DH || d < DH) {
+        float* op = o_lds + 4 * h * DH + d;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) op[((t & 3) + 8 * (t >> 2)) * DH] = o[t];
+        if (!h) {
+#pragma unroll
+          for (int t = 8; t < 11; ++t) op[((t & 3) + 8 * (t >> 2)) * DH] = o[t];
+        }
       }
     }
   }

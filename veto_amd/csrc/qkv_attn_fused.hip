@@ -117,7 +117,9 @@ struct Geo {
   static constexpr int w_buf(int j) { return j < 2 ? kABytes + j * kPair : 2 * kPair; }
   // attention regions (one per wave; two phases as in attention_mfma_kernel): the four Q / K images, then V hi / lo (20 rows: row 19 is
   // zero and stands in for keys 19..31) + fp32 output rows
-  static constexpr int QP = DH * 2;                           // bytes per image row (no contraction padding: masked in registers)
+  // bytes per image row (no contraction padding: masked in registers).  A pitch that is a multiple of 64 bytes puts the 16 rows a half wave
+  // writes or reads on only 4 bank groups: six heads (192 B) get 16 bytes of padding (1.35 -> 1.22 ms per launch)
+  static constexpr int QP = DH * 2 + (DH % 32 == 0 ? 16 : 0);
   static constexpr int PLANE = kTokens * QP;
   static constexpr int VPLANE = (kTokens + 1) * QP;
   static constexpr int PH1 = 4 * PLANE, PH2 = 2 * VPLANE + kTokens * DH * 4;
@@ -125,7 +127,11 @@ struct Geo {
   static constexpr int kScratch = (kLdsTotal - 8 * REGION) & ~15;   // the regions end at the end of the LDS
   static constexpr bool kFreeW0 = kScratch >= kPair;          // the first weight image stays free during the attention phase
   static_assert(DH % 8 == 0 && NWB * kWBytes + 2 * kABytes <= kLdsTotal, "LDS budget");
-  static_assert(kScratch >= kABytes, "the first activation image stays free during the attention phase");
+  // pieces (8 rows) of the first activation image that stay free during the attention phase: the next tile's stage 0 lands there meanwhile;
+  // the pieces behind them (six heads: the last two, 2 KiB) are issued behind the attention phase like the first weight image
+  static constexpr int kAFree = kScratch >= kABytes ? APIECES : kScratch / 1024;
+  static_assert(kScratch % 1024 == 0 || kScratch >= kABytes, "the regions start on a piece boundary");
+  static_assert(kAFree >= APIECES - 4, "only a few pieces of the next tile's first stage wait for the attention phase");
   static_assert(a_buf(1) + (MB * 4) * 2048 <= kLdsTotal, "the dummy row block of wm = 3 reads inside the LDS");
 };
 
@@ -328,12 +334,17 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_fused_kernel(QkvAttnArgs g) {
     return t;
   };
   // this wave's share of stage s of a tile: activation rows into image `buf` (0 / 1) / weight rows into image `buf` (0 .. NWB - 1)
-  auto issue_acts = [&](const TileSrc& t, int s, int buf) {
+  // (p_lo, p_hi: only the pieces p_lo <= p < p_hi -- all of them but for the next tile's stage 0 around the attention phase, see kAFree)
+  auto issue_acts = [&](const TileSrc& t, int s, int buf, int p_lo = 0, int p_hi = APIECES) {
     const unsigned voff_a = piece_voff(lane_now(), wl * 8);
+    int issued = 0;
 #pragma unroll
     for (int k = 0; k < NPA; ++k)
-      if (a_begin + wl + 4 * k < a_end)
+      if (a_begin + wl + 4 * k < a_end && a_begin + wl + 4 * k >= p_lo && a_begin + wl + 4 * k < p_hi) {
+        ++issued;
         glds16(t.a + (size_t)(a_begin * 8 + 32 * k) * kRowB + s * 128, voff_a, lds0 + buf * G::kPair + (a_begin + wl + 4 * k) * 1024);
+      }
+    return issued;      // (wave-uniform)
   };
   auto issue_weights = [&](const TileSrc& t, int s, int buf) {
     if (!lower) return;
@@ -443,6 +454,8 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_fused_kernel(QkvAttnArgs g) {
       const TileSrc& ta = sa2 < kStages ? src : src_next;
       const TileSrc& tw = sw2 < kStages ? src : src_next;
       const int st_a = sa2 < kStages ? sa2 : 0, st_w = sw2 < kStages ? sw2 : 0;
+      const int a_limit = sa2 < kStages ? APIECES : G::kAFree;      // the next tile's stage 0: only the pieces the attention regions leave free
+      int n_issued = 0;                                             // this wave's activation instructions of this interval
       constexpr int wb2 = NWB == 3 ? (WB == 0 ? 2 : WB - 1) : (WB ^ 1);      // (s + 2) % 3 / (s + 1) % 2
       int a_lo, a_hi, w_lo, w_hi;      // LDS byte offsets of this lane's first activation / weight fragment: first and second 64-byte half
       if constexpr (kRederive) {
@@ -487,7 +500,7 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_fused_kernel(QkvAttnArgs g) {
           QACC(s_frag, t4, t1); QACC(s_bar2, t5, t4);
         }
         if (do_w) issue_weights(tw, st_w, wb2);
-        if (do_a) issue_acts(ta, st_a, AB);
+        if (do_a) n_issued = issue_acts(ta, st_a, AB, 0, a_limit);
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -508,8 +521,8 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_fused_kernel(QkvAttnArgs g) {
           QACC(s_bar2, t5, t4);
         }
       }
-      if (!lower && do_a) issue_acts(ta, st_a, AB);
-      younger = (do_a ? n_acts : 0) + (NWB == 3 && do_w ? n_weights : 0);
+      if (!lower && do_a) n_issued = issue_acts(ta, st_a, AB, 0, a_limit);
+      younger = n_issued + (NWB == 3 && do_w ? n_weights : 0);
       QST(t2);
       QACC(s_wait, t3, t0); QACC(s_bar1, t1, t3); QACC(s_main, t2, t1);
     };
@@ -746,11 +759,12 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_fused_kernel(QkvAttnArgs g) {
     if (has_next) {
       // the stages of the next tile that had to wait for the regions: stage 0's weight rows where the regions reach into the first weight
       // image (then interval 0 waits for them), stage 1 (NWB == 2: its weight rows go out in interval 0 like every W(s + 1))
+      if (G::kAFree < APIECES) issue_acts(src_next, 0, 0, G::kAFree, APIECES);      // (older than every stage-1 piece below)
       if (!G::kFreeW0) issue_weights(src_next, 0, 0);
       if (NWB == 3) issue_weights(src_next, 1, 1);
       issue_acts(src_next, 1, 1);
       younger = n_acts + (NWB == 3 ? n_weights : 0);
-      stage0_landed = G::kFreeW0;     // (waited for in front of the attention phase; else interval 0 waits with `younger`)
+      stage0_landed = G::kFreeW0 && G::kAFree == APIECES;     // (waited for in front of the attention phase; else interval 0 waits with `younger`)
     }
     QST(t1);
     QACC(s_att, t1, t0);
