@@ -78,6 +78,12 @@
 #ifndef QA_PRIO
 #define QA_PRIO 1
 #endif
+// row blocks of the four wave rows and the pairs of a batch: 1 = wave row wm owns the blocks wm, wm + 4, ... and batch bt holds the pairs 8 bt .. 8 bt + 7
+// (a block's rows then belong to ONE batch, but for the block that holds the batch boundary: 20 block visits of row writes per tile instead of 26, all eight
+// waves in every batch); 0 = contiguous blocks 5 wm .., pairs alternating between the batches two by two
+#ifndef QA_ROW_INTERLEAVE
+#define QA_ROW_INTERLEAVE 1
+#endif
 #ifndef QA_COL_INTERLEAVE
 #define QA_COL_INTERLEAVE 0
 #endif
@@ -277,6 +283,7 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_fused_kernel(QkvAttnArgs g) {
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = w & 3, wn = w >> 2;
   constexpr int kColBase = QA_COL_INTERLEAVE ? 2048 : NB * 2048, kColStep = QA_COL_INTERLEAVE ? 4096 : 2048;   // LDS bytes: wave column, block n -> n + 1
+  constexpr int kRowBase = QA_ROW_INTERLEAVE ? 2048 : MB * 2048, kRowStep = QA_ROW_INTERLEAVE ? 4 * 2048 : 2048;   // the same for the wave rows: block m -> m + 1
   const int b = blockIdx.x;
   const int H = g.heads;
   const int groups = (g.n_pair + TP - 1) / TP;
@@ -369,7 +376,7 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_fused_kernel(QkvAttnArgs g) {
     const int fo0 = fr0 * 128 + ((fq0 ^ ((fr0 >> 1) & 7)) << 4);
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      ab_[i] = G::a_buf(i) + (wm * MB) * 2048 + fo0;
+      ab_[i] = G::a_buf(i) + wm * kRowBase + fo0;
       ab64_[i] = ab_[i] ^ 64;
     }
 #pragma unroll
@@ -462,7 +469,7 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_fused_kernel(QkvAttnArgs g) {
         const int lane_s = lane_now();
         const int fr = lane_s & 15, fq = lane_s >> 4;
         const int frag_off = fr * 128 + ((fq ^ ((fr >> 1) & 7)) << 4);
-        a_lo = G::a_buf(AB) + (wm * MB) * 2048 + frag_off;
+        a_lo = G::a_buf(AB) + wm * kRowBase + frag_off;
         w_lo = G::w_buf(WB) + wn * kColBase + frag_off;
         a_hi = a_lo ^ 64;
         w_hi = w_lo ^ 64;
@@ -479,8 +486,8 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_fused_kernel(QkvAttnArgs g) {
       } else {
 #pragma unroll
       for (int m = 0; m < MB; ++m) {
-        fa0[m] = *(const i32x4*)(smem + a_lo + m * 2048);
-        fa1[m] = *(const i32x4*)(smem + a_hi + m * 2048);
+        fa0[m] = *(const i32x4*)(smem + a_lo + m * kRowStep);
+        fa1[m] = *(const i32x4*)(smem + a_hi + m * kRowStep);
       }
 #pragma unroll
       for (int i = 0; i < WBUF - 1; ++i) {
@@ -574,11 +581,12 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_fused_kernel(QkvAttnArgs g) {
     char* const region = smem + G::kScratch + w * G::REGION;
 #pragma unroll 1
     for (int bt = 0; bt < ((QA_ABLATE & 2) ? 0 : 2); ++bt) {
-      const int my_pair = group * TP + 4 * (w >> 1) + 2 * bt + (w & 1);     // the pair whose attention this wave runs in this batch
+      const int my_pair = group * TP + (QA_ROW_INTERLEAVE ? 8 * bt + w : 4 * (w >> 1) + 2 * bt + (w & 1));     // the pair whose attention this wave runs in this batch
       const bool active = my_pair < g.n_pair;
       // -- the owners write the batch's rows: lane (fr, fq) of block (n, m) holds token row 16 (5 wm + m) + fr, columns 16 (NB wn + n) + 4 fq ..
       // of q | k | v.  PHASE 0: the Q / K images (hi, lo planes); PHASE 1: the V images.  Everything but the row part of the address
       // is a compile-time constant per (wn, n): the stores carry it in their offset field.
+      auto batch_of = [](int pr) { return QA_ROW_INTERLEAVE ? pr >> 3 : (pr >> 1) & 1; };     // batch of pair pr of the tile
       auto write_rows = [&](auto wn_tag, auto phase_tag) {
         constexpr int WN = decltype(wn_tag)::value, PHASE = decltype(phase_tag)::value;
         constexpr int LO = PHASE == 0 ? G::PLANE : G::VPLANE;                  // distance hi plane -> lo plane
@@ -589,13 +597,13 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_fused_kernel(QkvAttnArgs g) {
         const int fr_w = lane_w & 15, fq_w = lane_w >> 4;
 #pragma unroll
         for (int m = 0; m < MB; ++m) {
-          const int r0 = 16 * (wm * MB + m);                                   // wave-uniform: skip blocks without a row of this batch
+          const int r0 = 16 * (QA_ROW_INTERLEAVE ? wm + 4 * m : wm * MB + m);  // wave-uniform: skip blocks without a row of this batch
           const int pa = (r0 * 27) >> 9, pb = ((r0 + 15) * 27) >> 9;           // (r / 19 for r < 513)
-          if (r0 >= TM || !((((pa >> 1) & 1) == bt) || (((pb >> 1) & 1) == bt))) continue;
+          if (r0 >= TM || !(batch_of(pa) == bt || batch_of(pb) == bt)) continue;
           const int r = r0 + fr_w;
           const int p = (r * 27) >> 9, t = r - 19 * p;                         // pair inside the tile, token
-          const bool mine = r < TM && ((p >> 1) & 1) == bt;
-          char* const rowp = smem + G::kScratch + (((p >> 2) << 1) | (p & 1)) * G::REGION + t * G::QP + 8 * fq_w;
+          const bool mine = r < TM && batch_of(p) == bt;
+          char* const rowp = smem + G::kScratch + (QA_ROW_INTERLEAVE ? p & 7 : ((p >> 2) << 1) | (p & 1)) * G::REGION + t * G::QP + 8 * fq_w;
           if (mine) {
             static_for_n<NB>([&](auto n_tag) {
               constexpr int n = decltype(n_tag)::value;
