@@ -123,11 +123,15 @@ __device__ __forceinline__ void att_static_for(F&& f) {
     att_static_for<I + 1, N>(f);
   }
 }
+// waves (= items) per workgroup of attention_mfma_kernel
+#ifndef ATT_WPB
+#define ATT_WPB 2
+#endif
 #ifndef TAB_SPLIT_LOADS
 #define TAB_SPLIT_LOADS 1      // 0: every chunk of the table form requested up front (round 4; two waves per SIMD)
 #endif
 template <int DH, bool TAB = false, bool F24 = false>
-__global__ __launch_bounds__(128, TAB && (!TAB_SPLIT_LOADS || DH > 72) ? 2 : 3) void attention_mfma_kernel(AttnArgs a) {
+__global__ __launch_bounds__(64 * ATT_WPB, TAB && (!TAB_SPLIT_LOADS || DH > 72) ? 2 : 3) void attention_mfma_kernel(AttnArgs a) {
   static_assert(!(TAB && F24), "the per-object form reads fp32 tables");
   saturating_conversions_on();   // (the mixed-row output path converts without clamps, common.h)
   constexpr int KS = (DH + 15) / 16;        // k-steps of QK^T (the upper half of the last one may lie behind the row: masked in registers)
@@ -152,14 +156,16 @@ __global__ __launch_bounds__(128, TAB && (!TAB_SPLIT_LOADS || DH > 72) ? 2 : 3) 
   constexpr int PER_MAT = kTokens * CH;
   constexpr int ROUNDS = (3 * PER_MAT + 63) / 64;
   static_assert(DH % 8 == 0 && QK_PLANE % 16 == 0 && V_PLANE % 16 == 0, "layout");
-  __shared__ __attribute__((aligned(16))) char smem[2 * WAVE_LDS];
+  __shared__ __attribute__((aligned(16))) char smem[ATT_WPB * WAVE_LDS];
 
   // A wave works on its own LDS region: no workgroup barrier anywhere (LDS operations of one wave complete in order; the two
   // barriers of the first version cost 3 % of the launch).  Every wave has ONE item (persistent waves that prefetch their next
   // item's operands were measured 13 % slower: the dispatcher's refill of finished workgroups spreads the memory phases better
   // than waves that march in step).
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const long item = (long)blockIdx.x * 2 + w;
+  // (the wave index as a SCALAR: item, pair, head and the table rows of the pair's objects are then wave-uniform to the compiler -- scalar loads of the
+  // indices, SGPR base + 32-bit lane offset for every gather instead of 64-bit vector address arithmetic per load)
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const long item = (long)blockIdx.x * ATT_WPB + w;
   if (item >= (long)a.n_pair * a.heads) return;
   char* base = smem + w * WAVE_LDS;
   char* q_hi = base;
@@ -191,12 +197,13 @@ __global__ __launch_bounds__(128, TAB && (!TAB_SPLIT_LOADS || DH > 72) ? 2 : 3) 
     const int mat = e / PER_MAT, rem = e % PER_MAT, i = rem / CH, c = rem % CH;
     const bool need = e < 3 * PER_MAT && !(a.cls_only && mat == 0 && i > 0);
     if (TAB && need && i >= 1 && i <= kPatchTokens) {
-      const size_t off = (size_t)(i - 1) * (3 * kDim) + mat * kDim + c * 8;
-      ld[r][0] = *(const f32x4*)(tab_s + off);
-      ld[r][1] = *(const f32x4*)(tab_s + off + 4);
-      ldb[TAB ? r : 0][0] = *(const f32x4*)(tab_o + off);
-      ldb[TAB ? r : 0][1] = *(const f32x4*)(tab_o + off + 4);
-      rs[TAB ? r : 0] = a.stats[((size_t)pair * kTokens + i) * 2 + 1];
+      // (32-bit byte offsets from wave-uniform bases: the saddr form of the loads, no 64-bit vector arithmetic)
+      const unsigned off = (unsigned)(((i - 1) * (3 * kDim) + mat * kDim + c * 8) * 4);
+      ld[r][0] = *(const f32x4*)((const char*)tab_s + off);
+      ld[r][1] = *(const f32x4*)((const char*)tab_s + off + 16u);
+      ldb[TAB ? r : 0][0] = *(const f32x4*)((const char*)tab_o + off);
+      ldb[TAB ? r : 0][1] = *(const f32x4*)((const char*)tab_o + off + 16u);
+      rs[TAB ? r : 0] = *(const float*)((const char*)(a.stats + (size_t)pair * kTokens * 2 + 1) + (unsigned)(i * 8));
     } else if (F24 && need) {
       // (the six dwords are kept packed in ld[r][0] / the first half of ld[r][1] until the conversion below)
       const char* src = (const char*)a.qkv + (((size_t)pair * kTokens + i) * (3 * kDim) + mat * kDim + head * DH + c * 8) * 3;
@@ -208,10 +215,10 @@ __global__ __launch_bounds__(128, TAB && (!TAB_SPLIT_LOADS || DH > 72) ? 2 : 3) 
       ld[r][0] = f32x4{__uint_as_float(d01[0]), __uint_as_float(d01[1]), __uint_as_float(d01[2]), __uint_as_float(d01[3])};
       ld[r][1] = f32x4{__uint_as_float(d2[0]), __uint_as_float(d2[1]), 0.f, 0.f};
     } else if (need) {
-      const float* src = TAB && i == 0 ? a.vec + 2 * (3 * kDim) + head * DH + mat * kDim + c * 8
-                                       : src0 + (size_t)i * (3 * kDim) + mat * kDim + c * 8;
-      ld[r][0] = *(const f32x4*)src;
-      ld[r][1] = *(const f32x4*)(src + 4);
+      const unsigned off = (unsigned)((mat * kDim + c * 8) * 4) + (TAB && i == 0 ? 0u : (unsigned)(i * (3 * kDim) * 4));
+      const char* src = TAB && i == 0 ? (const char*)(a.vec + 2 * (3 * kDim) + head * DH) : (const char*)src0;
+      ld[r][0] = *(const f32x4*)(src + off);
+      ld[r][1] = *(const f32x4*)(src + off + 16u);
     } else {
       ld[r][0] = f32x4{0.f, 0.f, 0.f, 0.f};
       ld[r][1] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -841,16 +848,16 @@ hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
   const int dh = kDim / a.heads;
   if (dh == 72 || dh == 96) {
     const long items = (long)a.n_pair * a.heads;
-    unsigned blocks = (unsigned)((items + 1) / 2);
+    unsigned blocks = (unsigned)((items + ATT_WPB - 1) / ATT_WPB);
     if (a.sw) {
       if (!a.ow || !a.stats || !a.vec || !a.subj || !a.obj || a.cls_only) return hipErrorInvalidValue;
-      if (dh == 72) VETO_LAUNCH((attention_mfma_kernel<72, true>), dim3(blocks), dim3(128), 0, s, a);
-      else VETO_LAUNCH((attention_mfma_kernel<96, true>), dim3(blocks), dim3(128), 0, s, a);
+      if (dh == 72) VETO_LAUNCH((attention_mfma_kernel<72, true>), dim3(blocks), dim3(64 * ATT_WPB), 0, s, a);
+      else VETO_LAUNCH((attention_mfma_kernel<96, true>), dim3(blocks), dim3(64 * ATT_WPB), 0, s, a);
     } else if (a.qkv_f24) {
-      if (dh == 72) VETO_LAUNCH((attention_mfma_kernel<72, false, true>), dim3(blocks), dim3(128), 0, s, a);
-      else VETO_LAUNCH((attention_mfma_kernel<96, false, true>), dim3(blocks), dim3(128), 0, s, a);
-    } else if (dh == 72) VETO_LAUNCH(attention_mfma_kernel<72>, dim3(blocks), dim3(128), 0, s, a);
-    else VETO_LAUNCH(attention_mfma_kernel<96>, dim3(blocks), dim3(128), 0, s, a);
+      if (dh == 72) VETO_LAUNCH((attention_mfma_kernel<72, false, true>), dim3(blocks), dim3(64 * ATT_WPB), 0, s, a);
+      else VETO_LAUNCH((attention_mfma_kernel<96, false, true>), dim3(blocks), dim3(64 * ATT_WPB), 0, s, a);
+    } else if (dh == 72) VETO_LAUNCH(attention_mfma_kernel<72>, dim3(blocks), dim3(64 * ATT_WPB), 0, s, a);
+    else VETO_LAUNCH(attention_mfma_kernel<96>, dim3(blocks), dim3(64 * ATT_WPB), 0, s, a);
     return hipGetLastError();
   }
   if (a.sw || a.qkv_f24) return hipErrorInvalidValue;
