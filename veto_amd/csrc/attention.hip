@@ -381,7 +381,7 @@ __global__ __launch_bounds__(64 * ATT_WPB, TAB && (!TAB_SPLIT_LOADS || DH > 72) 
     const f32x4 v1 = *(const f32x4*)(o_lds + i * DH + c * 8 + 4);
     const size_t row = a.cls_only ? (size_t)pair : (size_t)pair * kTokens + i;
     if (a.o_fmt == FMT_MIXED) {   // wave-uniform
-      store_act8_mixed(a.o + row * (2 * kDim), head * DH + c * 8, v0, v1);
+      store_act8_mixed<ACT8_NT != 0>(a.o + row * (2 * kDim), head * DH + c * 8, v0, v1);
       continue;
     }
     bf16x8 hi, lo;

@@ -193,21 +193,20 @@ __device__ __forceinline__ f32x4 unpack_f24x4(uint32_t d0, uint32_t d1, uint32_t
 }
 
 // 8 consecutive columns (col % 8 == 0) of a mixed activation row: two 16-byte stores
-#ifndef ACT8_NT
-#define ACT8_NT 0
-#endif
+// NT: non-temporal stores (rows that are next read a launch or more later: DESIGN.md section 7.4, cache policy)
+template <bool NT = false>
 __device__ __forceinline__ void store_act8_mixed(__bf16* row, int col, f32x4 v0, f32x4 v1) {
   char* base = (char*)row;
   u32x2 h0, h1, xy0, xy1;
   mixed_pack4(v0, h0, xy0);
   mixed_pack4(v1, h1, xy1);
-#if ACT8_NT
-  __builtin_nontemporal_store(u32x4{h0[0], h0[1], h1[0], h1[1]}, (u32x4*)(base + mixed_h_offset(col)));
-  __builtin_nontemporal_store(u32x4{xy0[0], xy0[1], xy1[0], xy1[1]}, (u32x4*)(base + mixed_x_offset(col)));
-#else
-  *(u32x4*)(base + mixed_h_offset(col)) = u32x4{h0[0], h0[1], h1[0], h1[1]};
-  *(u32x4*)(base + mixed_x_offset(col)) = u32x4{xy0[0], xy0[1], xy1[0], xy1[1]};
-#endif
+  if constexpr (NT) {
+    __builtin_nontemporal_store(u32x4{h0[0], h0[1], h1[0], h1[1]}, (u32x4*)(base + mixed_h_offset(col)));
+    __builtin_nontemporal_store(u32x4{xy0[0], xy0[1], xy1[0], xy1[1]}, (u32x4*)(base + mixed_x_offset(col)));
+  } else {
+    *(u32x4*)(base + mixed_h_offset(col)) = u32x4{h0[0], h0[1], h1[0], h1[1]};
+    *(u32x4*)(base + mixed_x_offset(col)) = u32x4{xy0[0], xy0[1], xy1[0], xy1[1]};
+  }
 }
 
 __device__ __forceinline__ float wave_sum(float v) {
