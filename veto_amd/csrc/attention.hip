@@ -108,6 +108,40 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a, int dh, int 
 }
 
 typedef __attribute__((ext_vector_type(16))) float f32x16;
+// Two fp32 values -> packed 16-bit hi and lo parts, x ~= hi + lo: the operand planes of the attention products (three MFMA terms hi hi + hi lo + lo hi).
+// ATT_F16_SPLIT (round 5, as qkv_attn_fused.hip): fp16 hi (11 significant bits) + fp16 lo, 22 bits in all, FOUR vector instructions per value pair
+// (v_cvt_pk_f16_f32, two v_fma_mix_f32 that read the packed halves in place, v_cvt_pk_f16_f32); q / k / v are O(10) (LayerNorm'ed rows times weights), far
+// inside the fp16 range (the conversions saturate: MODE.FP16_OVFL is set), a lo part below 2^-24 is lost -- less than a bf16 lo keeps of such a value.
+// 0: bf16 hi + bf16 lo (16 bits, six instructions; rounds 1-4).
+#ifndef ATT_F16_SPLIT
+#define ATT_F16_SPLIT 1
+#endif
+__device__ __forceinline__ void att_split2(float a, float b, uint32_t& hi, uint32_t& lo) {
+#if ATT_F16_SPLIT
+  uint32_t h, l;
+  float l0, l1;
+  asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(h) : "v"(a), "v"(b));      // (volatile: reads MODE, see mixed_pack4 in common.h)
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l0) : "v"(h), "v"(a));
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(l1) : "v"(h), "v"(b));
+  asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(l) : "v"(l0), "v"(l1));
+  hi = h;
+  lo = l;
+#else
+  __bf16 h0, l0, h1, l1;
+  split_bf16(a, h0, l0);
+  split_bf16(b, h1, l1);
+  hi = (uint32_t)__builtin_bit_cast(unsigned short, h0) | ((uint32_t)__builtin_bit_cast(unsigned short, h1) << 16);
+  lo = (uint32_t)__builtin_bit_cast(unsigned short, l0) | ((uint32_t)__builtin_bit_cast(unsigned short, l1) << 16);
+#endif
+}
+typedef _Float16 att_f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f32x16 att_mfma(const u32x4& a, const u32x4& b, const f32x16& c) {
+#if ATT_F16_SPLIT
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(att_f16x8, a), __builtin_bit_cast(att_f16x8, b), c, 0, 0, 0);
+#else
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+#endif
+}
 typedef short att_s16x4 __attribute__((ext_vector_type(4)));
 typedef short att_s16x8 __attribute__((ext_vector_type(8)));
 
@@ -250,22 +284,20 @@ __global__ __launch_bounds__(64 * ATT_WPB, TAB && (!TAB_SPLIT_LOADS || DH > 72) 
         v0 = unpack_f24x4(__float_as_uint(ld[r][0][0]), __float_as_uint(ld[r][0][1]), __float_as_uint(ld[r][0][2]));
         v1 = unpack_f24x4(__float_as_uint(ld[r][0][3]), __float_as_uint(ld[r][1][0]), __float_as_uint(ld[r][1][1]));
       }
-      bf16x8 hi, lo;
-#pragma unroll
-      for (int t = 0; t < 8; ++t) {
-        __bf16 hh, ll;
-        split_bf16(t < 4 ? v0[t & 3] : v1[t & 3], hh, ll);
-        hi[t] = hh;
-        lo[t] = ll;
-      }
+      uint32_t h4[4], l4[4];
+      att_split2(v0[0], v0[1], h4[0], l4[0]);
+      att_split2(v0[2], v0[3], h4[1], l4[1]);
+      att_split2(v1[0], v1[1], h4[2], l4[2]);
+      att_split2(v1[2], v1[3], h4[3], l4[3]);
+      const u32x4 hi = {h4[0], h4[1], h4[2], h4[3]}, lo = {l4[0], l4[1], l4[2], l4[3]};
       if (PHASE == 0) {
         char* dst = (mat == 0 ? q_hi : k_hi) + i * RB + c * 16;
-        *(bf16x8*)dst = hi;
-        *(bf16x8*)(dst + QK_PLANE) = lo;
+        *(u32x4*)dst = hi;
+        *(u32x4*)(dst + QK_PLANE) = lo;
       } else {
         char* dst = v_hi + i * RB + c * 16;
-        *(bf16x8*)dst = hi;
-        *(bf16x8*)(dst + V_PLANE) = lo;
+        *(u32x4*)dst = hi;
+        *(u32x4*)(dst + V_PLANE) = lo;
       }
     }
   };
@@ -281,15 +313,15 @@ __global__ __launch_bounds__(64 * ATT_WPB, TAB && (!TAB_SPLIT_LOADS || DH > 72) 
 #pragma unroll
   for (int s = 0; s < KS; ++s) {
     const int off = rr * RB + (16 * s + 8 * h) * 2;
-    bf16x8 kh = *(const bf16x8*)(k_hi + off), kl = *(const bf16x8*)(k_lo + off);
-    bf16x8 qh = *(const bf16x8*)(q_hi + off), ql = *(const bf16x8*)(q_lo + off);
+    u32x4 kh = *(const u32x4*)(k_hi + off), kl = *(const u32x4*)(k_lo + off);
+    u32x4 qh = *(const u32x4*)(q_hi + off), ql = *(const u32x4*)(q_lo + off);
     if (16 * s + 8 >= DH) {      // the upper half of the last k-step lies behind the row: zeros (both operands: 0 x NaN is NaN)
-      const bf16x8 z = __builtin_bit_cast(bf16x8, u32x4{0u, 0u, 0u, 0u});
+      const u32x4 z = {0u, 0u, 0u, 0u};
       if (h) { kh = z; kl = z; qh = z; ql = z; }
     }
-    st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl, qh, st, 0, 0, 0);
-    st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, ql, st, 0, 0, 0);
-    st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qh, st, 0, 0, 0);
+    st = att_mfma(kl, qh, st);
+    st = att_mfma(kh, ql, st);
+    st = att_mfma(kh, qh, st);
   }
 
   // ---- softmax over the keys of query (lane & 31): 16 registers here + 16 in lane ^ 32 ---------
@@ -311,13 +343,13 @@ __global__ __launch_bounds__(64 * ATT_WPB, TAB && (!TAB_SPLIT_LOADS || DH > 72) 
   }
   sum += __shfl_xor(sum, 32, 64);
   const float inv = 1.f / sum;
-  bf16x8 ph[2], pl[2];
+  u32x4 ph[2], pl[2];
 #pragma unroll
-  for (int t = 0; t < 16; ++t) {
-    __bf16 hh, ll;
-    split_bf16(p[t] * inv, hh, ll);
-    ph[t >> 3][t & 7] = hh;
-    pl[t >> 3][t & 7] = ll;
+  for (int t = 0; t < 16; t += 2) {
+    uint32_t h2, l2;
+    att_split2(p[t] * inv, p[t + 1] * inv, h2, l2);
+    ph[t >> 3][(t & 7) >> 1] = h2;      // (constant indices: the loop is unrolled)
+    pl[t >> 3][(t & 7) >> 1] = l2;
   }
 
   // ---- the V^T images over the Q / K images: every ds_read of those has returned (each was waited for in front of its MFMA, and a
@@ -343,7 +375,7 @@ __global__ __launch_bounds__(64 * ATT_WPB, TAB && (!TAB_SPLIT_LOADS || DH > 72) 
     auto tr_pair = [](const char* p0, const char* p1) {
       const att_s16x4 x = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) att_s16x4*)p0);
       const att_s16x4 y = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) att_s16x4*)p1);
-      return __builtin_bit_cast(bf16x8, (att_s16x8)__builtin_shufflevector(x, y, 0, 1, 2, 3, 4, 5, 6, 7));
+      return __builtin_bit_cast(u32x4, (att_s16x8)__builtin_shufflevector(x, y, 0, 1, 2, 3, 4, 5, 6, 7));
     };
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
@@ -353,11 +385,11 @@ __global__ __launch_bounds__(64 * ATT_WPB, TAB && (!TAB_SPLIT_LOADS || DH > 72) 
       for (int t = 0; t < 16; ++t) o[t] = 0.f;
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
-        const bf16x8 vh = tr_pair(v_hi + trow[s][0] + 64 * n, v_hi + trow[s][1] + 64 * n);
-        const bf16x8 vl = tr_pair(v_lo + trow[s][0] + 64 * n, v_lo + trow[s][1] + 64 * n);
-        o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pl[s], vh, o, 0, 0, 0);
-        o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ph[s], vl, o, 0, 0, 0);
-        o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ph[s], vh, o, 0, 0, 0);
+        const u32x4 vh = tr_pair(v_hi + trow[s][0] + 64 * n, v_hi + trow[s][1] + 64 * n);
+        const u32x4 vl = tr_pair(v_lo + trow[s][0] + 64 * n, v_lo + trow[s][1] + 64 * n);
+        o = att_mfma(pl[s], vh, o);
+        o = att_mfma(ph[s], vl, o);
+        o = att_mfma(ph[s], vh, o);
       }
       // register t holds query (t & 3) + 8 (t >> 2) + 4 h: t < 8 always a token, t = 8..10 only in the lower half wave (16..18), t >= 11 never
       if (32 * n + 32 <= DH || d < DH) {
