@@ -84,6 +84,9 @@
 #ifndef QA_ROW_INTERLEAVE
 #define QA_ROW_INTERLEAVE 1
 #endif
+#ifndef QA_PITCH_PAD
+#define QA_PITCH_PAD 16
+#endif
 #ifndef QA_COL_INTERLEAVE
 #define QA_COL_INTERLEAVE 0
 #endif
@@ -125,7 +128,7 @@ struct Geo {
   // zero and stands in for keys 19..31) + fp32 output rows
   // bytes per image row (no contraction padding: masked in registers).  A pitch that is a multiple of 64 bytes puts the 16 rows a half wave
   // writes or reads on only 4 bank groups: six heads (192 B) get 16 bytes of padding (1.35 -> 1.22 ms per launch)
-  static constexpr int QP = DH * 2 + (DH % 32 == 0 ? 16 : 0);
+  static constexpr int QP = DH * 2 + (DH % 32 == 0 ? QA_PITCH_PAD : 0);
   static constexpr int PLANE = kTokens * QP;
   static constexpr int VPLANE = (kTokens + 1) * QP;
   static constexpr int PH1 = 4 * PLANE, PH2 = 2 * VPLANE + kTokens * DH * 4;
