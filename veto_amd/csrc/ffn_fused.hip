@@ -79,6 +79,13 @@
 #ifndef FFN_PINGPONG
 #define FFN_PINGPONG 0
 #endif
+// TIMING PROBE (results are WRONG): the correction stages of the FeedForward (fc1, fc2; not the out projection) as block-scaled fp6
+// (e2m3) operands -- the K = 128 MFMA in its fp6 form (6 registers per operand, half the cycles of the e4m3 form), 96 instead of 128 bytes
+// of every row per correction stage through the LDS-DMA (12 + 18 instead of 16 + 24 pieces of an fc1 stage, 18 instead of 24 of an fc2
+// sub-stage), plus stand-ins for the block-scale traffic (3 / 1 small DMA instructions per stage, three scale reads per stage and wave)
+#ifndef FFN_FP6_PROBE
+#define FFN_FP6_PROBE 0
+#endif
 
 namespace veto {
 
@@ -225,6 +232,16 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs g) {
     if (c & 1) ks = 2 * (8 - (ks >> 1)) + (ks & 1);
 #endif
     const unsigned dst = lds0 + slot * kSlot + w * 1024;
+#if FFN_FP6_PROBE
+    if (ks & 1) {
+      if (k == 1 && w >= 4) {      // (waves 4-6: the stand-in of a scale DMA: 2 x 256 B of activation scales, 1 KiB of weight scales)
+        if (w < 6) asm volatile("s_mov_b32 m0, %0\n\ts_nop 4\n\tglobal_load_lds_dword %1, %2" ::"s"(lds0 + slot * kSlot + 12288 + (w - 4) * 256), "v"((unsigned)(lane_now() * 4)), "s"(a_panel) : "memory");
+        else if (w == 6) glds16(g.w1, (unsigned)(lane_now() * 16), lds0 + slot * kSlot + kAB + 18432);
+        return;
+      }
+      if (k == 4 && w >= 2) return;
+    }
+#endif
     if ((FFN_ABLATE & 32) && (ks & 1) && (k == 1 || k == 4)) return;
     if ((FFN_ABLATE & 128) && (ks & 1) && k == 1) return;   // (the activation half of ablation 32 alone)
     if (k < 2) glds16(a_panel + ks * 128 + k * 64 * kRow1, voff1, dst + k * 8 * 1024);
@@ -233,6 +250,12 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs g) {
   // instruction k (of 3) of an fc2 sub-stage: 24 KiB of W2 rows (column third t, 128-byte slice `slice` of the row)
   auto issue_fc2 = [&](int slice, int t, int slot, int k) {
     const unsigned dst = lds0 + slot * kSlot + w * 1024 + kAB;
+#if FFN_FP6_PROBE
+    if ((slice & 1) && k == 2 && w >= 2) {
+      if (w == 7) glds16(g.w2, (unsigned)(lane_now() * 16), lds0 + slot * kSlot + kAB + 18432);
+      return;
+    }
+#endif
     if ((FFN_ABLATE & 32) && (slice & 1) && k == 2) return;
     glds16(g.w2 + (size_t)t * ((size_t)FC * kRow2) + slice * 128 + (size_t)k * 64 * kRow2, voff2, dst + k * 8 * 1024);
   };
@@ -271,13 +294,17 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs g) {
   //  * the first VALU / LDS read of an accumulator behind its last MFMA: mfma_drain*() below, tied to those accumulators;
   //  * an accumulator chain needs none; operands come from ds_read (waited for through the register dependency).
   // tools/audit_ffn_asm.py checks the generated code for compiler instructions that touch accumulator registers near an MFMA.
-  auto mma = [&](auto kind_tag, f32x4& acc, const i32x4& fw0, const i32x4& fw1, const i32x4& fa0, const i32x4& fa1, int scale) {
+  auto mma = [&](auto kind_tag, f32x4& acc, const i32x4& fw0, const i32x4& fw1, const i32x4& fa0, const i32x4& fa1, int scale, int scale_b = 0x7f7f7f7f) {
     constexpr int KIND = decltype(kind_tag)::value;
     if (FFN_ABLATE & 2) {
       asm volatile("" : "+v"(acc) : "v"(fw0), "v"(fw1), "v"(fa0), "v"(fa1));
       return;
     }
-    if constexpr (KIND == 0) {
+    if constexpr (KIND == 2) {      // (FFN_FP6_PROBE) the fp6 form: 24 bytes per operand and lane
+      typedef int i32x6 __attribute__((ext_vector_type(6)));
+      const i32x6 w6 = __builtin_shufflevector(fw0, fw1, 0, 1, 2, 3, 4, 5), a6 = __builtin_shufflevector(fa0, fa1, 0, 1, 2, 3, 4, 5);
+      asm(FFN_MMA_NOP "v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0] cbsz:2 blgp:2" : "+v"(acc) : "v"(w6), "v"(a6), "v"(scale), "v"(scale_b));
+    } else if constexpr (KIND == 0) {
       asm(FFN_MMA_NOP "v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(fw0), "v"(fa0));
       asm(FFN_MMA_NOP "v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(fw1), "v"(fa1));
     } else {
@@ -310,6 +337,25 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs g) {
     const unsigned a0 = lds0 + AB + wm * 4096 + fo, a1 = lds0 + AB + wm * 4096 + (fo ^ 64);
     const unsigned w0 = lds0 + SB + kAB + wn * 4096 + fo, w1 = lds0 + SB + kAB + wn * 4096 + (fo ^ 64);
     i32x4 fw0[2], fw1[2];
+    typedef __attribute__((address_space(3))) u32x2 lds_u32x2_t;
+    constexpr int KIND_S = decltype(kind_tag)::value;
+    // second half of a fragment: 16 bytes, or (fp6 probe) 8
+    auto half2 = [&](unsigned addr) {
+      if constexpr (KIND_S == 2) {
+        const u32x2 v = *(const lds_u32x2_t*)(size_t)addr;
+        i32x4 r;
+        r[0] = (int)v[0]; r[1] = (int)v[1];
+        return r;
+      } else {
+        return (i32x4)*(lds_frag_t)(size_t)addr;
+      }
+    };
+    int scale_a = 0x7f7f7f7f;
+    if constexpr (KIND_S == 2) {     // stand-ins of the block-scale reads: one dword of activation scales, one of weight scales per lane
+      typedef __attribute__((address_space(3))) int lds_int_t;
+      scale_a = *(const lds_int_t*)(size_t)(lds0 + SB + 12288 + (fo & 0xffc));
+      scale = *(const lds_int_t*)(size_t)(lds0 + SB + kAB + 18432 + (fo & 0xffc));
+    }
     if (FFN_ABLATE & 4) {
 #pragma unroll
       for (int m = 0; m < 2; ++m) {
@@ -331,11 +377,11 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs g) {
 #pragma unroll
       for (int m = 0; m < 2; ++m) {
         fa0[m] = *(lds_frag_t)(size_t)(a0 + m * 2048);
-        fa1[m] = *(lds_frag_t)(size_t)(a1 + m * 2048);
+        fa1[m] = half2(a1 + m * 2048);
       }
     }
     fw0[0] = *(lds_frag_t)(size_t)(w0);
-    fw1[0] = *(lds_frag_t)(size_t)(w1);
+    fw1[0] = half2(w1);
     // the first two DMA instructions go out while the first fragments are on their way from the LDS (their issue back-pressure
     // and the LDS latency overlap instead of adding up); the others follow groups 0, 1, 2
 #if FFN_PINGPONG
@@ -354,10 +400,10 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs g) {
     for (int i = 0; i < 6; ++i) {
       if (i < 5) {
         fw0[(i + 1) & 1] = *(lds_frag_t)(size_t)(w0 + ((i + 1) >> 1) * 8192 + ((i + 1) & 1) * 2048);
-        fw1[(i + 1) & 1] = *(lds_frag_t)(size_t)(w1 + ((i + 1) >> 1) * 8192 + ((i + 1) & 1) * 2048);
+        fw1[(i + 1) & 1] = half2(w1 + ((i + 1) >> 1) * 8192 + ((i + 1) & 1) * 2048);
       }
 #pragma unroll
-      for (int m = 0; m < 2; ++m) mma(kind_tag, acc[i][m], fw0[i & 1], fw1[i & 1], fa0[m], fa1[m], scale);
+      for (int m = 0; m < 2; ++m) mma(kind_tag, acc[i][m], fw0[i & 1], fw1[i & 1], fa0[m], fa1[m], scale, scale_a);
 #if !FFN_PINGPONG
       dma(i + FFN_DMA_EARLY);
 #endif
@@ -715,7 +761,19 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs g) {
         else if (P == kPer - 1) {
           if (stream_ends) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-        } else if (P + 1 < kS1) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        }
+#if FFN_FP6_PROBE
+        // (this wave's DMA instructions of stage P + 1 -- fewer in a correction stage, and they differ per wave)
+        else if (P + 1 < kS1 && ((P + 1) & 1)) {
+          if (w < 2) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+          else if (w < 7) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        } else if (P + 1 >= kS1 && ((P + 1 - kS1) % 6) >= 3) {
+          if (w < 2 || w == 7) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        }
+#endif
+        else if (P + 1 < kS1) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
         if (P >= kS1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's hidden-image stores are in the LDS
         STAMP(t1);
@@ -741,7 +799,7 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs g) {
         constexpr int SB = (P % kRing) * kSlot;
         auto mark = [&](int i) { (void)i; TL(P, 3 + i); };
         if constexpr (P < kS1) {
-          stage(Tag<P % 2>(), Tag<SB>(), Tag<SB>(), acc1, sc1, dma, Tag<0>(), fa0, fa1, [](int) {}, mark);
+          stage(Tag<(P % 2) * (FFN_FP6_PROBE ? 2 : 1)>(), Tag<SB>(), Tag<SB>(), acc1, sc1, dma, Tag<0>(), fa0, fa1, [](int) {}, mark);
         } else {
           // beside the MFMAs of sub-stages 0..3 of block J: bias + GELU + conversion of one (16 columns x 16 rows) unit of block
           // J + 1, a value per group, packed and stored in group 4
@@ -774,7 +832,7 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs g) {
               }
             }
           };
-          stage(Tag<KIND2>(), Tag<(KIND2 == 0 ? (J == 1 ? 0 : kHidOff) : (J == 1 ? kSlot : kHidOff + kAB))>(), Tag<SB>(), acc2[T], sc2, dma,
+          stage(Tag<KIND2 * (FFN_FP6_PROBE ? 2 : 1)>(), Tag<(KIND2 == 0 ? (J == 1 ? 0 : kHidOff) : (J == 1 ? kSlot : kHidOff + kAB))>(), Tag<SB>(), acc2[T], sc2, dma,
                 Tag<(T > 0)>(), fa0, fa1, valu, mark);
         }
         STAMP(t0);

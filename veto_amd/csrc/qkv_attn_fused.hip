@@ -90,6 +90,11 @@
 #ifndef QA_COL_INTERLEAVE
 #define QA_COL_INTERLEAVE 0
 #endif
+// TIMING PROBE (results are WRONG): the correction stages as block-scaled fp6 (e2m3) operands -- the K = 128 MFMA in its fp6 form, three
+// quarters of the pieces of a correction stage through the LDS-DMA, stand-ins for the block-scale traffic (ffn_fused.hip, FFN_FP6_PROBE)
+#ifndef QA_FP6_PROBE
+#define QA_FP6_PROBE 0
+#endif
 
 namespace veto {
 
@@ -348,25 +353,43 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_fused_kernel(QkvAttnArgs g) {
   auto issue_acts = [&](const TileSrc& t, int s, int buf, int p_lo = 0, int p_hi = APIECES) {
     const unsigned voff_a = piece_voff(lane_now(), wl * 8);
     int issued = 0;
+    int a_end_s = a_end;
+#if QA_FP6_PROBE
+    if (s & 1) a_end_s = a_begin + (a_end - a_begin) * 3 / 4;      // three quarters of this half's pieces
+#endif
 #pragma unroll
     for (int k = 0; k < NPA; ++k)
-      if (a_begin + wl + 4 * k < a_end && a_begin + wl + 4 * k >= p_lo && a_begin + wl + 4 * k < p_hi) {
+      if (a_begin + wl + 4 * k < a_end_s && a_begin + wl + 4 * k >= p_lo && a_begin + wl + 4 * k < p_hi) {
         ++issued;
         glds16(t.a + (size_t)(a_begin * 8 + 32 * k) * kRowB + s * 128, voff_a, lds0 + buf * G::kPair + (a_begin + wl + 4 * k) * 1024);
       }
+#if QA_FP6_PROBE
+    if ((s & 1) && (w == 0 || w >= 3) && p_lo == 0) {      // stand-ins of the scale DMAs: 5 x 256 B of activation scales, 1 KiB of weight scales
+      ++issued;
+      if (w == 0) glds16(t.w, (unsigned)(lane_now() * 16), lds0 + buf * G::kPair + 30720);
+      else asm volatile("s_mov_b32 m0, %0\n\ts_nop 4\n\tglobal_load_lds_dword %1, %2" ::"s"(lds0 + buf * G::kPair + 31744 + (w - 3) * 256), "v"((unsigned)(lane_now() * 4)), "s"(t.a) : "memory");
+    }
+#endif
     return issued;      // (wave-uniform)
   };
   auto issue_weights = [&](const TileSrc& t, int s, int buf) {
-    if (!lower) return;
+    if (!lower) return 0;
     const unsigned voff_w = piece_voff(lane_now(), 0);
+    int issued = 0;
+    int wp = G::WPIECES;
+#if QA_FP6_PROBE
+    if (s & 1) wp = G::WPIECES * 3 / 4;
+#endif
 #pragma unroll
     for (int k = 0; k < NPW; ++k) {
       const int c = wl + 4 * k;          // piece c of the head's q | k | v rows: matrix c / PM, rows 8 (c % PM) .. of that matrix's head slice
-      if (c < G::WPIECES) {
+      if (c < wp) {
+        ++issued;
         const int mat = c / G::PM, cm = c - mat * G::PM;
         glds16(t.w + (size_t)(mat * kDim + 8 * cm) * kRowB + s * 128, voff_w, lds0 + (buf < 2 ? kABytes + buf * G::kPair : 2 * G::kPair) + c * 1024);
       }
     }
+    return issued;
   };
 
   // Fragment addresses.  Eight heads: one base register per image and 64-byte half (ten registers), so that every fragment read of the main
@@ -432,13 +455,17 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_fused_kernel(QkvAttnArgs g) {
     // DMA queue (scratch traffic shares vmcnt).  The compiler then pads no MFMA hazard: `s_nop 1` opens every MFMA (operand written by a
     // vector instruction right in front of it), the first non-MFMA readers of the accumulators sit behind mfma_drain() below, and
     // veto_amd/asmcheck.py audits the generated code after every build.
-    auto mma = [&](auto kind_tag, f32x4& c, const i32x4& w0, const i32x4& w1, const i32x4& a0, const i32x4& a1, int scale) {
+    auto mma = [&](auto kind_tag, f32x4& c, const i32x4& w0, const i32x4& w1, const i32x4& a0, const i32x4& a1, int scale, int scale_b = 0x7f7f7f7f) {
       constexpr int KIND = decltype(kind_tag)::value;
       if (QA_ABLATE & 4) {
         asm volatile("" : "+v"(c) : "v"(w0), "v"(w1), "v"(a0), "v"(a1));
       } else if constexpr (KIND == 0) {
         asm(QA_MMA_NOP "v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(c) : "v"(w0), "v"(a0));
         asm(QA_MMA_NOP "v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(c) : "v"(w1), "v"(a1));
+      } else if constexpr (QA_FP6_PROBE != 0) {
+        typedef int i32x6 __attribute__((ext_vector_type(6)));
+        const i32x6 w6 = __builtin_shufflevector(w0, w1, 0, 1, 2, 3, 4, 5), a6 = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5);
+        asm(QA_MMA_NOP "v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0] cbsz:2 blgp:2" : "+v"(c) : "v"(w6), "v"(a6), "v"(scale), "v"(scale_b));
       } else {
         const i32x8 w8 = __builtin_shufflevector(w0, w1, 0, 1, 2, 3, 4, 5, 6, 7), a8 = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
         asm(QA_MMA_NOP "v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0]" : "+v"(c) : "v"(w8), "v"(a8), "v"(scale), "v"(0x7f7f7f7f));
@@ -466,6 +493,7 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_fused_kernel(QkvAttnArgs g) {
       const int st_a = sa2 < kStages ? sa2 : 0, st_w = sw2 < kStages ? sw2 : 0;
       const int a_limit = sa2 < kStages ? APIECES : G::kAFree;      // the next tile's stage 0: only the pieces the attention regions leave free
       int n_issued = 0;                                             // this wave's activation instructions of this interval
+      int n_w_issued = 0;
       constexpr int wb2 = NWB == 3 ? (WB == 0 ? 2 : WB - 1) : (WB ^ 1);      // (s + 2) % 3 / (s + 1) % 2
       int a_lo, a_hi, w_lo, w_hi;      // LDS byte offsets of this lane's first activation / weight fragment: first and second 64-byte half
       if constexpr (kRederive) {
@@ -481,6 +509,23 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_fused_kernel(QkvAttnArgs g) {
       }
       constexpr int WBUF = kRederive ? 2 : QA_WBUF;
       i32x4 fa0[MB], fa1[MB], fw0[WBUF], fw1[WBUF];
+      // second half of a fragment: 16 bytes, or (fp6 probe, correction stage) 8
+      auto half2 = [&](int off) {
+        if constexpr (QA_FP6_PROBE != 0 && KIND == 1) {
+          const u32x2 v = *(const u32x2*)(smem + off);
+          i32x4 r;
+          r[0] = (int)v[0]; r[1] = (int)v[1];
+          return r;
+        } else {
+          return *(const i32x4*)(smem + off);
+        }
+      };
+      int sc_w = mix_scale, sc_a = 0x7f7f7f7f;
+      if constexpr (QA_FP6_PROBE != 0 && KIND == 1) {      // stand-ins of the block-scale reads
+        const u32x2 sa2 = *(const u32x2*)(smem + G::a_buf(AB) + 30720 + ((a_lo * 2) & 0x3f8));
+        sc_w = *(const int*)(smem + G::a_buf(AB) + 31744 + (w_lo & 0x3fc));
+        sc_a = (int)(sa2[0] ^ sa2[1]);
+      }
       if (QA_ABLATE & 16) {
 #pragma unroll
         for (int m = 0; m < MB; ++m) { fa0[m] = fa1[m] = i32x4{0, 0, 0, 0}; asm volatile("" : "+v"(fa0[m]), "+v"(fa1[m])); }
@@ -490,12 +535,12 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_fused_kernel(QkvAttnArgs g) {
 #pragma unroll
       for (int m = 0; m < MB; ++m) {
         fa0[m] = *(const i32x4*)(smem + a_lo + m * kRowStep);
-        fa1[m] = *(const i32x4*)(smem + a_hi + m * kRowStep);
+        fa1[m] = half2(a_hi + m * kRowStep);
       }
 #pragma unroll
       for (int i = 0; i < WBUF - 1; ++i) {
         fw0[i] = *(const i32x4*)(smem + w_lo + i * kColStep);
-        fw1[i] = *(const i32x4*)(smem + w_hi + i * kColStep);
+        fw1[i] = half2(w_hi + i * kColStep);
       }
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -509,7 +554,7 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_fused_kernel(QkvAttnArgs g) {
           QST(t5);
           QACC(s_frag, t4, t1); QACC(s_bar2, t5, t4);
         }
-        if (do_w) issue_weights(tw, st_w, wb2);
+        if (do_w) n_w_issued = issue_weights(tw, st_w, wb2);
         if (do_a) n_issued = issue_acts(ta, st_a, AB, 0, a_limit);
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -517,10 +562,10 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_fused_kernel(QkvAttnArgs g) {
       for (int n = 0; n < NB; ++n) {
         if (n + WBUF - 1 < NB && !(QA_ABLATE & 16)) {
           fw0[(n + WBUF - 1) % WBUF] = *(const i32x4*)(smem + w_lo + (n + WBUF - 1) * kColStep);
-          fw1[(n + WBUF - 1) % WBUF] = *(const i32x4*)(smem + w_hi + (n + WBUF - 1) * kColStep);
+          fw1[(n + WBUF - 1) % WBUF] = half2(w_hi + (n + WBUF - 1) * kColStep);
         }
 #pragma unroll
-        for (int m = 0; m < MB; ++m) mma(kind_tag, acc[n][m], fw0[n % WBUF], fw1[n % WBUF], fa0[m], fa1[m], mix_scale);
+        for (int m = 0; m < MB; ++m) mma(kind_tag, acc[n][m], fw0[n % WBUF], fw1[n % WBUF], fa0[m], fa1[m], sc_w, sc_a);
         __builtin_amdgcn_sched_barrier(0);
         if (n == 0 && !lower && do_a) {
           // (the upper half joins the release barrier behind its first group: its fragments are in registers by then, and its matrix
@@ -532,7 +577,7 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_fused_kernel(QkvAttnArgs g) {
         }
       }
       if (!lower && do_a) n_issued = issue_acts(ta, st_a, AB, 0, a_limit);
-      younger = n_issued + (NWB == 3 && do_w ? n_weights : 0);
+      younger = n_issued + (NWB == 3 && do_w ? n_w_issued : 0);
       QST(t2);
       QACC(s_wait, t3, t0); QACC(s_bar1, t1, t3); QACC(s_main, t2, t1);
     };
