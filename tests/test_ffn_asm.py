@@ -19,7 +19,7 @@ def test_generated_code_of_the_panel_kernel_passes_its_audit(shipped):
     assert asmcheck.unpadded(shipped) == []
     assert asmcheck.m0_users(shipped) == []
     st = asmcheck.stats(shipped)
-    assert sorted(st) == [0, 1, 2]
+    assert sorted(st) == [0, 1, 2, 210, 211]      # (210 / 211: the layer tail on 3-byte residual rows in / in and out)
     for mode, k in st.items():
         assert k["scratch_ops"] == 0 and k["scratch_bytes"] == 0, (mode, k)
         assert k["vgprs"] is not None and k["vgprs"] <= asmcheck.MAX_VGPRS, (mode, k)
@@ -43,6 +43,8 @@ def test_generated_code_of_the_fused_qkv_attention_kernel_passes_its_audit(tmp_p
     k = st[72]      # the eight-head form (the default path): no scratch at all -- a reload inside the main loop drains the DMA queue
     assert k["scratch_ops"] == 0 and k["scratch_bytes"] == 0 and k["vgprs"] <= asmcheck.MAX_VGPRS and k["barriers"] >= 10, k
     assert st[96]["vgprs"] <= asmcheck.MAX_VGPRS
+    # the six-head form is allowed the spill it has today and no more (a reload inside the stage loop drains the wave's DMA queue)
+    assert st[96]["scratch_bytes"] <= 64 and st[96]["scratch_ops"] <= 13, st[96]
     assert asmcheck.problems(path, source=src, scratch_ok=(96,)) == []
     bad = asmcheck.compile_asm(str(tmp_path), extra_flags=["-DQA_NO_PADS"], source=src)
     assert len(asmcheck.unpadded(bad)) > 100

@@ -1046,14 +1046,17 @@ def test_restructured_first_and_last_layer_match_the_plain_path(tmp_path):
     # launch per panel phase
     variants = (("default", {}), ("plain", {"VETO_QKV0_TABLES": "0", "VETO_CLS_FOLD": "0"}),
                 ("round2-forms", {"VETO_FOLD_BLOCKS": "0", "VETO_QKV_F24": "0", "VETO_TAIL_FUSED": "0", "VETO_FFN_LATE": "0", "VETO_CLS_MFMA": "0"}),
-                ("two-launch-attention", {"VETO_QKV_ATTN_FUSED": "0"}))
+                ("two-launch-attention", {"VETO_QKV_ATTN_FUSED": "0"}),
+                # the residual stream between the layers as 3-byte floats (round 6: measured null, kept as a variant): a 16-bit significand
+                # in the stream itself, so it sits further from the default than the exact re-formulations above
+                ("x-f24", {"VETO_X_F24": "1"}))
     for tag, env in variants:
         path = str(tmp_path / (tag + ".npy"))
         subprocess.run([sys.executable, "-c", code, path], check=True, env=dict(os.environ, **env), timeout=600)
         outs.append(np.load(path))
     g, _, _ = load_golden("predcls_n36_l4h8")
-    for o in outs[1:]:
-        assert np.abs(outs[0] - o).max() < 1e-4
+    for (tag, _), o in zip(variants[1:], outs[1:]):
+        assert np.abs(outs[0] - o).max() < (3e-4 if tag == "x-f24" else 1e-4), tag
     for o in outs:
         assert np.abs(o - g["rel_dists"]).max() <= LOGIT_TOL
 

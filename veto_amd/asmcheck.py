@@ -32,7 +32,8 @@ def compile_asm(out_dir, extra_flags=(), source="ffn_fused.hip"):
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found")
     out = os.path.join(out_dir, os.path.splitext(source)[0] + ".s")
-    cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-S", "--cuda-device-only", "-Wno-unused-result", "-Wno-unused-value"]
+    from .build import FLAGS      # the flags the shipped objects are compiled with: the audited code is the shipped code
+    cmd = [hipcc] + list(FLAGS) + ["-S", "--cuda-device-only"]
     cmd += list(extra_flags) + [source, "-o", out]
     subprocess.run(cmd, cwd=CSRC, check=True)
     return out
@@ -167,15 +168,22 @@ def m0_users(path):
     return [text for text, inasm in _instructions(path) if not inasm and re.search(r"\bm0\b", text)]
 
 
-# source -> (kernel name pattern with the template argument as group 1, the instantiations that must be present)
-KERNELS = {"ffn_fused.hip": (r"ffn_fused_kernelILi(\d+)E", (0, 1, 2)),
-           "qkv_attn_fused.hip": (r"qkv_attn_fused_kernelILi(\d+)E", (72, 96))}
+# source -> (kernel name pattern: the integer template argument as group 1, the boolean ones behind it as group 2; the instantiations that
+# must be present).  An instantiation's key is its integer argument, with the boolean arguments appended as digits when any of them is set:
+# ffn_fused_kernel<2, true, true> (the layer tail on 3-byte residual rows) is 211, <2, false, false, true> (its single-pass form) 2001.
+KERNELS = {"ffn_fused.hip": (r"ffn_fused_kernelILi(\d+)E((?:Lb[01]E)*)", (0, 1, 2, 210, 211)),
+           "qkv_attn_fused.hip": (r"qkv_attn_fused_kernelILi(\d+)E((?:Lb[01]E)*)", (72, 96))}
+
+
+def _inst_key(m):
+    bools = re.findall(r"Lb([01])E", m.group(2) or "")
+    return int(m.group(1) + "".join(bools)) if "1" in bools else int(m.group(1))
 
 
 def stats(path, pattern=KERNELS["ffn_fused.hip"][0]):
     """{template argument: dict(barriers, scratch_ops, compiler_vmcnt_waits, vgprs, scratch_bytes, by_interval)} per kernel instantiation."""
     text = open(path).read().split("\n")
-    starts = [(i, re.search(pattern, l).group(1)) for i, l in enumerate(text)
+    starts = [(i, _inst_key(re.search(pattern, l))) for i, l in enumerate(text)
               if re.match(r"^_ZN4veto.*" + pattern + r".*:", l)]
     out = {}
     for i0, mode in starts:

@@ -3,6 +3,7 @@
 Every source is compiled to its own object (in parallel, cached by modification time under build/obj, which is neither tracked nor
 shipped) and the objects are linked into the one shared library the C ABI lives in."""
 import concurrent.futures
+import hashlib
 import os
 import shutil
 import subprocess
@@ -27,6 +28,15 @@ def _stale():
     return any(_mtime(f) > t for f in SOURCES + HEADERS)
 
 
+def _toolchain_stamp(hipcc):
+    """What the cached objects depend on besides their sources: the flags and the compiler."""
+    try:
+        version = subprocess.run([hipcc, "--version"], capture_output=True, text=True, check=True).stdout
+    except (OSError, subprocess.CalledProcessError):
+        version = "unknown"
+    return hashlib.sha256((" ".join(FLAGS) + "\n" + version).encode()).hexdigest()
+
+
 def build_native(force=False, verbose=False, jobs=None):
     """Compiles every HIP source for gfx950 into one shared library. Returns its path.  force=True recompiles every object."""
     if not force and not _stale():
@@ -36,6 +46,10 @@ def build_native(force=False, verbose=False, jobs=None):
         raise RuntimeError("hipcc not found; cannot build %s" % LIB)
     os.makedirs(OBJ, exist_ok=True)
     newest_header = max(_mtime(h) for h in HEADERS)
+    # objects of other flags or another compiler are stale whatever their age (tools/variants.sh writes its objects under other names)
+    stamp_file, stamp = os.path.join(OBJ, "toolchain.stamp"), _toolchain_stamp(hipcc)
+    if not os.path.exists(stamp_file) or open(stamp_file).read() != stamp:
+        force = True
 
     def compile_one(src):
         obj = os.path.join(OBJ, src + ".o")
@@ -49,6 +63,8 @@ def build_native(force=False, verbose=False, jobs=None):
 
     with concurrent.futures.ThreadPoolExecutor(max_workers=jobs or min(6, os.cpu_count() or 1)) as pool:
         objs = list(pool.map(compile_one, SOURCES))
+    with open(stamp_file, "w") as f:
+        f.write(stamp)
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
     if verbose:
         print(" ".join(cmd), flush=True)

@@ -174,7 +174,9 @@ __device__ __forceinline__ void static_for(F&& f) {
 // MODE 0: the FeedForward block.  MODE 1: the attention out projection + residual (+ LayerNorm2 epilogue) on the same skeleton: ONE
 // GEMM x <- x + a W^T + b with the [128 x 576] result in registers, 18 k-slices x 3 column thirds = 54 positions per panel, the
 // activation slice of a k-slice rides with its first third (always ring slot 0) and its fragments are held across the thirds.
-template <int MODE>
+// RF24 / OF24 (MODE 2): the residual rows come in / the result rows go out as 3-byte floats (common.h: rows of 576 * 3 bytes at g.resid /
+// g.out) -- the residual stream between the layers of the default path, a quarter fewer bytes in the two bursts of a panel boundary
+template <int MODE, bool RF24 = false, bool OF24 = false>
 __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs g) {
   saturating_conversions_on();   // (the hidden and LayerNorm conversions to mixed rows carry no clamps, common.h)
   __shared__ __attribute__((aligned(16))) char smem[kLds];
@@ -537,6 +539,15 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs g) {
       for (int m = 0; m < 2; ++m) {
         const int row = row0 + m * 16;
         if (row < g.M) {
+          if constexpr (OF24) {
+            // four columns = 12 bytes; the quad of lanes of a row stores 48 contiguous bytes.  The registers keep the fp32 values: the
+            // LayerNorm below normalises what the layer computed, the next layer's residual is what memory holds (rounded to 16 bits)
+            char* op = (char*)g.out + ((size_t)row * kDim + col0) * 3;
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+#pragma unroll
+              for (int i = 0; i < 6; ++i) *(u32x3*)(op + (t * FC + (i >> 1) * 64 + (i & 1) * 16) * 3) = pack_f24x4(acc2[t][i][m]);
+          } else {
           float* op = g.out + (size_t)row * g.ldo + col0;
 #pragma unroll
           for (int t = 0; t < 3; ++t)
@@ -548,6 +559,7 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs g) {
               *(f32x4*)(op + t * FC + (i >> 1) * 64 + (i & 1) * 16) = acc2[t][i][m];
 #endif
             }
+          }
         }
       }
     }
@@ -659,6 +671,10 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs g) {
             int row = panel * FR + wm * 32 + m * 16 + r;
             if (row >= g.M) row = g.M - 1;          // clamp: rows past the end are never stored
             if (FFN_ABLATE & 256) acc2[t][i][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+            else if constexpr (RF24) {
+              const u32x3 d = *(const u32x3*)((const char*)g.resid + ((size_t)row * kDim + wn * 32 + q * 4 + t * FC + (i >> 1) * 64 + (i & 1) * 16) * 3);
+              acc2[t][i][m] = unpack_f24x4(d[0], d[1], d[2]);
+            }
 #if FFN_NT & 4
             else acc2[t][i][m] = __builtin_nontemporal_load((const f32x4*)(g.resid + (size_t)row * g.ldr + wn * 32 + q * 4 + t * FC + (i >> 1) * 64 + (i & 1) * 16));
 #else
@@ -867,6 +883,8 @@ hipError_t launch_panel(FfnArgs g, int mode, hipStream_t s) {
   if (g.M <= 0 || !g.a || !g.w2 || !g.b2 || !g.resid || !g.out || !g.exp2) return hipErrorInvalidValue;
   if (mode != 1 && (!g.w1 || !g.b1 || !g.exp1)) return hipErrorInvalidValue;
   if (mode == 2 && (!g.wo || !g.bo || !g.expo || !g.lnm_w || !g.lnm_b || !g.ln_out)) return hipErrorInvalidValue;
+  if ((g.resid_f24 || g.out_f24) && (mode != 2 || !g.resid_f24)) return hipErrorInvalidValue;      // (3-byte rows: the layer tail only; never f32 in, 3 bytes out)
+  if (g.resid_f24 != g.out_f24 && (const void*)g.resid == (const void*)g.out) return hipErrorInvalidValue;   // (rows of different pitch cannot be rewritten in place)
   static int num_cu = 0;
   if (num_cu == 0) {
     int dev = 0;
@@ -881,6 +899,8 @@ hipError_t launch_panel(FfnArgs g, int mode, hipStream_t s) {
   const int nblocks = g.n_panels < num_cu ? g.n_panels : num_cu;   // one persistent workgroup per CU (LDS: 159 KiB each)
   if (mode == 0) VETO_LAUNCH(ffn_fused_kernel<0>, dim3(nblocks), dim3(512), 0, s, g);
   else if (mode == 1) VETO_LAUNCH(ffn_fused_kernel<1>, dim3(nblocks), dim3(512), 0, s, g);
+  else if (g.resid_f24 && g.out_f24) VETO_LAUNCH((ffn_fused_kernel<2, true, true>), dim3(nblocks), dim3(512), 0, s, g);
+  else if (g.resid_f24) VETO_LAUNCH((ffn_fused_kernel<2, true, false>), dim3(nblocks), dim3(512), 0, s, g);
   else VETO_LAUNCH(ffn_fused_kernel<2>, dim3(nblocks), dim3(512), 0, s, g);
   hipError_t rc = hipGetLastError();
 #ifdef VETO_FFN_STAMPS

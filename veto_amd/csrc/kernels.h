@@ -82,6 +82,9 @@ struct FfnArgs {
   const int* expo;
   const float* lnm_w;
   const float* lnm_b;
+  // launch_layer_tail only: resid / out are rows of 576 3-byte floats (common.h, pack_f24x4; ldr / ldo unused) instead of fp32 rows.  out_f24
+  // needs resid_f24; with different formats the two must be different buffers
+  int resid_f24, out_f24;
   int n_panels;          // filled by the launcher
   int late;              // filled by the launcher (speed only): start delay (~us) of the workgroups that have one panel fewer than the others
 };
@@ -158,6 +161,7 @@ struct AssembleArgs {
   __bf16* a;                // LN(x), split rows [n_pair*19, 2*576]
   float* stats;             // optional [n_pair*19, 2]: (mean, rstd) of every row; then `a` is written for tokens 17 / 18 only
   int a_fmt;                // ... in this operand format (FMT_SPLIT / FMT_MIXED; with stats only)
+  int x_f24;                // (with stats only) x is written as rows of 576 3-byte floats (common.h) instead of fp32
   int n_pair;
   // training only: pos_drop (EMB_DROPOUT) on the assembled tokens; element (row, col) -> index row*576 + col
   unsigned long long drop_seed;
@@ -181,8 +185,11 @@ hipError_t launch_dropout_apply(const float* x, float* y, size_t rows, int n_col
 // dst row r at dst + r*ldd (bf16 elements; 0 = contiguous rows of 2*576)
 // counters[4] += {elements, fp16 values at +-65504, e4m3 value-plane bytes at +-448, e4m3 residual-plane bytes at +-448} of mixed rows
 hipError_t launch_count_saturation(const void* base, long stride_bytes, int rows, int K, unsigned long long* counters, hipStream_t s);
+// x_f24: the source rows are 3-byte floats (common.h); ldx still counts elements
 hipError_t launch_layernorm(const float* x, long ldx, const float* w, const float* b, __bf16* dst, int rows,
-                            hipStream_t s, int fmt = FMT_SPLIT, long ldd = 0);
+                            hipStream_t s, int fmt = FMT_SPLIT, long ldd = 0, bool x_f24 = false);
+// n 3-byte floats (n % 4 == 0) -> fp32
+hipError_t launch_unpack_f24(const void* src, float* dst, size_t n, hipStream_t s);
 
 struct AttnArgs {
   const float* qkv;        // [n_pair*19, 1728]; qkv_f24: the same matrix as 3-byte floats (rows of 5184 bytes)

@@ -451,6 +451,7 @@ __global__ __launch_bounds__(256) void assemble_kernel(AssembleArgs a) {
   }
   RowQ r;
   float* xr = a.x + (size_t)row * kDim;
+  char* xr24 = (char*)a.x + (size_t)row * (kDim * 3);      // x_f24: rows of 3-byte floats
   // Three groups of three 16-byte chunks: with all nine chunks of the three sources in flight at once the kernel needed 138
   // registers (3 waves per SIMD) and was bound by the latency of its gathers (0.32 ms for 0.73 GB written = 2.3 TB/s, against
   // 5.5 TB/s for plain store streams, profiles/r02_store_bw.txt); a group keeps 9 loads in flight per lane and leaves the
@@ -485,6 +486,14 @@ __global__ __launch_bounds__(256) void assemble_kernel(AssembleArgs a) {
           v[e] = dropout_keep(a.drop_seed, (unsigned long long)row * kDim + c + e, a.drop_thresh) ? v[e] * a.drop_scale : 0.f;
       }
       r.v[j] = v;
+      if (a.x_f24) {      // (the statistics below are those of the fp32 row: the tables of layer 0 are normalised with them)
+#if ASM_NT
+        __builtin_nontemporal_store(pack_f24x4(v), (u32x3*)(xr24 + 3 * c));
+#else
+        *(u32x3*)(xr24 + 3 * c) = pack_f24x4(v);
+#endif
+        continue;
+      }
 #if ASM_NT
       __builtin_nontemporal_store(v, (f32x4*)(xr + c));
 #else
@@ -616,7 +625,8 @@ __global__ __launch_bounds__(64) void qkv0_consts_kernel(const float* __restrict
   }
 }
 
-template <int FMT>
+// XF24: the rows are 3-byte floats (common.h), ldx counts ELEMENTS all the same (a row starts at byte 3 * row * ldx)
+template <int FMT, bool XF24 = false>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, long ldx,
                                                         const float* __restrict__ w,
                                                         const float* __restrict__ b,
@@ -625,11 +635,28 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
   const int row = blockIdx.x * 16 + (threadIdx.x >> 4);
   if (row >= rows) return;
   const int q = threadIdx.x & 15;
-  const float* xr = x + (size_t)row * ldx;
   RowQ r;
+  if constexpr (XF24) {
+    const char* xr = (const char*)x + (size_t)row * ldx * 3;
 #pragma unroll
-  for (int j = 0; j < 9; ++j) r.v[j] = *(const f32x4*)(xr + 4 * (q + 16 * j));
+    for (int j = 0; j < 9; ++j) {
+      const u32x3 d = *(const u32x3*)(xr + 12 * (q + 16 * j));
+      r.v[j] = unpack_f24x4(d[0], d[1], d[2]);
+    }
+  } else {
+    const float* xr = x + (size_t)row * ldx;
+#pragma unroll
+    for (int j = 0; j < 9; ++j) r.v[j] = *(const f32x4*)(xr + 4 * (q + 16 * j));
+  }
   rowq_layernorm_store<FMT>(r, q, w, b, dst + (size_t)row * ldd);
+}
+
+// 3-byte floats -> fp32 (debug outputs of a path that keeps its residual stream in 3-byte floats); n = number of values, a multiple of 4
+__global__ __launch_bounds__(256) void unpack_f24_kernel(const char* __restrict__ src, float* __restrict__ dst, size_t n4) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    const u32x3 d = *(const u32x3*)(src + i * 12);
+    *(f32x4*)(dst + i * 4) = unpack_f24x4(d[0], d[1], d[2]);
+  }
 }
 
 __global__ __launch_bounds__(256) void dropout_apply_kernel(const float* __restrict__ x, float* __restrict__ y, size_t n,
@@ -788,13 +815,23 @@ hipError_t launch_assemble(const AssembleArgs& a, hipStream_t s) {
     VETO_LAUNCH(assemble_kernel<true>, dim3((unsigned)((blocks + 7) / 8 * 8)), dim3(256), 0, s, a);
     // LayerNorm'ed split rows of the location / class tokens (rows 19 p + 17, 19 p + 18): 2 of 19 rows, read back from x
     for (int t = kPatchTokens + 1; t < kTokens; ++t) {
-      hipError_t e = launch_layernorm(a.x + (size_t)t * kDim, (long)kTokens * kDim, a.ln_w, a.ln_b, a.a + (size_t)t * 2 * kDim, a.n_pair, s,
-                                      a.a_fmt == FMT_MIXED ? FMT_MIXED : FMT_SPLIT, (long)kTokens * 2 * kDim);
+      const float* xt = a.x_f24 ? (const float*)((const char*)a.x + (size_t)t * kDim * 3) : a.x + (size_t)t * kDim;
+      hipError_t e = launch_layernorm(xt, (long)kTokens * kDim, a.ln_w, a.ln_b, a.a + (size_t)t * 2 * kDim, a.n_pair, s,
+                                      a.a_fmt == FMT_MIXED ? FMT_MIXED : FMT_SPLIT, (long)kTokens * 2 * kDim, a.x_f24 != 0);
       if (e != hipSuccess) return e;
     }
   } else {
+    if (a.x_f24) return hipErrorInvalidValue;      // (3-byte token rows: the per-object form of layer 0 only)
     VETO_LAUNCH(assemble_kernel<false>, dim3((unsigned)((blocks + 7) / 8 * 8)), dim3(256), 0, s, a);
   }
+  return hipGetLastError();
+}
+
+hipError_t launch_unpack_f24(const void* src, float* dst, size_t n, hipStream_t s) {
+  if (n % 4 != 0) return hipErrorInvalidValue;
+  const size_t n4 = n / 4;
+  const int blocks = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
+  VETO_LAUNCH(unpack_f24_kernel, dim3(blocks), dim3(256), 0, s, (const char*)src, dst, n4);
   return hipGetLastError();
 }
 
@@ -862,8 +899,13 @@ hipError_t launch_qkv0_consts(const float* wq, const float* gamma, const float* 
 }
 
 hipError_t launch_layernorm(const float* x, long ldx, const float* w, const float* b, __bf16* dst, int rows,
-                            hipStream_t s, int fmt, long ldd) {
+                            hipStream_t s, int fmt, long ldd, bool x_f24) {
   if (ldd == 0) ldd = 2 * kDim;
+  if (x_f24) {
+    if (fmt == FMT_MIXED) VETO_LAUNCH((layernorm_kernel<FMT_MIXED, true>), dim3((rows + 15) / 16), dim3(256), 0, s, x, ldx, w, b, dst, rows, ldd);
+    else VETO_LAUNCH((layernorm_kernel<FMT_SPLIT, true>), dim3((rows + 15) / 16), dim3(256), 0, s, x, ldx, w, b, dst, rows, ldd);
+    return hipGetLastError();
+  }
   if (fmt == FMT_MIXED) VETO_LAUNCH(layernorm_kernel<FMT_MIXED>, dim3((rows + 15) / 16), dim3(256), 0, s, x, ldx, w, b, dst, rows, ldd);
   else VETO_LAUNCH(layernorm_kernel<FMT_SPLIT>, dim3((rows + 15) / 16), dim3(256), 0, s, x, ldx, w, b, dst, rows, ldd);
   return hipGetLastError();
