@@ -33,7 +33,8 @@ PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA, /opt/skills/guides/MI355X_MICROAR
 PEAK_HBM_GBS = 8000.0
 # precision modes of the library (include/veto_amd.h): what the Linears compute in, and how many bf16-rate MFMA
 # passes one algorithmic FLOP costs in each
-DTYPE_OF = {"precise": "bf16x3 (split-bf16 MFMA, fp32 accumulate)", "fast": "bf16",
+DTYPE_OF = {"precise": "bf16x3 (split-bf16 MFMA, fp32 accumulate)",
+            "fast": "fp16 single pass (the mixed mode's launches with the correction stages of the fused token-row launches skipped)",
             "mixed": "fp16 + e4m3 correction terms (fp16 MFMA main product, e4m3 K=128 MFMA cross terms, fp32 accumulate)"}
 MFMA_PASSES = {"precise": 3.0, "fast": 1.0, "mixed": 2.0}
 DEFAULT_PRECISION = "mixed"

@@ -40,7 +40,11 @@ enum veto_status {
 
 enum veto_precision {
   VETO_PRECISE = 0,  /* 3-term split-bf16 MFMA, meets the 1e-3 logit tolerance (2-3e-5 measured) */
-  VETO_FAST = 1,     /* single bf16 MFMA pass, ~1e-2 logit error; reported separately */
+  VETO_FAST = 1,     /* single-pass form of VETO_MIXED (round 6; rounds 1-5: a single bf16 pass of every GEMM): the same launches
+                        on the same operand rows, but the two fused token-row launches of a layer (QKV + attention, layer tail) skip the
+                        correction stages -- the fp16 main product alone, neither loading nor multiplying the e4m3 planes.  The measured
+                        floor of the schedule with the precision terms free; logit error ~2e-3 (over the 1e-3 bar): reported, never
+                        parity-grade.  Inference only. */
   VETO_MIXED = 2     /* fp16 MFMA main product + e4m3 K=128 MFMA correction terms on the token-row Linears: 2/3 of the
                         matrix-pipe time of VETO_PRECISE, logit error 4-9e-5 measured (1e-3 tolerance); what the Python
                         plugin selects by default (VETO_AMD.PRECISION = "mixed").  Supported activation range: the e4m3
@@ -131,8 +135,9 @@ int veto_forward(veto_handle_t h, void* stream, const veto_inputs_t* in, void* w
  * happen silently in veto_forward.  This call makes them visible: it runs the same forward in its launch-per-stage form (every
  * mixed-row operand exists in memory; logits equal to veto_forward's up to the rounding order of the fused kernels) and counts,
  * behind every producer, the elements that sit AT the clamp values.  counts[layer * VETO_SAT_SITES + site] (host memory,
- * capacity >= layers * VETO_SAT_SITES entries); the last layer runs on split-bf16 operands and reports zeros, layer 0 feeds only
- * the location / class token rows through a mixed QKV projection.  Non-zero value_saturated / resid_saturated: those elements lost
+ * capacity >= layers * VETO_SAT_SITES entries); the last layer runs its attention on split-bf16 operands (its qkv_in / attn_out
+ * sites report zeros) and its FeedForward on the pairs' CLS rows only -- mixed rows all the same, and the classifier's input: its
+ * ffn_in / hidden sites count n_pair rows --, layer 0 feeds only the location / class token rows through a mixed QKV projection.  Non-zero value_saturated / resid_saturated: those elements lost
  * the correction terms (harmless in small numbers: the 1e-3 logit tolerance holds with 3 % of the hidden units at x 30 and some at
  * x 300, tests/test_gpu_parity.py::test_parity_on_trained_like_activations).  Non-zero f16_saturated: the result is wrong; use
  * VETO_PRECISE for this checkpoint. */

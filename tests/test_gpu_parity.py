@@ -598,7 +598,10 @@ def test_saturation_audit_counts_what_the_mixed_format_clamps():
     for l in range(layers - 1):
         assert rep[l]["attn_out"]["elements"] == n_rows * 576 and rep[l]["hidden"]["elements"] == n_rows * 1152, rep[l]
         assert rep[l]["qkv_in"]["elements"] == (90 * 2 * 576 if l == 0 else n_rows * 576), rep[l]
-    assert all(v["elements"] == 0 for v in rep[layers - 1].values())          # the last layer runs on split-bf16 operands
+    # the last layer: attention on split-bf16 operands, FeedForward on the 90 CLS rows as mixed rows (the classifier's input: audited too)
+    last = rep[layers - 1]
+    assert last["qkv_in"]["elements"] == 0 and last["attn_out"]["elements"] == 0, last
+    assert last["ffn_in"]["elements"] == 90 * 576 and last["hidden"]["elements"] == 90 * 1152, last
     assert all(v["f16_saturated"] == 0 and v["value_saturated"] == 0 and v["resid_saturated"] == 0 for r in rep for v in r.values()), rep
 
     sd = _trained_like_state_dict(layers)
@@ -609,7 +612,7 @@ def test_saturation_audit_counts_what_the_mixed_format_clamps():
     assert (torch.cat(list(out[1])) - torch.cat(list(ref[1]))).abs().max().item() <= 1e-4
     rep = model.last_saturation
     print("saturation audit, trained-like weights:", [{k: (v["value_saturated"], v["resid_saturated"]) for k, v in r.items()} for r in rep])
-    hid = [rep[l]["hidden"] for l in range(layers - 1)]
+    hid = [rep[l]["hidden"] for l in range(layers)]      # (the last layer's CLS rows included: its hidden units are scaled like the others')
     # (the residual plane clamps only where the fp16 rounding error itself exceeds 448 / 2^11 = 0.22, i.e. for some |a| >= 512)
     assert sum(h["value_saturated"] for h in hid) > 0, rep
     assert all(h["f16_saturated"] == 0 and h["value_saturated"] < 0.01 * h["elements"] for h in hid), rep
@@ -619,16 +622,21 @@ def test_saturation_audit_counts_what_the_mixed_format_clamps():
     assert sum(r["hidden"]["f16_saturated"] for r in model.last_saturation) > 0, model.last_saturation
 
 
-def test_fast_mode_error_is_reported_not_trusted():
+@pytest.mark.parametrize("name", ["predcls_n10_l4h8", "predcls_n36_l4h8", "predcls_b12_n36_l6h6"])
+def test_fast_mode_error_is_reported_not_trusted(name):
+    """VETO_FAST (round 6): VETO_MIXED's launches with the correction stages of the two fused token-row launches skipped -- the fp16 main
+    product alone.  Its error is an fp16 GEMM's (pure fp16 operands: 1.6-2.1e-3, tools/precision_study.py): far from the mixed mode's
+    5e-5 -- the stages really are skipped -- and far from garbage -- the shortened stage streams of both kernels (eight and six heads,
+    one panel and many) still multiply every fp16 slice exactly once."""
     from veto_amd import testing
     dev = _dev()
-    g, sd, batch = load_golden("predcls_n10_l4h8")
-    cfg = testing.make_config(4, 8, precision="fast")
+    g, sd, batch = load_golden(name)
+    cfg = testing.make_config(int(g["_layers"]), int(g["_heads"]), precision="fast")
     model = testing.make_predictor(cfg, sd, dev)
     out, _ = _run(model, batch, "predcls", dev)
     err = np.abs(torch.cat(list(out[1])).cpu().numpy() - g["rel_dists"]).max()
-    print("fast (single bf16) logit max-abs-err %.3e" % err)
-    assert err < 0.1
+    print("%s: fast (fp16 single pass) logit max-abs-err %.3e" % (name, err))
+    assert 2e-4 < err < 1e-2, err
 
 
 def test_full_size_properties():

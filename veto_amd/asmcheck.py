@@ -170,9 +170,9 @@ def m0_users(path):
 
 # source -> (kernel name pattern: the integer template argument as group 1, the boolean ones behind it as group 2; the instantiations that
 # must be present).  An instantiation's key is its integer argument, with the boolean arguments appended as digits when any of them is set:
-# ffn_fused_kernel<2, true, true> (the layer tail on 3-byte residual rows) is 211, <2, false, false, true> (its single-pass form) 2001.
-KERNELS = {"ffn_fused.hip": (r"ffn_fused_kernelILi(\d+)E((?:Lb[01]E)*)", (0, 1, 2, 210, 211)),
-           "qkv_attn_fused.hip": (r"qkv_attn_fused_kernelILi(\d+)E((?:Lb[01]E)*)", (72, 96))}
+# ffn_fused_kernel<2, true, true, false> (the layer tail on 3-byte residual rows) is 2110, <2, false, false, true> (its single-pass form) 2001.
+KERNELS = {"ffn_fused.hip": (r"ffn_fused_kernelILi(\d+)E((?:Lb[01]E)*)", (0, 1, 2, 2001, 2100, 2110)),
+           "qkv_attn_fused.hip": (r"qkv_attn_fused_kernelILi(\d+)E((?:Lb[01]E)*)", (72, 96, 721, 961))}
 
 
 def _inst_key(m):

@@ -97,9 +97,7 @@ constexpr int FH = 2 * kDim;                // hidden width 1152
 constexpr int kChunks = FH / FC;            // 6
 constexpr int kRow1 = kDim * 4;             // bytes of a mixed row with K = 576 (activation rows, W1 rows)
 constexpr int kRow2 = FH * 4;               // ... with K = 1152 (W2 rows)
-constexpr int kS1 = kDim / 64 * 2;          // 18 fc1 stages per chunk
-constexpr int kS2 = FC / 64 * 2 * 3;        // 18 fc2 sub-stages per chunk
-constexpr int kPer = kS1 + kS2;             // stages per chunk
+// (stages per chunk: 18 fc1 stages + 18 fc2 sub-stages on mixed operands, 9 + 9 in the single-pass form: `Stages` inside the kernel)
 constexpr int kAB = FR * 128;               // activation part of a ring slot: 16 KiB
 constexpr int kWB = FC * 128;               // weight part: 24 KiB
 constexpr int kSlot = kAB + kWB;
@@ -176,8 +174,16 @@ __device__ __forceinline__ void static_for(F&& f) {
 // activation slice of a k-slice rides with its first third (always ring slot 0) and its fragments are held across the thirds.
 // RF24 / OF24 (MODE 2): the residual rows come in / the result rows go out as 3-byte floats (common.h: rows of 576 * 3 bytes at g.resid /
 // g.out) -- the residual stream between the layers of the default path, a quarter fewer bytes in the two bursts of a panel boundary
-template <int MODE, bool RF24 = false, bool OF24 = false>
+// FAST (VETO_FAST): the single-pass form -- the fp16 main product only.  The correction stage of every 64-k block is skipped (not loaded,
+// not multiplied), everything else is the same kernel on the same mixed rows: what this schedule costs with the precision terms free.
+template <int MODE, bool RF24 = false, bool OF24 = false, bool FAST = false>
 __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs g) {
+  constexpr int NK = FAST ? 1 : 2;           // stages per 64-k block: {fp16 part, e4m3 part}, or the fp16 part alone
+  constexpr int kS1 = kDim / 64 * NK;        // fc1 stages per chunk: 18 / 9
+  constexpr int kS2 = FC / 64 * NK * 3;      // fc2 sub-stages per chunk: 18 / 9
+  constexpr int kPer = kS1 + kS2;            // a multiple of the ring length either way
+  constexpr int kOutPos = kDim / 64 * NK * 3;   // positions of the out projection: 54 / 27
+  static_assert(kPer % kRing == 0 && kOutPos % kRing == 0, "a position's ring slot is a compile-time constant");
   saturating_conversions_on();   // (the hidden and LayerNorm conversions to mixed rows carry no clamps, common.h)
   __shared__ __attribute__((aligned(16))) char smem[kLds];
   const int tid = threadIdx.x;
@@ -458,7 +464,7 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs g) {
 #pragma unroll
       for (int m = 0; m < 2; ++m) {
         *(u32x2*)(smem + hid_f16(J) + ho + m * 2048) = hh[ib][m];
-        *(u32x2*)(smem + hid_e4m3(J) + ho + m * 2048) = xy[ib][m];
+        if constexpr (!FAST) *(u32x2*)(smem + hid_e4m3(J) + ho + m * 2048) = xy[ib][m];
       }
     }
   };
@@ -470,13 +476,15 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs g) {
   // The stream of stages: per chunk 36 positions -- 18 fc1 stages (0..17), then 18 fc2 sub-stages (hidden block j = 0..2 x
   // {fp16, e4m3} x column third 0..2).  Position P lives in ring slot P % 3 (36 is a multiple of 3: every LDS address is a
   // compile-time constant).  The stage two positions on is issued during interval P, into the slot position P - 1 used.
+  // (issue_fc1 / issue_out take the 128-byte SLICE of the rows: stage index x 2 in the single-pass form, which walks the fp16 slices only)
+  constexpr int SL = FAST ? 2 : 1;
 #pragma unroll
   for (int k = 0; k < 5; ++k) {
     if (MODE == 0) issue_fc1(panel_base(0), 0, 0, 0, k); else issue_out(panel_base(0), 0, 0, 0, k);
   }
 #pragma unroll
   for (int k = 0; k < 5; ++k) {
-    if (MODE == 0) issue_fc1(panel_base(0), 0, 1, 1, k); else issue_out(panel_base(0), 0, 1, 1, k);
+    if (MODE == 0) issue_fc1(panel_base(0), 0, 1 * SL, 1, k); else issue_out(panel_base(0), 0, 1, 1, k);
   }
   int skip = 0;                       // intervals whose stage is known to have landed (behind a full drain)
 
@@ -695,11 +703,11 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs g) {
       const bool stream_ends = MODE == 2 || it == my_panels - 1;
       const char* a_next = panel_base(it + 1);          // (not dereferenced when the stream ends)
       i32x4 fa0[2], fa1[2];
-      static_for<0, 54>([&](auto p_tag) {
+      static_for<0, kOutPos>([&](auto p_tag) {
         constexpr int P = decltype(p_tag)::value, KS = P / 3, T = P % 3;
         STAMP(t0);
         if (skip > 0) --skip;
-        else if (P == 53) {
+        else if (P == kOutPos - 1) {
           if (stream_ends) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
         } else if ((P + 1) % 3 == 0) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
@@ -710,11 +718,11 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs g) {
         ACC(s_wait, t1, t0); ACC(s_bar, t2, t1);
         auto dma = [&](int k) {
           constexpr int P2 = P + 2;
-          if constexpr (P2 < 54) issue_out(a_panel, P2 / 3, P2 % 3, P2 % 3, k);
-          else if (!stream_ends) issue_out(a_next, (P2 - 54) / 3, (P2 - 54) % 3, (P2 - 54) % 3, k);
+          if constexpr (P2 < kOutPos) issue_out(a_panel, P2 / 3 * SL, P2 % 3, P2 % 3, k);
+          else if (!stream_ends) issue_out(a_next, (P2 - kOutPos) / 3 * SL, (P2 - kOutPos) % 3, (P2 - kOutPos) % 3, k);
         };
-        stage(Tag<KS & 1>(), Tag<0>(), Tag<T * kSlot>(), acc2[T], MODE == 2 ? sco : sc2, dma, Tag<(T > 0)>(), fa0, fa1, [](int) {}, [](int) {});
-        if constexpr (MODE == 2 && P == 52) {
+        stage(Tag<(FAST ? 0 : KS & 1)>(), Tag<0>(), Tag<T * kSlot>(), acc2[T], MODE == 2 ? sco : sc2, dma, Tag<(T > 0)>(), fa0, fa1, [](int) {}, [](int) {});
+        if constexpr (MODE == 2 && P == kOutPos - 2) {
           // the phase's last DMA instruction is long out: the parameters of the mid-panel epilogue are requested here and drained by
           // the wait of position 53
           const int tl = w * 64 + lane_now();
@@ -740,7 +748,7 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs g) {
 #pragma unroll
       for (int k = 0; k < 5; ++k) issue_fc1(ffn_base(it), 0, 0, 0, k);
 #pragma unroll
-      for (int k = 0; k < 5; ++k) issue_fc1(ffn_base(it), 0, 1, 1, k);
+      for (int k = 0; k < 5; ++k) issue_fc1(ffn_base(it), 0, 1 * SL, 1, k);
       skip = 0;
       STAMP(t1); ACC(s_epi, t1, t0);
     }
@@ -759,8 +767,8 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs g) {
       i32x4 fa0[2], fa1[2];     // activation fragments: re-read every fc1 stage, held across the three column thirds in fc2
       static_for<0, kPer>([&](auto p_tag) {
         constexpr int P = decltype(p_tag)::value;
-        constexpr int Q = P >= kS1 ? P - kS1 : 0;                        // fc2 sub-stage index (P >= 18)
-        constexpr int J = Q / 6, S = Q % 6, KIND2 = S / 3, T = S % 3;    // hidden block, sub-stage of the block = kind x third
+        constexpr int Q = P >= kS1 ? P - kS1 : 0;                        // fc2 sub-stage index (P >= kS1)
+        constexpr int J = Q / (3 * NK), S = Q % (3 * NK), KIND2 = S / 3, T = S % 3;    // hidden block, sub-stage of the block = kind x third
         if constexpr (P == kS1) {                                         // hidden block 0 of the chunk: nothing to overlap it with
           STAMP(t0);
           mfma_drain4(acc1[0][0], acc1[0][1], acc1[1][0], acc1[1][1]);   // (every fc1 MFMA of the chunk is behind these three)
@@ -801,54 +809,61 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs g) {
         auto dma = [&](int k) {       // instruction k of this wave's share of the stage two positions on
           constexpr int P2 = P + 2, S2 = P2 % kRing;
           if constexpr (P2 < kS1) {
-            if (k < 5) issue_fc1(f_panel, c, P2, S2, k);
+            if (k < 5) issue_fc1(f_panel, c, P2 * SL, S2, k);
           } else if constexpr (P2 < kPer) {
             constexpr int Q2 = P2 - kS1;
-            if (k < 3) issue_fc2((c * 3 + Q2 / 6) * 2 + (Q2 % 6) / 3, Q2 % 3, S2, k);
+            if (k < 3) issue_fc2((c * 3 + Q2 / (3 * NK)) * 2 + (Q2 % (3 * NK)) / 3, Q2 % 3, S2, k);
           } else {
             if (k < 5 && !stream_ends) {
               if (MODE == 2 && c == kChunks - 1) issue_out(a_next, 0, P2 - kPer, S2, k);   // the next panel opens with its out projection
-              else issue_fc1(a_next, c_next, P2 - kPer, S2, k);
+              else issue_fc1(a_next, c_next, (P2 - kPer) * SL, S2, k);
             }
           }
         };
         constexpr int SB = (P % kRing) * kSlot;
         auto mark = [&](int i) { (void)i; TL(P, 3 + i); };
         if constexpr (P < kS1) {
-          stage(Tag<(P % 2) * (FFN_FP6_PROBE ? 2 : 1)>(), Tag<SB>(), Tag<SB>(), acc1, sc1, dma, Tag<0>(), fa0, fa1, [](int) {}, mark);
+          stage(Tag<(FAST ? 0 : (P % 2) * (FFN_FP6_PROBE ? 2 : 1))>(), Tag<SB>(), Tag<SB>(), acc1, sc1, dma, Tag<0>(), fa0, fa1, [](int) {}, mark);
         } else {
           // beside the MFMAs of sub-stages 0..3 of block J: bias + GELU + conversion of one (16 columns x 16 rows) unit of block
           // J + 1, a value per group, packed and stored in group 4
-          constexpr bool CONV = J < 2 && S < 4 && !(FFN_ABLATE & 8);
-          constexpr int IB = (S >> 1) & 1, MM = S & 1;
+          // (single-pass form: a block has three sub-stages, so two units per sub-stage -- one in groups 0..2, one in groups 3..5 -- in the first two)
+          constexpr bool CONV = J < 2 && S < (FAST ? 2 : 4) && !(FFN_ABLATE & 8);
           f32x4 gv, pre;
           int ho = 0;
           auto valu = [&](int i) {
             if constexpr (CONV) {
-              if (i == 0) {
+              const int unit = FAST ? 2 * S + (i >= 3) : S, ii = FAST ? i % 3 : i - FFN_CONV_G0;     // (constants once the group loop is unrolled)
+              const int IB = (unit >> 1) & 1, MM = unit & 1;
+              if (FAST ? ii == 0 : i == 0) {
                 const int lane_h = lane_now();
                 const int hr = lane_h & 15, hq = lane_h >> 4;
                 const int ls = wn * 4 + IB * 2 + (hq >> 1);
                 ho = (wm * 32 + MM * 16 + hr) * 128 + ((ls ^ ((hr >> 1) & 7)) << 4) + (hq & 1) * 8;
                 pre = acc1[2 * (J + 1) + IB][MM] + *(const f32x4*)(smem + kB1Off + (c * FC + (J + 1) * 64 + wn * 32 + IB * 16 + hq * 4) * 4);
               }
-              if (i == FFN_CONV_G0 || i == FFN_CONV_G0 + 1) {          // two values per group on the packed fp32 instructions
-                const int k = 2 * (i - FFN_CONV_G0);
+              if (ii == 0 || ii == 1) {          // two values per group on the packed fp32 instructions
+                const int k = 2 * ii;
                 const f32x2 g2 = gelu_sigmoid2(f32x2{pre[k], pre[k + 1]});
                 gv[k] = g2[0];
                 gv[k + 1] = g2[1];
                 asm volatile("" : "+v"(gv[k]), "+v"(gv[k + 1]));   // pins the piece in its group (register-only code carries no order of its own)
               }
-              if (i == FFN_CONV_G0 + 2) {
+              if (ii == 2) {
                 u32x2 h, xy;
                 mixed_pack4(gv, h, xy);
-                asm volatile("" : "+v"(h), "+v"(xy));
-                *(u32x2*)(smem + hid_f16(J + 1) + ho) = h;
-                *(u32x2*)(smem + hid_e4m3(J + 1) + ho) = xy;
+                if constexpr (FAST) {
+                  asm volatile("" : "+v"(h));
+                  *(u32x2*)(smem + hid_f16(J + 1) + ho) = h;
+                } else {
+                  asm volatile("" : "+v"(h), "+v"(xy));
+                  *(u32x2*)(smem + hid_f16(J + 1) + ho) = h;
+                  *(u32x2*)(smem + hid_e4m3(J + 1) + ho) = xy;
+                }
               }
             }
           };
-          stage(Tag<KIND2 * (FFN_FP6_PROBE ? 2 : 1)>(), Tag<(KIND2 == 0 ? (J == 1 ? 0 : kHidOff) : (J == 1 ? kSlot : kHidOff + kAB))>(), Tag<SB>(), acc2[T], sc2, dma,
+          stage(Tag<(FAST ? 0 : KIND2 * (FFN_FP6_PROBE ? 2 : 1))>(), Tag<(KIND2 == 0 ? (J == 1 ? 0 : kHidOff) : (J == 1 ? kSlot : kHidOff + kAB))>(), Tag<SB>(), acc2[T], sc2, dma,
                 Tag<(T > 0)>(), fa0, fa1, valu, mark);
         }
         STAMP(t0);
@@ -883,6 +898,7 @@ hipError_t launch_panel(FfnArgs g, int mode, hipStream_t s) {
   if (g.M <= 0 || !g.a || !g.w2 || !g.b2 || !g.resid || !g.out || !g.exp2) return hipErrorInvalidValue;
   if (mode != 1 && (!g.w1 || !g.b1 || !g.exp1)) return hipErrorInvalidValue;
   if (mode == 2 && (!g.wo || !g.bo || !g.expo || !g.lnm_w || !g.lnm_b || !g.ln_out)) return hipErrorInvalidValue;
+  if (g.fast && (mode != 2 || g.resid_f24 || g.out_f24)) return hipErrorInvalidValue;      // (the single-pass form: the layer tail on fp32 residual rows)
   if ((g.resid_f24 || g.out_f24) && (mode != 2 || !g.resid_f24)) return hipErrorInvalidValue;      // (3-byte rows: the layer tail only; never f32 in, 3 bytes out)
   if (g.resid_f24 != g.out_f24 && (const void*)g.resid == (const void*)g.out) return hipErrorInvalidValue;   // (rows of different pitch cannot be rewritten in place)
   static int num_cu = 0;
@@ -899,6 +915,7 @@ hipError_t launch_panel(FfnArgs g, int mode, hipStream_t s) {
   const int nblocks = g.n_panels < num_cu ? g.n_panels : num_cu;   // one persistent workgroup per CU (LDS: 159 KiB each)
   if (mode == 0) VETO_LAUNCH(ffn_fused_kernel<0>, dim3(nblocks), dim3(512), 0, s, g);
   else if (mode == 1) VETO_LAUNCH(ffn_fused_kernel<1>, dim3(nblocks), dim3(512), 0, s, g);
+  else if (g.fast) VETO_LAUNCH((ffn_fused_kernel<2, false, false, true>), dim3(nblocks), dim3(512), 0, s, g);
   else if (g.resid_f24 && g.out_f24) VETO_LAUNCH((ffn_fused_kernel<2, true, true>), dim3(nblocks), dim3(512), 0, s, g);
   else if (g.resid_f24) VETO_LAUNCH((ffn_fused_kernel<2, true, false>), dim3(nblocks), dim3(512), 0, s, g);
   else VETO_LAUNCH(ffn_fused_kernel<2>, dim3(nblocks), dim3(512), 0, s, g);
@@ -936,7 +953,7 @@ hipError_t launch_panel(FfnArgs g, int mode, hipStream_t s) {
     }
     fprintf(stderr, "[ffn stamps M%d] wave 0 of each workgroup, mean cycles: load wait %.0f barrier %.0f dma issue %.0f mfma %.0f hidden %.0f "
             "epilogue %.0f total %.0f (%.2f panels x %d chunks x %d stages)\n", g.M, sum[0] / nb, sum[1] / nb, sum[2] / nb, sum[3] / nb,
-            sum[4] / nb, sum[5] / nb, sum[6] / nb, sum[7] / nb, kChunks, kPer);
+            sum[4] / nb, sum[5] / nb, sum[6] / nb, sum[7] / nb, kChunks, 36);
   }
 #endif
   return rc;

@@ -85,6 +85,7 @@ struct FfnArgs {
   // launch_layer_tail only: resid / out are rows of 576 3-byte floats (common.h, pack_f24x4; ldr / ldo unused) instead of fp32 rows.  out_f24
   // needs resid_f24; with different formats the two must be different buffers
   int resid_f24, out_f24;
+  int fast;              // launch_layer_tail only (VETO_FAST): the fp16 main product alone -- the correction stages are neither loaded nor multiplied
   int n_panels;          // filled by the launcher
   int late;              // filled by the launcher (speed only): start delay (~us) of the workgroups that have one panel fewer than the others
 };
@@ -220,6 +221,7 @@ struct QkvAttnArgs {
   const int* w_exp;
   char* o;
   int n_pair, heads;
+  int fast;      // VETO_FAST: the fp16 main product alone (the correction stages are neither loaded nor multiplied)
 };
 bool qkv_attn_fused_supports(int heads);
 size_t qkv_attn_rows_padded(int n_pair);

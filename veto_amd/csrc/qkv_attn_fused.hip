@@ -104,7 +104,7 @@ constexpr int TP = 16;                     // pairs per tile
 constexpr int TM = TP * kTokens;           // 304 rows = 19 row blocks of 16
 constexpr int MB = 5;                      // row blocks per wave
 constexpr int kRowB = kDim * 4;            // bytes of a mixed row (K = 576)
-constexpr int kStages = kDim / 64 * 2;     // 18
+// (18 stages per tile: kStages inside the kernel)
 constexpr int kABytes = TM * 128;          // activation part of a ring slot
 constexpr int APIECES = TM / 8;            // 38 LDS-DMA instructions (8 rows x 128 B each) per activation stage
 constexpr int kLdsTotal = 163840;
@@ -280,10 +280,16 @@ __device__ __forceinline__ u32x4 lds_tr_pair(const char* p0, const char* p1) {
   return __builtin_bit_cast(u32x4, v);
 }
 
-template <int DH>
+// FAST (VETO_FAST): the single-pass form -- the fp16 main product only.  The tile's stage stream keeps a length that is a multiple of the
+// 2 x 3 image rotation (the next tile's first stage must land in image 0 of both kinds): 9 fp16 stages + 3 EMPTY intervals (a barrier, the
+// DMA issue of the stages behind them, no fragment reads, no MFMAs) instead of 18 stages.
+template <int DH, bool FAST = false>
 __global__ __launch_bounds__(512, 2) void qkv_attn_fused_kernel(QkvAttnArgs g) {
   using G = Geo<DH>;
   constexpr int NB = G::NB, NWB = G::NWB;
+  constexpr int kStages = FAST ? 12 : 18;      // intervals of a tile's main loop
+  constexpr int kReal = FAST ? 9 : 18;         // ... of which the first kReal multiply: stage s = the 128-byte slice SL * s of every row
+  constexpr int SL = FAST ? 2 : 1;
   saturating_conversions_on();   // (the mixed-row output converts without clamps, common.h)
   __shared__ __attribute__((aligned(16))) char smem[kLdsTotal];
   const int tid = threadIdx.x;
@@ -361,7 +367,7 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_fused_kernel(QkvAttnArgs g) {
     for (int k = 0; k < NPA; ++k)
       if (a_begin + wl + 4 * k < a_end_s && a_begin + wl + 4 * k >= p_lo && a_begin + wl + 4 * k < p_hi) {
         ++issued;
-        glds16(t.a + (size_t)(a_begin * 8 + 32 * k) * kRowB + s * 128, voff_a, lds0 + buf * G::kPair + (a_begin + wl + 4 * k) * 1024);
+        glds16(t.a + (size_t)(a_begin * 8 + 32 * k) * kRowB + s * (SL * 128), voff_a, lds0 + buf * G::kPair + (a_begin + wl + 4 * k) * 1024);
       }
 #if QA_FP6_PROBE
     if ((s & 1) && (w == 0 || w >= 3) && p_lo == 0) {      // stand-ins of the scale DMAs: 5 x 256 B of activation scales, 1 KiB of weight scales
@@ -386,7 +392,7 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_fused_kernel(QkvAttnArgs g) {
       if (c < wp) {
         ++issued;
         const int mat = c / G::PM, cm = c - mat * G::PM;
-        glds16(t.w + (size_t)(mat * kDim + 8 * cm) * kRowB + s * 128, voff_w, lds0 + (buf < 2 ? kABytes + buf * G::kPair : 2 * G::kPair) + c * 1024);
+        glds16(t.w + (size_t)(mat * kDim + 8 * cm) * kRowB + s * (SL * 128), voff_w, lds0 + (buf < 2 ? kABytes + buf * G::kPair : 2 * G::kPair) + c * 1024);
       }
     }
     return issued;
@@ -486,8 +492,9 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_fused_kernel(QkvAttnArgs g) {
       // of stage s + 2 into the third image (NWB == 3) or of stage s + 1 into the other image (NWB == 2).  Behind the tile's last stage
       // only the next tile's stage 0 may be in flight (the attention regions cover every other image): stage 1 follows the attention.
       const int sa2 = s + 2, sw2 = NWB == 3 ? s + 2 : s + 1;
-      const bool do_a = sa2 < kStages || (sa2 == kStages && has_next);
-      const bool do_w = sw2 < kStages || (sw2 == kStages && has_next && G::kFreeW0);
+      const bool real = s < kReal;      // (FAST: the last three intervals of a tile multiply nothing)
+      const bool do_a = sa2 < kReal || (sa2 == kStages && has_next);
+      const bool do_w = sw2 < kReal || (sw2 == kStages && has_next && G::kFreeW0);
       const TileSrc& ta = sa2 < kStages ? src : src_next;
       const TileSrc& tw = sw2 < kStages ? src : src_next;
       const int st_a = sa2 < kStages ? sa2 : 0, st_w = sw2 < kStages ? sw2 : 0;
@@ -526,7 +533,7 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_fused_kernel(QkvAttnArgs g) {
         sc_w = *(const int*)(smem + G::a_buf(AB) + 31744 + (w_lo & 0x3fc));
         sc_a = (int)(sa2[0] ^ sa2[1]);
       }
-      if (QA_ABLATE & 16) {
+      if ((QA_ABLATE & 16) || !real) {
 #pragma unroll
         for (int m = 0; m < MB; ++m) { fa0[m] = fa1[m] = i32x4{0, 0, 0, 0}; asm volatile("" : "+v"(fa0[m]), "+v"(fa1[m])); }
 #pragma unroll
@@ -558,6 +565,10 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_fused_kernel(QkvAttnArgs g) {
         if (do_a) n_issued = issue_acts(ta, st_a, AB, 0, a_limit);
       }
       __builtin_amdgcn_sched_barrier(0);
+      if (!real) {
+        // an empty interval: no fragments, no MFMAs; the upper half joins the release barrier right away
+        if (!lower && do_a) wg_barrier();
+      } else
 #pragma unroll
       for (int n = 0; n < NB; ++n) {
         if (n + WBUF - 1 < NB && !(QA_ABLATE & 16)) {
@@ -587,13 +598,14 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_fused_kernel(QkvAttnArgs g) {
 #elif QA_PRIO == 2
     if (lower) __builtin_amdgcn_s_setprio(1);
 #endif
+    constexpr int K1 = FAST ? 0 : 1;      // kind of the odd stages: the e4m3 part of a block, or (FAST) the next block's fp16 part
     for (int s = 0; s < kStages; s += 6) {
       stage(Tag<0>(), Tag<0>(), Tag<0>(), s);
-      stage(Tag<1>(), Tag<1>(), Tag<1 % NWB>(), s + 1);
+      stage(Tag<K1>(), Tag<1>(), Tag<1 % NWB>(), s + 1);
       stage(Tag<0>(), Tag<0>(), Tag<2 % NWB>(), s + 2);
-      stage(Tag<1>(), Tag<1>(), Tag<3 % NWB>(), s + 3);
+      stage(Tag<K1>(), Tag<1>(), Tag<3 % NWB>(), s + 3);
       stage(Tag<0>(), Tag<0>(), Tag<4 % NWB>(), s + 4);
-      stage(Tag<1>(), Tag<1>(), Tag<5 % NWB>(), s + 5);
+      stage(Tag<K1>(), Tag<1>(), Tag<5 % NWB>(), s + 5);
     }
 
     // ---- attention phase -----------------------------------------------------------------------------------------------------------
@@ -858,7 +870,10 @@ hipError_t launch_qkv_attn_fused(const QkvAttnArgs& g, hipStream_t s) {
   const int ntiles = (g.n_pair + TP - 1) / TP * g.heads;
   int nblocks = num_cu;       // one persistent workgroup per CU (the whole LDS each)
   if (ntiles < nblocks) nblocks = (ntiles + 7) / 8 * 8;
-  if (kDim / g.heads == 72) VETO_LAUNCH(qkv_attn_fused_kernel<72>, dim3(nblocks), dim3(512), 0, s, g);
+  if (g.fast) {
+    if (kDim / g.heads == 72) VETO_LAUNCH((qkv_attn_fused_kernel<72, true>), dim3(nblocks), dim3(512), 0, s, g);
+    else VETO_LAUNCH((qkv_attn_fused_kernel<96, true>), dim3(nblocks), dim3(512), 0, s, g);
+  } else if (kDim / g.heads == 72) VETO_LAUNCH(qkv_attn_fused_kernel<72>, dim3(nblocks), dim3(512), 0, s, g);
   else VETO_LAUNCH(qkv_attn_fused_kernel<96>, dim3(nblocks), dim3(512), 0, s, g);
   hipError_t rc = hipGetLastError();
 #ifdef VETO_QA_STAMPS
