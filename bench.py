@@ -40,6 +40,15 @@ MFMA_PASSES = {"precise": 3.0, "fast": 1.0, "mixed": 2.0}
 DEFAULT_PRECISION = "mixed"
 
 
+def load_traffic(name, workload):
+    """profiles/<name> (written by tools/pmc_traffic.py from the --pmc passes of one profile tag) if it describes `workload`, else None."""
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", name)))
+        return tj if tj.get("workload") == workload and "kernels" in tj and "tag" in tj else None
+    except (OSError, ValueError):
+        return None
+
+
 def flops_per_pair(layers, heads):
     """Reference-equivalent dense FLOPs (2*M*N*K) per pair, SURVEY.md section 8(d)."""
     patch = 16 * 2048 * 576 * 2
@@ -255,15 +264,13 @@ def main():
                     for k in ("attention", "attention_cls", "layernorm") if k in prof and prof[k]["bytes_per_launch"]}
         gather_bytes = prof["assemble_tokens"]["bytes_per_launch"]      # bytes the kernel writes, as the library accounts them
         gather_gbps = gather_bytes / (kern["assemble_tokens"]["avg_ms"] * 1e-3) / 1e9
-        traffic, attention_pmc, tj_kernels = None, None, None
-        try:  # PMC-derived numbers for THIS workload, written by tools/pmc_traffic.py from the profile tag named inside
-            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-            if tj.get("workload") == [args.images, args.objs, args.layers, args.heads, args.precision]:
-                traffic = tj["kernels"].get(dom, {}).get("hbm_bytes_per_launch")
-                attention_pmc = tj.get("attention")
-                tj_kernels = tj["kernels"]
-        except (OSError, ValueError, KeyError):
-            pass
+        # PMC-derived numbers for THIS workload (HBM bytes per launch, MFMA-busy fractions): counters cannot be collected inside a timed
+        # run, so they come from the committed rocprofv3 --pmc passes of the profile tag named in `traffic_source` (tools/pmc_traffic.py)
+        tj = load_traffic("traffic.json", [args.images, args.objs, args.layers, args.heads, args.precision])
+        traffic = tj["kernels"].get(dom, {}).get("hbm_bytes_per_launch") if tj else None
+        attention_pmc = tj.get("attention") if tj else None
+        tj_kernels = tj["kernels"] if tj else None
+        traffic_source = "profiles/%s_pmc_*.txt (rocprofv3 --pmc passes of profile tag %s)" % (tj["tag"], tj["tag"]) if tj else None
         res = {
             "metric": "relation-pairs/sec (PredCls, 36 obj/img)", "value": value, "unit": "pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
@@ -277,7 +284,7 @@ def main():
             "ranks_seen": ranks_seen, "devices": devices,
             "per_rank_pairs_per_s": [round(n_pairs * args.steps / e, 1) for e in rank_elapsed],
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": PEAK_BF16_TFLOPS,
-                         "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic,
+                         "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic, "traffic_source": traffic_source,
                          "note": "achieved = algorithmic 2*M*N*K of one launch / its mean hipEvent duration; this precision mode "
                                  "issues %.4g bf16-equivalent MFMA passes per algorithmic FLOP" % passes},
             # the four floors of the dominant launch (rates measured on MI355X in round 4): it runs above all of
@@ -372,6 +379,27 @@ def extra_lines(args, dev, batch, sd):
     out["l6h6"] = {"workload": "the reference's shipped architecture (6 layers x 6 heads) on the same 12 x %d batch" % n,
                    "pairs_per_s": n_pairs / dt, "ms_per_step": dt * 1e3, "precision": args.precision,
                    "logit_max_abs_err_image0": float((lg[:ppi] - ref6).abs().max())}
+    # its own roofline object: the dominant launch by the library's hipEvent timers, counted traffic from this architecture's own PMC passes
+    eng6 = m6._engine
+    eng6.profile_reset()
+    eng6.profile_enable(True)
+    with torch.no_grad():
+        for _ in range(3):
+            m6(props, pairs, None, None, roi_features=rgb, roi_depth_features=dep)
+    torch.cuda.synchronize(dev)
+    prof6 = eng6.profile()
+    eng6.profile_enable(False)
+    mat6 = {k: v for k, v in prof6.items() if (k.startswith("gemm_") or k in ("layer_tail_fused", "qkv_attn_fused")) and v["flops_per_launch"]}
+    if mat6:
+        dom6 = max(mat6, key=lambda k: mat6[k]["total_ms"] / mat6[k]["launches"])
+        avg6 = mat6[dom6]["total_ms"] / mat6[dom6]["launches"]
+        tf6 = mat6[dom6]["flops_per_launch"] / (avg6 * 1e-3) / 1e12
+        tj6 = load_traffic("traffic_l6h6.json", [args.images, n, 6, 6, args.precision])
+        out["l6h6"]["roofline"] = {"bound": "mfma", "kernel": dom6, "ms_per_launch": avg6, "launches_per_step": mat6[dom6]["launches"] // 3,
+                                   "achieved": tf6, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": tf6 / PEAK_BF16_TFLOPS,
+                                   "traffic": tj6["kernels"].get(dom6, {}).get("hbm_bytes_per_launch") if tj6 else None,
+                                   "traffic_source": "profiles/%s_pmc_*.txt" % tj6["tag"] if tj6 else None}
+        out["l6h6"]["kernels_ms_per_step"] = {k: round(v["total_ms"] / 3, 4) for k, v in sorted(prof6.items(), key=lambda kv: -kv[1]["total_ms"])[:8]}
     del m6
     ref, _, _ = vo.forward(sd, vo.OracleConfig(layers=args.layers, heads=args.heads), img0)
     for prec in sorted(DTYPE_OF):

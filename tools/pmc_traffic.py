@@ -1,7 +1,7 @@
 """Builds profiles/traffic.json (what bench.py puts into `roofline.traffic` and `attention`) from the rocprofv3 --pmc CSVs of
 ONE profile tag, so that the bench line and the committed profile always come from the same run set.
 
-    python tools/pmc_traffic.py <tag> <pmc_fetch_dir> <pmc_write_dir> <pmc_mfma_dir> [--workload 12 36 4 8 mixed]
+    python tools/pmc_traffic.py <tag> <pmc_fetch_dir> <pmc_write_dir> <pmc_mfma_dir> [--workload 12 36 4 8 mixed] [--out traffic.json]
 
 HBM bytes per launch follow /opt/skills/guides/MI355X_MICROARCH.md, section HBM: FETCH_SIZE / WRITE_SIZE are in KiB and come from
 separate passes; on gfx950 FETCH_SIZE reports half of the bytes of a wide (16 B per lane) coalesced read stream, so
@@ -62,7 +62,7 @@ def per_label(steps):
                 label = name.replace("void ", "").replace("veto::", "").replace("(anonymous namespace)::", "")
                 label = re.split(r"[<(]", label)[0].strip() or name[:40]
                 if label == "ffn_fused_kernel":  # the names bench.py's per-kernel timers use: MODE 0 FeedForward, MODE 1 out projection
-                    label = {"0": "ffn_fused", "1": "out_ln_fused", "2": "layer_tail_fused"}[re.search(r"ffn_fused_kernel<(\d)>", name).group(1)]
+                    label = {"0": "ffn_fused", "1": "out_ln_fused", "2": "layer_tail_fused"}[re.search(r"ffn_fused_kernel<(\d)", name).group(1)]
                 if label == "qkv_attn_fused_kernel":
                     label = "qkv_attn_fused"
                 if "attention_mfma_kernel" in name:          # the table form of layer 0 is its own instantiation
@@ -98,7 +98,8 @@ def main():
                                  "the dominant GEMM for comparison", "kernels": {k: v.get("mfma_busy") for k, v in att.items()},
                          "gemm_qkv_mfma_busy": kernels.get("gemm_qkv", {}).get("mfma_busy"),
                          "layer_tail_mfma_busy": kernels.get("layer_tail_fused", {}).get("mfma_busy")}}
-    json.dump(doc, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
+    out_name = sys.argv[sys.argv.index("--out") + 1] if "--out" in sys.argv else "traffic.json"      # (other workloads: their own file)
+    json.dump(doc, open(os.path.join(ROOT, "profiles", out_name), "w"), indent=1)
     for k, v in kernels.items():
         print("%-34s x%d  hbm %8.1f MB  mfma_busy %s" % (k, v["launches_per_step"], v["hbm_bytes_per_launch"] / 1e6, v.get("mfma_busy")))
 

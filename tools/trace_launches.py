@@ -36,11 +36,11 @@ def main(path):
             cur.append((inst, (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3))
         elif cur is not None and "qkv_attn_fused_kernel" in name:
             qa.append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
-        elif cur is not None and "ffn_fused_kernel<0>" in name:
+        elif cur is not None and "ffn_fused_kernel<0" in name:
             ffn.append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
-        elif cur is not None and "ffn_fused_kernel<1>" in name:
+        elif cur is not None and "ffn_fused_kernel<1" in name:
             outp.append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
-        elif cur is not None and "ffn_fused_kernel<2>" in name:
+        elif cur is not None and "ffn_fused_kernel<2" in name:
             tail.append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
     n = max(len(s) for s in steps)
     steps = [s for s in steps if len(s) == n]

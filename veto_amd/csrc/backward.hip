@@ -223,7 +223,8 @@ __device__ __forceinline__ bf16x8 lds_tr_pair(const char* p0, const char* p1) {
   return __builtin_bit_cast(bf16x8, v);
 }
 
-template <int DH>
+// QF24: qkv holds 3-byte floats (common.h: rows of 1728 x 3 bytes) -- lossless here: every operand is split into bf16 hi + lo anyway
+template <int DH, bool QF24 = false>
 __global__ __launch_bounds__(128) void attention_backward_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
                                                                       float* __restrict__ dqkv, __bf16* __restrict__ dqkv_split,
                                                                       int n_pair, int heads, int cls_only) {
@@ -244,6 +245,7 @@ __global__ __launch_bounds__(128) void attention_backward_mfma_kernel(const floa
   auto plane = [&](int mat, int lo) { return base + (2 * mat + lo) * PLANE; };   // mat: 0 q, 1 k, 2 v, 3 dO
   float* stat = (float*)(base + 8 * PLANE);                                       // [3][32]: max, 1 / sum, D
   const float* src0 = qkv + (size_t)pair * kTokens * (3 * kDim) + head * DH;
+  const char* src24 = (const char*)qkv + ((size_t)pair * kTokens * (3 * kDim) + head * DH) * 3;      // (QF24)
   // cls_only (last layer): dout is compact [n_pair, 576]; the queries / output gradients of tokens 1..18 enter as zeros
   const float* gsrc = dout + (cls_only ? (size_t)pair * kDim : (size_t)pair * kTokens * kDim) + head * DH;
 
@@ -257,9 +259,16 @@ __global__ __launch_bounds__(128) void attention_backward_mfma_kernel(const floa
       ld[r][0] = f32x4{0.f, 0.f, 0.f, 0.f};
       ld[r][1] = f32x4{0.f, 0.f, 0.f, 0.f};
     } else if (e < 4 * PER_MAT) {
+      if (QF24 && mat < 3) {      // 8 values = 24 bytes (8-byte aligned: 16 + 8)
+        const char* sp = src24 + ((size_t)i * (3 * kDim) + mat * kDim + c * 8) * 3;
+        const u32x2 d01 = *(const u32x2*)sp, d23 = *(const u32x2*)(sp + 8), d45 = *(const u32x2*)(sp + 16);
+        ld[r][0] = unpack_f24x4(d01[0], d01[1], d23[0]);
+        ld[r][1] = unpack_f24x4(d23[1], d45[0], d45[1]);
+      } else {
       const float* src = mat < 3 ? src0 + (size_t)i * (3 * kDim) + mat * kDim + c * 8 : gsrc + (size_t)i * kDim + c * 8;
       ld[r][0] = *(const f32x4*)src;
       ld[r][1] = *(const f32x4*)(src + 4);
+      }
     }
   }
 #pragma unroll
@@ -604,12 +613,16 @@ static hipError_t launch_attention_backward_dh(const float* qkv, const float* do
 }
 
 hipError_t launch_attention_backward(const float* qkv, const float* dout, float* dqkv, __bf16* dqkv_split, int n_pair, int heads, int cls_only,
-                                     hipStream_t s) {
+                                     hipStream_t s, bool qkv_f24) {
   if (heads <= 0 || kDim % heads != 0 || n_pair <= 0 || (!dqkv == !dqkv_split)) return hipErrorInvalidValue;
   const int dh = kDim / heads;
+  if (qkv_f24 && dh != 72 && dh != 96) return hipErrorInvalidValue;      // (the MFMA form only)
   if (dh == 72 || dh == 96) {
     const unsigned blocks = (unsigned)(((long)n_pair * heads + 1) / 2);
-    if (dh == 72) VETO_LAUNCH(attention_backward_mfma_kernel<72>, dim3(blocks), dim3(128), 0, s, qkv, dout, dqkv, dqkv_split, n_pair, heads, cls_only);
+    if (qkv_f24) {
+      if (dh == 72) VETO_LAUNCH((attention_backward_mfma_kernel<72, true>), dim3(blocks), dim3(128), 0, s, qkv, dout, dqkv, dqkv_split, n_pair, heads, cls_only);
+      else VETO_LAUNCH((attention_backward_mfma_kernel<96, true>), dim3(blocks), dim3(128), 0, s, qkv, dout, dqkv, dqkv_split, n_pair, heads, cls_only);
+    } else if (dh == 72) VETO_LAUNCH(attention_backward_mfma_kernel<72>, dim3(blocks), dim3(128), 0, s, qkv, dout, dqkv, dqkv_split, n_pair, heads, cls_only);
     else VETO_LAUNCH(attention_backward_mfma_kernel<96>, dim3(blocks), dim3(128), 0, s, qkv, dout, dqkv, dqkv_split, n_pair, heads, cls_only);
     return hipGetLastError();
   }

@@ -495,6 +495,11 @@ __global__ __launch_bounds__(64 * (NCONS + NLOAD), 3) void gemm_split_ps_kernel(
               for (int e = 0; e < 4; ++e) v[e] = gelu_sigmoid(v[e]);
             }
             store_act4<kMixed ? FMT_MIXED : FMT_SPLIT>(g.c_split + (size_t)row * g.ldc, col, v);
+          } else if (EPI == EPI_PRE_GELU) {   // training: the pre-activation survives for gelu', its GELU is fc2's operand (was a pass of its own)
+            *(f32x4*)(g.c + (size_t)row * g.ldc_f32 + col) = v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+            store_act4<FMT_SPLIT>(g.c_split + (size_t)row * g.ldc, col, v);
           } else if (EPI == EPI_ATOMIC) {
             float* dstc = g.c + (size_t)row * g.ldc + col;
 #pragma unroll
@@ -557,6 +562,9 @@ hipError_t launch_ps_terms(GemmArgs g, int epi, int nblocks, hipStream_t s) {
     case EPI_RESID: VETO_LAUNCH((gemm_split_ps_kernel<NTERMS, EPI_RESID>), grid, block, 0, s, g); break;
     case EPI_GELU_SPLIT: VETO_LAUNCH((gemm_split_ps_kernel<NTERMS, EPI_GELU_SPLIT>), grid, block, 0, s, g); break;
     case EPI_SPLIT: VETO_LAUNCH((gemm_split_ps_kernel<NTERMS, EPI_SPLIT>), grid, block, 0, s, g); break;
+    case EPI_PRE_GELU:
+      if constexpr (NTERMS == 3) { VETO_LAUNCH((gemm_split_ps_kernel<NTERMS, EPI_PRE_GELU>), grid, block, 0, s, g); break; }
+      else return hipErrorInvalidValue;
     case EPI_ATOMIC:
       if (g.tn) VETO_LAUNCH((gemm_split_ps_kernel<NTERMS, EPI_ATOMIC, true>), grid, block, 0, s, g);
       else VETO_LAUNCH((gemm_split_ps_kernel<NTERMS, EPI_ATOMIC>), grid, block, 0, s, g);

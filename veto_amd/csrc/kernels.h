@@ -4,7 +4,7 @@
 
 namespace veto {
 
-enum Epi { EPI_F32 = 0, EPI_RESID = 1, EPI_GELU_SPLIT = 2, EPI_ATOMIC = 3, EPI_RESID_DROP = 4, EPI_F24 = 5, EPI_SPLIT = 6 };   // EPI_F24: EPI_F32 written as 3-byte floats (common.h); EPI_SPLIT: split rows, no activation
+enum Epi { EPI_F32 = 0, EPI_RESID = 1, EPI_GELU_SPLIT = 2, EPI_ATOMIC = 3, EPI_RESID_DROP = 4, EPI_F24 = 5, EPI_SPLIT = 6, EPI_PRE_GELU = 7 };   // EPI_F24: EPI_F32 written as 3-byte floats (common.h); EPI_SPLIT: split rows, no activation; EPI_PRE_GELU (training, split rows): the fp32 pre-activation to c (row stride ldc_f32) AND exact-erf gelu of it as split rows to c_split
 
 // C[M,N] = A[M,K] . W[N,K]^T with A and W in the split-row format (common.h): rows of 2K bf16.
 struct GemmArgs {
@@ -18,6 +18,7 @@ struct GemmArgs {
   long lda;            // A row stride in bf16 elements (0 = 2K)
   long ldr;
   long ldc;
+  long ldc_f32;        // EPI_PRE_GELU: row stride of c in floats (ldc is c_split's)
   int k_splits;          // EPI_ATOMIC: the reduction K is cut into this many equal ranges (K/32 % k_splits == 0), each a
                          // tile of its own that ADDS into c with fp32 atomics (c zero-initialised); 0/1 = one range
   // EPI_RESID_DROP (training only): EPI_RESID with dropout on (A.W^T + bias) before the residual is added; element (row, col) uses index
@@ -365,8 +366,9 @@ hipError_t launch_meet_sample(const MeetSampleArgs& a, hipStream_t s);
 // qkv, dqkv: [n_pair*19, 1728]; dout: [n_pair*19, 576] (gradient of the attention output before the out projection)
 // exactly one of dqkv (fp32 [n_pair*19, 1728]) and dqkv_split (split rows [n_pair*19, 2*1728]) is written
 // cls_only: dout is compact [n_pair, 576] (gradient of the CLS query's output only), q rows 1..18 of qkv are not read
+// qkv_f24 (head widths 72 / 96): qkv holds 3-byte floats (common.h), rows of 1728 x 3 bytes
 hipError_t launch_attention_backward(const float* qkv, const float* dout, float* dqkv, __bf16* dqkv_split, int n_pair, int heads, int cls_only,
-                                     hipStream_t s);
+                                     hipStream_t s, bool qkv_f24 = false);
 // dx = LayerNorm backward of dy w.r.t. x (+ dres if given); dgamma_dbeta [2, 576]; partial: workspace of
 // layernorm_backward_partial_floats(rows) floats
 size_t layernorm_backward_partial_floats(int rows);

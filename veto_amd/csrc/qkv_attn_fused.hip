@@ -319,7 +319,17 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_fused_kernel(QkvAttnArgs g) {
   // A wave's pieces (8 rows x 128 B each) are wl, wl + 4, ... of its range (wl = w & 3).
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
   const int wl = w & 3;
-  const bool lower = w < 4;
+  constexpr bool kRederiveLower = NB * MB * 4 > 160;      // (six heads only: see kRederive below)
+  // (a scalar 0 / 1 pinned in a scalar register, compared where it is used: as a plain bool the compiler carries the wave-uniform flag as a
+  // lane mask AND its complement, and at 180 accumulators it spilled a vector copy of it into the stage loop)
+  int lower_s = __builtin_amdgcn_readfirstlane(w < 4 ? 1 : 0);
+  asm volatile("" : "+s"(lower_s));
+  auto is_lower = [&]() {      // (laundered at every use: one scalar compare each, no lane mask that lives across the stage loop)
+    int t = lower_s;
+    if (kRederiveLower) asm volatile("" : "+s"(t));
+    return t != 0;
+  };
+#define lower is_lower()
   constexpr int kASplit = NWB == 3 ? QA_ASPLIT : 0;      // (even: a piece's swizzle parity is its index's)
   const int a_begin = lower ? 0 : kASplit, a_end = lower ? kASplit : APIECES;    // this wave's activation pieces: a_begin + wl + 4 k < a_end
   // Lane-dependent offsets are re-derived from the lane id where they are used (laundered through an empty asm: a few vector instructions
@@ -330,7 +340,9 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_fused_kernel(QkvAttnArgs g) {
   constexpr bool kRederive = NB * MB * 4 > 160;
   auto lane_now = [&]() {
     int l = lane;
-    if (kRederive) asm volatile("" : "+v"(l));
+    // (re-derived from the hardware, two instructions, rather than laundered from `lane`: at 180 accumulators a register that holds the
+    // lane id across the main loop is itself spilled, and its reload sat behind the first barrier of every sixth stage)
+    if (kRederive) asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
     return l;
   };
   // per-lane source offset of a piece: row (lane >> 3) of its 8, 16-byte slot (lane & 7) XOR-swizzled with the row's position in its 16-row block
@@ -442,7 +454,11 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_fused_kernel(QkvAttnArgs g) {
   for (int it = 0; it < my_tiles; ++it) {
     const int tile = tile_of(it);
     const int group = tile / H, head = tile - group * H;
-    const bool has_next = it + 1 < my_tiles;
+    // (pinned in a scalar register: out of scalar registers at 180 accumulators, the compiler otherwise keeps this flag as a 0 / 1 VECTOR
+    // value and spills THAT to scratch -- a reload in the stage loop, which waits for vmcnt(0) and with it for the wave's whole DMA queue)
+    int has_next_s = __builtin_amdgcn_readfirstlane(it + 1 < my_tiles ? 1 : 0);
+    if (kRederive) asm volatile("" : "+s"(has_next_s));
+    const bool has_next = has_next_s != 0;
     const TileSrc src = src_next;
     if (has_next) src_next = tile_src(tile_of(it + 1));
     f32x4 acc[NB][MB];
@@ -845,6 +861,8 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_fused_kernel(QkvAttnArgs g) {
   }
 #endif
 }
+
+#undef lower
 
 }  // namespace
 

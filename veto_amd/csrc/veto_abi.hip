@@ -92,7 +92,8 @@ struct veto_handle_s {
   std::map<std::string, int> index;
   float* raw = nullptr;      // fp32 copies of every state-dict tensor
   char* derived = nullptr;   // split planes, transposes, folded tables
-  bool dirty = true;
+  bool dirty = true;         // a weight was uploaded since the derived operands were built
+  bool infer_dirty = false;  // ... the training-side operands are current, the inference-only ones (mixed rows, layer-0 tables, folded last layer) are not
   // generation of the derived weight operands (bumped by every finalize_weights) and, per training workspace, the generation its
   // saved activations were computed with: veto_backward refuses a workspace whose forward saw other weights
   uint64_t weight_gen = 0;
@@ -189,29 +190,43 @@ struct ProfScope {
   }
 };
 
-int finalize_weights(veto_handle_t h, hipStream_t s) {
+// train_only: just the operands the training path reads (split rows of the Linears, the patch / pair-projection / head re-layouts).  A
+// training loop uploads every weight after every optimizer step; the mixed rows (a max-|w| reduction per tensor), the table form of
+// layer 0 and the folded last layer are the inference path's, and are built when an inference forward next needs them (infer_dirty).
+int finalize_weights(veto_handle_t h, hipStream_t s, bool train_only = false) {
   for (const Param& q : h->params)
     if (!q.loaded) return fail(VETO_ERR_WEIGHTS, "weight '%s' was never loaded", q.name.c_str());
   const int L = h->cfg.layers;
+  const bool base = h->dirty;      // (false: only the inference-side operands are missing)
   for (int l = 0; l < L; ++l) {
     LayerW& w = h->layers[l];
+    if (base) {
     HIP_TRY(launch_split_rows(h->p(lname(l, "0.fn.to_qkv.weight")), w.qkv, 3 * kDim, kDim, s));
     HIP_TRY(launch_split_rows(h->p(lname(l, "0.fn.to_out.0.weight")), w.out, kDim, kDim, s));
     HIP_TRY(launch_split_rows(h->p(lname(l, "1.fn.net.0.weight")), w.fc1, 2 * kDim, kDim, s));
     HIP_TRY(launch_split_rows(h->p(lname(l, "1.fn.net.3.weight")), w.fc2, kDim, 2 * kDim, s));
-    if (h->cfg.precision != VETO_PRECISE) {      // (VETO_FAST runs VETO_MIXED's launches, with the correction stages of the fused ones skipped)
+    }
+    if (h->cfg.precision != VETO_PRECISE && !train_only) {      // (VETO_FAST runs VETO_MIXED's launches, with the correction stages of the fused ones skipped)
       HIP_TRY(launch_mixed_weight_rows(h->p(lname(l, "0.fn.to_qkv.weight")), w.qkv_m, 3 * kDim, kDim, w.exp_m + 0, s));
       HIP_TRY(launch_mixed_weight_rows(h->p(lname(l, "0.fn.to_out.0.weight")), w.out_m, kDim, kDim, w.exp_m + 1, s));
       HIP_TRY(launch_mixed_weight_rows(h->p(lname(l, "1.fn.net.0.weight")), w.fc1_m, 2 * kDim, kDim, w.exp_m + 2, s));
       HIP_TRY(launch_mixed_weight_rows(h->p(lname(l, "1.fn.net.3.weight")), w.fc2_m, kDim, 2 * kDim, w.exp_m + 3, s));
     }
   }
+  if (base) {
   const std::string pe = std::string(kT) + "patch_embed.";
   HIP_TRY(launch_build_patch_weight(h->p(pe + "proj_d.weight"), h->p(pe + "proj_d.bias"), h->p(pe + "proj_v.weight"),
                                     h->p(pe + "proj_v.bias"), h->patch_w, h->patch_bias, s));
   HIP_TRY(launch_transpose_pair_proj(h->p("location_projection.0.weight"), h->loc_wt, kPosDim, s));
   HIP_TRY(launch_transpose_pair_proj(h->p("class_projection.0.weight"), h->cls_wt, h->cfg.embed_dim, s));
   HIP_TRY(launch_transpose_head(h->p("rel_out.weight"), h->head_wt, h->cfg.num_out, s));
+  }
+  if (train_only) {
+    h->dirty = false;
+    h->infer_dirty = true;
+    ++h->weight_gen;
+    return VETO_OK;
+  }
   {   // layer 0: Wqkv diag(gamma) and the weight-only vectors of the per-object form (fold_tmp holds >= 1728 x 576 floats)
     const std::string T0 = kT;
     HIP_TRY(launch_qkv0_consts(h->p(lname(0, "0.fn.to_qkv.weight")), h->layers[0].ln1_w, h->layers[0].ln1_b, h->p(T0 + "pos_embedding"),
@@ -244,8 +259,9 @@ int finalize_weights(veto_handle_t h, hipStream_t s) {
     HIP_TRY(launch_split_rows(h->fold_tmp, h->fold_n, (size_t)kDim, H * kDim, s));
     }
   }
+  if (base) ++h->weight_gen;      // (completing a training-side upload changes no operand a training workspace was computed with)
   h->dirty = false;
-  ++h->weight_gen;
+  h->infer_dirty = false;
   return VETO_OK;
 }
 
@@ -323,6 +339,7 @@ int run_gemm(veto_handle_t h, hipStream_t s, const char* name, const __bf16* a, 
   g.w = w + (size_t)w_row0 * 2 * K;
   g.bias = bias; g.resid = resid; g.c = c; g.c_split = c_split;
   g.M = M; g.N = N; g.K = K; g.ldr = ldr; g.ldc = ldc;
+  if (epi == EPI_PRE_GELU) g.ldc_f32 = N;      // (c = the fp32 pre-activation rows, contiguous; ldc is the split rows')
   const double kk = kb_tiles > 0 ? 32.0 * kb_steps : (double)K;
   const double flops = 2.0 * M * (double)N * kk;
   const double bytes = 4.0 * ((double)M * K + (double)N * kk) + (double)M * N * (epi == EPI_RESID ? 8.0 : epi == EPI_F24 ? 3.0 : 4.0);
@@ -535,7 +552,7 @@ static int forward_impl(veto_handle_t h, void* stream, const veto_inputs_t* in, 
     return fail(VETO_ERR_INVALID, "batch too large");
   hipStream_t s = (hipStream_t)stream;
   HIP_TRY(hipSetDevice(h->cfg.device));
-  if (h->dirty) {
+  if (h->dirty || h->infer_dirty) {
     int rc = finalize_weights(h, s);
     if (rc != VETO_OK) return rc;
   }
@@ -937,6 +954,14 @@ struct TrainWs {
   size_t total;
 };
 
+// q / k / v of the training path as 3-byte floats (common.h) between the QKV projection, the attention and the attention backward: all
+// three split them into 16-bit hi + lo parts anyway, so the 16-bit significand in memory is what they would have kept -- 1.7 KB per token
+// row and layer less to keep and to move (round 6).  MFMA head widths only; VETO_TRAIN_QKV_F24=0: fp32.
+bool train_qkv_f24(veto_handle_t h) {
+  static const bool off = env_knob_is("VETO_TRAIN_QKV_F24", "0");
+  return !off && (h->dh == 72 || h->dh == 96);
+}
+
 TrainWs carve_train(char* base, veto_handle_t h, int n_obj, int n_pair) {
   TrainWs w;
   size_t off = 0;
@@ -959,7 +984,7 @@ TrainWs carve_train(char* base, veto_handle_t h, int n_obj, int n_pair) {
     TrainLayer& t = w.layers[l];
     t.xin = (float*)take(mpad * kDim * 4);
     t.a1 = (__bf16*)take(mpad * 2 * kDim * 2);
-    t.qkv = (float*)take(mpad * 3 * kDim * 4);
+    t.qkv = (float*)take(mpad * 3 * kDim * (train_qkv_f24(h) ? 3 : 4));
     t.ao = (__bf16*)take(mpad * 2 * kDim * 2);
     t.xmid = (float*)take(mpad * kDim * 4);
     t.a2 = (__bf16*)take(mpad * 2 * kDim * 2);
@@ -1103,7 +1128,7 @@ int veto_forward_train(veto_handle_t h, void* stream, const veto_inputs_t* in, c
   if (!out_logits) return fail(VETO_ERR_INVALID, "null out_logits");
   hipStream_t s = (hipStream_t)stream;
   HIP_TRY(hipSetDevice(h->cfg.device));
-  if (h->dirty) { rc = finalize_weights(h, s); if (rc) return rc; }
+  if (h->dirty) { rc = finalize_weights(h, s, true); if (rc) return rc; }
   h->train_gen.erase(workspace);     // (stamped at the end: a failed forward leaves no workspace that veto_backward would accept)
   const int n_obj = in->n_obj, n_pair = in->n_pair, L = h->cfg.layers, H = h->cfg.heads, n_out = h->cfg.num_out;
   const int M = n_pair * kTokens;
@@ -1140,6 +1165,8 @@ int veto_forward_train(veto_handle_t h, void* stream, const veto_inputs_t* in, c
     a.drop_seed = d.seed; a.drop_thresh = d.thresh; a.drop_scale = d.scale;
     HIP_TRY(launch_assemble(a, s));
   }
+  const bool q24 = train_qkv_f24(h);
+  const int qepi = q24 ? EPI_F24 : EPI_F32;
   for (int l = 0; l < L; ++l) {
     const LayerW& w = h->layers[l];
     TrainLayer& t = ws.layers[l];
@@ -1147,43 +1174,43 @@ int veto_forward_train(veto_handle_t h, void* stream, const veto_inputs_t* in, c
       // Last layer: only x[:, 0] reaches the loss (model_veto.py:23), so -- as at inference -- keys / values cover the 19
       // tokens, everything behind the attention runs on the CLS row of each pair.  The saved activations of this layer
       // (ao, xmid, a2, pre, hid, ws.xout) are COMPACT: row p = pair p.  The backward mirrors this.
-      rc = run_gemm(h, s, "gemm_kv_last", t.a1, w.qkv, nullptr, nullptr, 0, t.qkv + kDim, nullptr, 3 * kDim, M, 2 * kDim, kDim, EPI_F32, 0,
-                    kDim);
+      rc = run_gemm(h, s, "gemm_kv_last", t.a1, w.qkv, nullptr, nullptr, 0, q24 ? (float*)((char*)t.qkv + 3 * kDim) : t.qkv + kDim, nullptr,
+                    3 * kDim, M, 2 * kDim, kDim, qepi, 0, kDim);
       if (rc) return rc;
       rc = run_gemm(h, s, "gemm_q_cls", t.a1, w.qkv, nullptr, nullptr, 0, t.qkv, nullptr, (long)kTokens * 3 * kDim, n_pair, kDim, kDim,
-                    EPI_F32, (long)kTokens * 2 * kDim, 0);
+                    qepi, (long)kTokens * 2 * kDim, 0);
       if (rc) return rc;
       {
         AttnArgs a{};
-        a.qkv = t.qkv; a.n_pair = n_pair; a.heads = H; a.cls_only = 1; a.o = t.ao;
+        a.qkv = t.qkv; a.n_pair = n_pair; a.heads = H; a.cls_only = 1; a.o = t.ao; a.qkv_f24 = q24 ? 1 : 0;
         HIP_TRY(launch_attention(a, s));
       }
       rc = run_gemm(h, s, "gemm_out_cls", t.ao, w.out, w.out_b, t.xin, (long)kTokens * kDim, t.xmid, nullptr, kDim, n_pair, kDim, kDim,
                     EPI_RESID, 0, 0, drop_site(opts, 3 + l));
       if (rc) return rc;
       HIP_TRY(launch_layernorm(t.xmid, kDim, w.ln2_w, w.ln2_b, t.a2, n_pair, s));
-      rc = run_gemm(h, s, "gemm_fc1_cls", t.a2, w.fc1, w.fc1_b, nullptr, 0, t.pre, nullptr, 2 * kDim, n_pair, 2 * kDim, kDim, EPI_F32);
+      rc = run_gemm(h, s, "gemm_fc1_cls", t.a2, w.fc1, w.fc1_b, nullptr, 0, t.pre, t.hid, 4 * kDim, n_pair, 2 * kDim, kDim, EPI_PRE_GELU);
       if (rc) return rc;
-      HIP_TRY(launch_gelu_split(t.pre, t.hid, (size_t)n_pair, 2 * kDim, s));
       rc = run_gemm(h, s, "gemm_fc2_cls", t.hid, w.fc2, w.fc2_b, t.xmid, kDim, ws.xout, nullptr, kDim, n_pair, kDim, 2 * kDim, EPI_RESID);
       if (rc) return rc;
       break;
     }
     float* xnext = ws.layers[l + 1].xin;
-    rc = run_gemm(h, s, "gemm_qkv", t.a1, w.qkv, nullptr, nullptr, 0, t.qkv, nullptr, 3 * kDim, M, 3 * kDim, kDim, EPI_F32);
+    rc = run_gemm(h, s, "gemm_qkv", t.a1, w.qkv, nullptr, nullptr, 0, t.qkv, nullptr, 3 * kDim, M, 3 * kDim, kDim, qepi);
     if (rc) return rc;
     {
       AttnArgs a{};
-      a.qkv = t.qkv; a.n_pair = n_pair; a.heads = H; a.cls_only = 0; a.o = t.ao;
+      a.qkv = t.qkv; a.n_pair = n_pair; a.heads = H; a.cls_only = 0; a.o = t.ao; a.qkv_f24 = q24 ? 1 : 0;
       HIP_TRY(launch_attention(a, s));
     }
     rc = run_gemm(h, s, "gemm_out", t.ao, w.out, w.out_b, t.xin, kDim, t.xmid, nullptr, kDim, M, kDim, kDim, EPI_RESID, 0, 0,
                   drop_site(opts, 3 + l));
     if (rc) return rc;
     HIP_TRY(launch_layernorm(t.xmid, kDim, w.ln2_w, w.ln2_b, t.a2, M, s));
-    rc = run_gemm(h, s, "gemm_fc1", t.a2, w.fc1, w.fc1_b, nullptr, 0, t.pre, nullptr, 2 * kDim, M, 2 * kDim, kDim, EPI_F32);
+    // (the epilogue writes the fp32 pre-activation -- gelu' needs it -- AND its exact-erf GELU as fc2's split rows: round 6; before, a pass
+    // of its own read the pre-activation back, 0.55 ms per layer)
+    rc = run_gemm(h, s, "gemm_fc1", t.a2, w.fc1, w.fc1_b, nullptr, 0, t.pre, t.hid, 4 * kDim, M, 2 * kDim, kDim, EPI_PRE_GELU);
     if (rc) return rc;
-    HIP_TRY(launch_gelu_split(t.pre, t.hid, (size_t)M, 2 * kDim, s));
     rc = run_gemm(h, s, "gemm_fc2", t.hid, w.fc2, w.fc2_b, t.xmid, kDim, xnext, nullptr, kDim, M, kDim, 2 * kDim, EPI_RESID);
     if (rc) return rc;
     HIP_TRY(launch_layernorm(xnext, kDim, h->layers[l + 1].ln1_w, h->layers[l + 1].ln1_b, ws.layers[l + 1].a1, M, s));
@@ -1255,7 +1282,7 @@ int veto_backward(veto_handle_t h, void* stream, const veto_inputs_t* in, const 
     rc = run_linear_backward(h, s, ws, ws.dmid, R, kDim, t.ao, kDim, h->p(lname(l, "0.fn.to_out.0.weight")),
                              G(lname(l, "0.fn.to_out.0.weight")), G(lname(l, "0.fn.to_out.0.bias")), ws.dtmp, drop);
     if (rc) return rc;
-    HIP_TRY(launch_attention_backward(t.qkv, ws.dtmp, nullptr, ws.dsplit, n_pair, H, last ? 1 : 0, s));
+    HIP_TRY(launch_attention_backward(t.qkv, ws.dtmp, nullptr, ws.dsplit, n_pair, H, last ? 1 : 0, s, train_qkv_f24(h)));
     const float* dres = ws.dmid;
     if (last) {
       // the residual gradient d x_mid lives on the CLS rows only: spread the compact rows over a zeroed token matrix
