@@ -164,10 +164,23 @@ __device__ __forceinline__ void att_static_for(F&& f) {
 #ifndef TAB_SPLIT_LOADS
 #define TAB_SPLIT_LOADS 1      // 0: every chunk of the table form requested up front (round 4; two waves per SIMD)
 #endif
+// -DVETO_ATT_STAMPS: a diagnostic build that sums s_memtime deltas per phase over all waves (tools/att_stamps.py prints them): where an
+// item's time goes -- issue of the gathers, the wait for their first use, conversion, S^T, softmax, V conversion, P V, the output stores
+#ifdef VETO_ATT_STAMPS
+__device__ unsigned long long g_att_stamps[8192 * 10];      // one slot per item (mod 8192): plain stores, no atomics in the timed kernel
+#define ATT_T(k) do { __builtin_amdgcn_sched_barrier(0); unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); \
+                      __builtin_amdgcn_sched_barrier(0); att_dt[k] = t_ - att_t; att_t = t_; } while (0)
+#else
+#define ATT_T(k)
+#endif
 template <int DH, bool TAB = false, bool F24 = false>
 __global__ __launch_bounds__(64 * ATT_WPB, TAB && (!TAB_SPLIT_LOADS || DH > 72) ? 2 : 3) void attention_mfma_kernel(AttnArgs a) {
   static_assert(!(TAB && F24), "the per-object form reads fp32 tables");
   saturating_conversions_on();   // (the mixed-row output path converts without clamps, common.h)
+#ifdef VETO_ATT_STAMPS
+  unsigned long long att_t, att_dt[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(att_t)::"memory");
+#endif
   constexpr int KS = (DH + 15) / 16;        // k-steps of QK^T (the upper half of the last one may lie behind the row: masked in registers)
   // bytes per row of the Q / K / V images (bf16; round 5: no contraction padding).  The pitch decides the bank conflicts of the fragment reads
   // (ds_read_b128: 16 rows per lane group, bank = (a / 4) mod 64): 144 B (DH = 72) puts the 16 rows of a group on 16 different bank quadruples;
@@ -185,7 +198,11 @@ __global__ __launch_bounds__(64 * ATT_WPB, TAB && (!TAB_SPLIT_LOADS || DH > 72) 
   constexpr int V_PLANE = (kTokens + 1) * RB;
   constexpr int O_BYTES = kTokens * DH * 4;
   constexpr int PHASE2 = 2 * V_PLANE + O_BYTES;
-  constexpr int WAVE_LDS = ((4 * QK_PLANE > PHASE2 ? 4 * QK_PLANE : PHASE2) + 64 + 15) & ~15;      // (+64: over-reads behind the last row stay inside)
+  // TAB (round 6): behind the images, the head's c2 (3 DH floats) and the pair's 19 rstd values, staged ONCE per item -- they were a global
+  // load per chunk and per token of every round (27 vector-memory instructions per item on a kernel that is bound by exactly those)
+  constexpr int kConstBytes = TAB ? (3 * DH * 4 + 32 * 4) : 0;
+  constexpr int kImgBytes = ((4 * QK_PLANE > PHASE2 ? 4 * QK_PLANE : PHASE2) + 64 + 15) & ~15;      // (+64: over-reads behind the last row stay inside)
+  constexpr int WAVE_LDS = kImgBytes + kConstBytes;
   constexpr int CH = DH / 8;                // 8-element chunks per row
   constexpr int PER_MAT = kTokens * CH;
   constexpr int ROUNDS = (3 * PER_MAT + 63) / 64;
@@ -210,9 +227,16 @@ __global__ __launch_bounds__(64 * ATT_WPB, TAB && (!TAB_SPLIT_LOADS || DH > 72) 
   char* v_lo = v_hi + V_PLANE;
 
   // ---- global -> registers (all loads in flight), then -> bf16 hi/lo LDS images ----------------
-  f32x4 ld[ROUNDS][2];
-  f32x4 ldb[TAB ? ROUNDS : 1][2];     // TAB: the object-side table row of a patch token
-  float rs[TAB ? ROUNDS : 1];         // TAB: rstd of the token row
+  // TAB (round 6): the gathers go out in 16-byte PIECES, consecutive lanes on consecutive pieces of a row (a row of the head's slice is
+  // DH / 4 pieces = 288 contiguous bytes): one wave instruction then touches ~11 cache lines.  Rounds 3-5 gave a lane a 32-byte chunk as
+  // two loads (+0, +16): each of the two instructions touched the ~23 lines of all 64 chunks, and the in-kernel timeline
+  // (profiles/r06_attention_stamps.txt) showed the kernel bound by the issue of its vector-memory instructions -- 8.3 k of an item's
+  // 29.8 k cycles issuing 36 gathers, 10 k more in the conversion phase waiting for the per-chunk loads of c2 and rstd.
+  constexpr int PC = DH / 4;                        // pieces per row
+  constexpr int PER_MAT4 = kTokens * PC;
+  constexpr int ROUNDS4 = (3 * PER_MAT4 + 63) / 64;
+  f32x4 ld[TAB ? 1 : ROUNDS][2];      // (not TAB) a lane's 32-byte chunk of round r
+  f32x4 lt[TAB ? ROUNDS4 : 1], lo_[TAB ? ROUNDS4 : 1];      // TAB: subject-side piece (or the plain row's), object-side piece
   const int pair = (int)(item / a.heads), head = (int)(item % a.heads);
   const float* src0 = a.qkv + (size_t)pair * kTokens * (3 * kDim) + head * DH;
   const float* tab_s = nullptr;
@@ -221,24 +245,51 @@ __global__ __launch_bounds__(64 * ATT_WPB, TAB && (!TAB_SPLIT_LOADS || DH > 72) 
     tab_s = a.sw + (size_t)a.subj[pair] * kPatchTokens * (3 * kDim) + head * DH;
     tab_o = a.ow + (size_t)a.obj[pair] * kPatchTokens * (3 * kDim) + head * DH;
   }
-  // TAB: two table rows per chunk are twice the registers in flight, so the chunks go out in two groups: the rounds that hold a Q or K
-  // chunk now, the V-only rounds behind the Q / K conversion (their latency then lies under S^T and the softmax) -- the peak is ~110
-  // registers instead of 170 and the kernel runs three waves per SIMD without spilling (round 4 had two).
-  constexpr int kLateFrom = TAB_SPLIT_LOADS && TAB ? (2 * PER_MAT + 63) / 64 : ROUNDS;     // first round without a Q / K chunk
+  // TAB: two table rows per piece are twice the registers in flight, so the pieces go out in two groups: the rounds that hold a Q or K
+  // piece now, the V-only rounds behind the Q / K conversion (their latency then lies under S^T and the softmax) -- the kernel runs three
+  // waves per SIMD without spilling (round 4 had two).
+  constexpr int kLateFrom = TAB ? (TAB_SPLIT_LOADS ? (2 * PER_MAT4 + 63) / 64 : ROUNDS4) : ROUNDS;     // first round without a Q / K piece
+  constexpr int kRounds = TAB ? ROUNDS4 : ROUNDS;
+  float* const c2_lds = (float*)(base + kImgBytes);                 // TAB: [3 DH] c2 of this head | [32] rstd of the pair's token rows
+  float* const rs_lds = c2_lds + 3 * DH;
+  if constexpr (TAB) {
+    // (one or two vector-memory instructions for c2, 16 bytes per lane, and one for the 19 rstd values)
+    constexpr int NC2 = 3 * DH / 4;      // 54 pieces (eight heads), 72 (six: a second, partial instruction)
+#pragma unroll
+    for (int idx0 = 0; idx0 < NC2; idx0 += 64) {
+      const int idx = idx0 + lane;
+      if (idx < NC2) {
+        const int mat = idx / PC, c4 = idx % PC;
+        *(f32x4*)(c2_lds + idx * 4) = *(const f32x4*)(a.vec + head * DH + mat * kDim + c4 * 4);
+      }
+    }
+    if (lane < kTokens) rs_lds[lane] = a.stats[((size_t)pair * kTokens + lane) * 2 + 1];
+  }
   auto load_round = [&](auto r_tag) {
     constexpr int r = decltype(r_tag)::value;
     const int e = lane + 64 * r;
+    if constexpr (TAB) {
+      const int mat = e / PER_MAT4, rem = e % PER_MAT4, i = rem / PC, c4 = rem % PC;
+      const bool need = e < 3 * PER_MAT4;
+      lo_[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (need && i >= 1 && i <= kPatchTokens) {
+        // (32-bit byte offsets from wave-uniform bases: the saddr form of the loads, no 64-bit vector arithmetic)
+        const unsigned off = (unsigned)(((i - 1) * (3 * kDim) + mat * kDim + c4 * 4) * 4);
+        // (the store to lt[r] last, as in the other branches: the compiler merges the branches' trailing stores, and a merged store to
+        // "lt[r] or lo_[r]" keeps both arrays in scratch memory)
+        lo_[r] = *(const f32x4*)((const char*)tab_o + off);
+        lt[r] = *(const f32x4*)((const char*)tab_s + off);
+      } else if (need) {
+        const unsigned off = (unsigned)((mat * kDim + c4 * 4) * 4) + (i == 0 ? 0u : (unsigned)(i * (3 * kDim) * 4));
+        const char* src = i == 0 ? (const char*)(a.vec + 2 * (3 * kDim) + head * DH) : (const char*)src0;
+        lt[r] = *(const f32x4*)(src + off);
+      } else {
+        lt[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    } else {
     const int mat = e / PER_MAT, rem = e % PER_MAT, i = rem / CH, c = rem % CH;
     const bool need = e < 3 * PER_MAT && !(a.cls_only && mat == 0 && i > 0);
-    if (TAB && need && i >= 1 && i <= kPatchTokens) {
-      // (32-bit byte offsets from wave-uniform bases: the saddr form of the loads, no 64-bit vector arithmetic)
-      const unsigned off = (unsigned)(((i - 1) * (3 * kDim) + mat * kDim + c * 8) * 4);
-      ld[r][0] = *(const f32x4*)((const char*)tab_s + off);
-      ld[r][1] = *(const f32x4*)((const char*)tab_s + off + 16u);
-      ldb[TAB ? r : 0][0] = *(const f32x4*)((const char*)tab_o + off);
-      ldb[TAB ? r : 0][1] = *(const f32x4*)((const char*)tab_o + off + 16u);
-      rs[TAB ? r : 0] = *(const float*)((const char*)(a.stats + (size_t)pair * kTokens * 2 + 1) + (unsigned)(i * 8));
-    } else if (F24 && need) {
+    if (F24 && need) {
       // (the six dwords are kept packed in ld[r][0] / the first half of ld[r][1] until the conversion below)
       const char* src = (const char*)a.qkv + (((size_t)pair * kTokens + i) * (3 * kDim) + mat * kDim + head * DH + c * 8) * 3;
       // 24 bytes at an 8-byte-aligned address as 16 + 8 (two vector-memory instructions per chunk instead of three: 27 -> 18 load
@@ -249,35 +300,50 @@ __global__ __launch_bounds__(64 * ATT_WPB, TAB && (!TAB_SPLIT_LOADS || DH > 72) 
       ld[r][0] = f32x4{__uint_as_float(d01[0]), __uint_as_float(d01[1]), __uint_as_float(d01[2]), __uint_as_float(d01[3])};
       ld[r][1] = f32x4{__uint_as_float(d2[0]), __uint_as_float(d2[1]), 0.f, 0.f};
     } else if (need) {
-      const unsigned off = (unsigned)((mat * kDim + c * 8) * 4) + (TAB && i == 0 ? 0u : (unsigned)(i * (3 * kDim) * 4));
-      const char* src = TAB && i == 0 ? (const char*)(a.vec + 2 * (3 * kDim) + head * DH) : (const char*)src0;
-      ld[r][0] = *(const f32x4*)(src + off);
-      ld[r][1] = *(const f32x4*)(src + off + 16u);
+      const unsigned off = (unsigned)((mat * kDim + c * 8) * 4) + (unsigned)(i * (3 * kDim) * 4);
+      ld[r][0] = *(const f32x4*)((const char*)src0 + off);
+      ld[r][1] = *(const f32x4*)((const char*)src0 + off + 16u);
     } else {
       ld[r][0] = f32x4{0.f, 0.f, 0.f, 0.f};
       ld[r][1] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
+    }
   };
   att_static_for<0, kLateFrom>(load_round);
-  // Conversion of the loaded chunks into the bf16 hi / lo images.  PHASE 0: the Q and K chunks (and, TAB, the table arithmetic of
-  // every chunk, so that only its result stays in registers); PHASE 1, behind S^T: the V chunks into the transposed images.
+  ATT_T(0);      // index arithmetic + issue of the early gathers
+  // Conversion of the loaded chunks / pieces into the 16-bit hi / lo images.  PHASE 0: the Q and K ones (and, TAB, the table arithmetic of
+  // every early round's pieces, so that only its result stays in registers); PHASE 1, behind S^T: the V ones into the V images.
   auto convert = [&](auto phase_tag) {
     constexpr int PHASE = decltype(phase_tag)::value;
+    if constexpr (TAB) {
+      att_static_for<0, ROUNDS4>([&](auto r_tag) {
+        constexpr int r = decltype(r_tag)::value;
+        // (rounds that hold no piece of this phase; phase 0 visits the early rounds' V pieces too, for the table arithmetic)
+        if constexpr (!(PHASE == 0 ? r >= kLateFrom : 64 * r + 63 < 2 * PER_MAT4)) {
+          const int e = lane + 64 * r;
+          const int mat = e / PER_MAT4, rem = e % PER_MAT4, i = rem / PC, c4 = rem % PC;
+          if (e < 3 * PER_MAT4) {
+            // (the table arithmetic of a round runs in the phase that first sees the round's data: phase 0 for the early rounds, phase 1 for the late)
+            if ((PHASE == 0 ? r < kLateFrom : r >= kLateFrom) && i >= 1 && i <= kPatchTokens)      // rstd (SW + OW) + c2
+              lt[r] = rs_lds[i] * (lt[r] + lo_[r]) + *(const f32x4*)(c2_lds + mat * DH + c4 * 4);
+            if (PHASE == 0 ? mat < 2 : mat == 2) {
+              uint32_t h0, l0, h1, l1;
+              att_split2(lt[r][0], lt[r][1], h0, l0);
+              att_split2(lt[r][2], lt[r][3], h1, l1);
+              char* dst = (PHASE == 0 ? (mat == 0 ? q_hi : k_hi) : v_hi) + i * RB + c4 * 8;
+              *(u32x2*)dst = u32x2{h0, h1};
+              *(u32x2*)(dst + (PHASE == 0 ? QK_PLANE : V_PLANE)) = u32x2{l0, l1};
+            }
+          }
+        }
+      });
+    } else {
 #pragma unroll
     for (int r = 0; r < ROUNDS; ++r) {
-      // (rounds that hold no chunk of this phase; TAB: phase 0 visits the V rounds too, for the table arithmetic)
-      if (PHASE == 0 ? ((!TAB || r >= kLateFrom) && 64 * r >= 2 * PER_MAT) : 64 * r + 63 < 2 * PER_MAT) continue;
+      if (PHASE == 0 ? 64 * r >= 2 * PER_MAT : 64 * r + 63 < 2 * PER_MAT) continue;      // (rounds that hold no chunk of this phase)
       const int e = lane + 64 * r;
       if (e >= 3 * PER_MAT) continue;
       const int mat = e / PER_MAT, rem = e % PER_MAT, i = rem / CH, c = rem % CH;
-      // (the table arithmetic of a round runs in the phase that first sees the round's data: phase 0 for the early rounds -- their V chunks
-      // included, so that only the result stays in registers --, phase 1 for the late ones)
-      if ((PHASE == 0 ? r < kLateFrom : r >= kLateFrom) && TAB && i >= 1 && i <= kPatchTokens) {     // rstd (SW + OW) + c2 (c2: 3 * DH floats per head, L1-resident)
-        const float* c2 = a.vec + head * DH + mat * kDim + c * 8;
-        const f32x4 c20 = *(const f32x4*)c2, c21 = *(const f32x4*)(c2 + 4);
-        ld[r][0] = rs[TAB ? r : 0] * (ld[r][0] + ldb[TAB ? r : 0][0]) + c20;
-        ld[r][1] = rs[TAB ? r : 0] * (ld[r][1] + ldb[TAB ? r : 0][1]) + c21;
-      }
       if (PHASE == 0 ? mat == 2 : mat < 2) continue;
       f32x4 v0 = ld[r][0], v1 = ld[r][1];
       if constexpr (F24) {      // (rows that were not read hold zeros, which unpack to zeros)
@@ -300,9 +366,16 @@ __global__ __launch_bounds__(64 * ATT_WPB, TAB && (!TAB_SPLIT_LOADS || DH > 72) 
         *(u32x4*)(dst + V_PLANE) = lo;
       }
     }
+    }
   };
+#ifdef VETO_ATT_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  ATT_T(1);      // wait for the early gathers (all of them: the stamped build drains here)
+#endif
   convert(IntTag<0>());
-  att_static_for<kLateFrom, ROUNDS>(load_round);      // (TAB: the V-only rounds; in flight under S^T)
+  ATT_T(2);      // table arithmetic + Q / K conversion + image stores
+  att_static_for<kLateFrom, kRounds>(load_round);      // (TAB: the V-only rounds; in flight under S^T)
+  ATT_T(3);      // issue of the late gathers
 
   // ---- S^T = K Q^T: row = key j, column = query i ----------------------------------------------
   const int r = lane & 31, h = lane >> 5;
@@ -324,6 +397,7 @@ __global__ __launch_bounds__(64 * ATT_WPB, TAB && (!TAB_SPLIT_LOADS || DH > 72) 
     st = att_mfma(kh, qh, st);
   }
 
+  ATT_T(4);      // S^T (fragment reads + 15 / 18 MFMAs)
   // ---- softmax over the keys of query (lane & 31): 16 registers here + 16 in lane ^ 32 ---------
   const float scale = 1.0f / sqrtf((float)DH);
   float p[16];
@@ -352,9 +426,15 @@ __global__ __launch_bounds__(64 * ATT_WPB, TAB && (!TAB_SPLIT_LOADS || DH > 72) 
     pl[t >> 3][(t & 7) >> 1] = l2;
   }
 
+  ATT_T(5);      // softmax + probability split
   // ---- the V^T images over the Q / K images: every ds_read of those has returned (each was waited for in front of its MFMA, and a
   // wave's LDS operations complete in order)
+#ifdef VETO_ATT_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  ATT_T(6);      // wait for the late gathers
+#endif
   convert(IntTag<1>());
+  ATT_T(7);      // V table arithmetic + conversion + image stores
   if (lane < 2 * (RB / 16)) {       // image row 19: the zero row (keys 19..31)
     const int pln = lane >= RB / 16;
     *(u32x4*)(base + pln * V_PLANE + kTokens * RB + (lane - pln * (RB / 16)) * 16) = u32x4{0u, 0u, 0u, 0u};
@@ -403,6 +483,7 @@ __global__ __launch_bounds__(64 * ATT_WPB, TAB && (!TAB_SPLIT_LOADS || DH > 72) 
       }
     }
   }
+  ATT_T(8);      // P V (transposed fragment reads + 18 MFMAs) + staging of the output rows
   const int nq = a.cls_only ? 1 : kTokens;
 #pragma unroll
   for (int e0 = 0; e0 < (kTokens * CH + 63) / 64 * 64; e0 += 64) {     // (a fixed trip count: the compiler can then count the stores
@@ -431,6 +512,13 @@ __global__ __launch_bounds__(64 * ATT_WPB, TAB && (!TAB_SPLIT_LOADS || DH > 72) 
     *(bf16x8*)dst = hi;
     *(bf16x8*)(dst + 32) = lo;
   }
+#ifdef VETO_ATT_STAMPS
+  ATT_T(9);      // output conversion + stores (issue; the stores drain behind the wave's end)
+  if (lane == 0) {
+    unsigned long long* slot = g_att_stamps + (size_t)(item & 8191) * 10;
+    for (int k = 0; k < 10; ++k) slot[k] = att_dt[k];
+  }
+#endif
 }
 
 
@@ -885,6 +973,25 @@ hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
       if (!a.ow || !a.stats || !a.vec || !a.subj || !a.obj || a.cls_only) return hipErrorInvalidValue;
       if (dh == 72) VETO_LAUNCH((attention_mfma_kernel<72, true>), dim3(blocks), dim3(64 * ATT_WPB), 0, s, a);
       else VETO_LAUNCH((attention_mfma_kernel<96, true>), dim3(blocks), dim3(64 * ATT_WPB), 0, s, a);
+#ifdef VETO_ATT_STAMPS
+      {
+        static unsigned long long all[8192 * 10];
+        unsigned long long host[10] = {0};
+        hipDeviceSynchronize();
+        hipMemcpyFromSymbol(all, HIP_SYMBOL(g_att_stamps), sizeof(all));
+        const long nslots = items < 8192 ? items : 8192;
+        for (long i = 0; i < nslots; ++i)
+          for (int k = 0; k < 10; ++k) host[k] += all[i * 10 + k];
+        const double n = (double)nslots;
+        static const char* names[10] = {"issue of the early gathers", "wait for the early gathers", "table arithmetic + Q / K conversion", "issue of the late gathers",
+                                        "S^T", "softmax", "wait for the late gathers", "V arithmetic + conversion", "P V + staging", "output conversion + stores"};
+        double tot = 0;
+        for (int k = 0; k < 10; ++k) tot += host[k] / n;
+        fprintf(stderr, "[attention stamps, table form, dh %d, last %.0f items] mean shader-clock cycles per item (s_memtime) and share:\n", dh, n);
+        for (int k = 0; k < 10; ++k) fprintf(stderr, "    %-38s %8.1f  %5.1f %%\n", names[k], host[k] / n, 100.0 * host[k] / n / tot);
+        fprintf(stderr, "    %-38s %8.1f\n", "sum", tot);
+      }
+#endif
     } else if (a.qkv_f24) {
       if (dh == 72) VETO_LAUNCH((attention_mfma_kernel<72, false, true>), dim3(blocks), dim3(64 * ATT_WPB), 0, s, a);
       else VETO_LAUNCH((attention_mfma_kernel<96, false, true>), dim3(blocks), dim3(64 * ATT_WPB), 0, s, a);
