@@ -79,6 +79,15 @@
 #ifndef FFN_PINGPONG
 #define FFN_PINGPONG 0
 #endif
+// 1: the LayerNorm rows of both epilogues leave as ONE 16-byte store per lane and 4 columns instead of two 8-byte stores (fp16 part, e4m3
+// part): the lane pair that holds 8 adjacent columns of a row exchanges halves (a quad-permute DPP move in the final epilogue, where the
+// pair is adjacent lanes; v_permlane16_swap in the mid-panel one, where it is 16 lanes apart), the even lane stores the 16 bytes of fp16
+// values, the odd one the 16 bytes of e4m3 planes -- 36 instead of 72 store instructions per wave and epilogue.  Measured (round 6, same
+// box, 287 280 rows): 2.229 / 2.222 / 2.224 ms with 8-byte stores, 2.234 / 2.202 / 2.208 with these: -0.5 % at best -- the panel
+// boundary is bound neither by its store-instruction count (this) nor by its bytes (VETO_X_F24).  Kept: fewer instructions, same results
+#ifndef FFN_LN16
+#define FFN_LN16 1
+#endif
 // TIMING PROBE (results are WRONG): the correction stages of the FeedForward (fc1, fc2; not the out projection) as block-scaled fp6
 // (e2m3) operands -- the K = 128 MFMA in its fp6 form (6 registers per operand, half the cycles of the e4m3 form), 96 instead of 128 bytes
 // of every row per correction stage through the LDS-DMA (12 + 18 instead of 16 + 24 pieces of an fc1 stage, 18 instead of 24 of an fc2
@@ -620,7 +629,14 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs g) {
         asm volatile("" : "+v"(nmean[m]), "+v"(rstd2[m]));   // (also keeps the compiler from carrying the 144 differences x - mean of
                                                              // pass 2 into the loop below: it did, and spilled them)
         const int row = row0 + m * 16;
-        lrow[m] = (gchar_t*)((!MID && MODE == 2 && g.ln1_out ? g.ln1_out : g.ln_out) + (size_t)(row < g.M ? row : g.M - 1) * kRow1 + mixed_h_offset(col0));
+#if FFN_LN16
+        // (even lane of a pair: the fp16 part at its own columns; odd lane: the e4m3 part, starting at its partner's group -- the column
+        // offset of a later block adds the same number of bytes to both: mixed_h_offset(cofs) == mixed_x_offset(cofs) - 128 for cofs % 4 == 0)
+        const int lbase = (q & 1) ? mixed_x_offset(col0) - 8 : mixed_h_offset(col0);
+#else
+        const int lbase = mixed_h_offset(col0);
+#endif
+        lrow[m] = (gchar_t*)((!MID && MODE == 2 && g.ln1_out ? g.ln1_out : g.ln_out) + (size_t)(row < g.M ? row : g.M - 1) * kRow1 + lbase);
         asm volatile("" : "+v"(lrow[m]));
       }
 #pragma unroll
@@ -638,6 +654,26 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs g) {
             const f32x4 y = {ylo[0], ylo[1], yhi[0], yhi[1]};
             u32x2 h, xy;
             mixed_pack4(y, h, xy);
+#if FFN_LN16
+            {
+              const bool odd = (q & 1) != 0;
+              const uint32_t s0 = odd ? h[0] : xy[0], s1 = odd ? h[1] : xy[1];      // what the partner stores
+              uint32_t r0, r1;
+              if constexpr (MID) {      // partner = lane ^ 16: rows of 16 lanes swapped pairwise
+                typedef unsigned u2v __attribute__((ext_vector_type(2)));
+                const u2v a0 = __builtin_amdgcn_permlane16_swap(s0, s0, false, false), a1 = __builtin_amdgcn_permlane16_swap(s1, s1, false, false);
+                r0 = odd ? a0[0] : a0[1];
+                r1 = odd ? a1[0] : a1[1];
+              } else {                  // partner = lane ^ 1
+                r0 = (uint32_t)__builtin_amdgcn_mov_dpp((int)s0, 0xB1, 0xf, 0xf, true);
+                r1 = (uint32_t)__builtin_amdgcn_mov_dpp((int)s1, 0xB1, 0xf, 0xf, true);
+              }
+              const u32x4 v16 = odd ? u32x4{r0, r1, xy[0], xy[1]} : u32x4{h[0], h[1], r0, r1};
+              typedef __attribute__((address_space(1))) u32x4 gu32x4_t;
+              if (row0 + m * 16 < g.M) *(gu32x4_t*)(lrow[m] + mixed_h_offset(cofs)) = v16;
+              continue;
+            }
+#endif
             if (row0 + m * 16 < g.M) {
 #if FFN_NT & 2
               if constexpr (!MID) {
