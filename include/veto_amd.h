@@ -39,7 +39,11 @@ enum veto_status {
 };
 
 enum veto_precision {
-  VETO_PRECISE = 0,  /* 3-term split-bf16 MFMA, meets the 1e-3 logit tolerance (2-3e-5 measured) */
+  VETO_PRECISE = 0,  /* 3-term split-bf16 MFMA on every Linear, meets the 1e-3 logit tolerance (2-3e-5 measured).  Range: the Linears'
+                        operands keep the fp32 exponent range; the ATTENTION products (every mode, the training path included) split
+                        q / k / v and the probabilities into fp16 hi + fp16 lo planes (22 significant bits): |q|, |k|, |v| beyond 65504
+                        saturate there and components below ~2^-24 are dropped -- both far outside what LayerNorm'ed rows times
+                        weights produce (O(10)); no audit counts them */
   VETO_FAST = 1,     /* single-pass form of VETO_MIXED (round 6; rounds 1-5: a single bf16 pass of every GEMM): the same launches
                         on the same operand rows, but the two fused token-row launches of a layer (QKV + attention, layer tail) skip the
                         correction stages -- the fp16 main product alone, neither loading nor multiplying the e4m3 planes.  The measured

@@ -937,14 +937,8 @@ hipError_t launch_panel(FfnArgs g, int mode, hipStream_t s) {
   if (g.fast && (mode != 2 || g.resid_f24 || g.out_f24)) return hipErrorInvalidValue;      // (the single-pass form: the layer tail on fp32 residual rows)
   if ((g.resid_f24 || g.out_f24) && (mode != 2 || !g.resid_f24)) return hipErrorInvalidValue;      // (3-byte rows: the layer tail only; never f32 in, 3 bytes out)
   if (g.resid_f24 != g.out_f24 && (const void*)g.resid == (const void*)g.out) return hipErrorInvalidValue;   // (rows of different pitch cannot be rewritten in place)
-  static int num_cu = 0;
-  if (num_cu == 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorInvalidDevice;
-    num_cu = prop.multiProcessorCount;
-    if (num_cu < 1) num_cu = 1;
-  }
+  int num_cu = device_cu_count();
+  if (num_cu < 1) return hipErrorInvalidDevice;
   g.n_panels = (g.M + FR - 1) / FR;
   static const int late = env_knob_int("VETO_FFN_LATE", 90);      // (speed only; 0 in one arm of the parity tests)
   g.late = late;

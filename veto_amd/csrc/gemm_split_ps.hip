@@ -590,14 +590,10 @@ hipError_t launch_gemm_split(GemmArgs g, int epi, int precision, hipStream_t s) 
 
 // g.tiles_m / g.tiles_n / g.lda are already filled by launch_gemm_split.
 hipError_t launch_gemm_split_ps(GemmArgs g, int epi, int precision, hipStream_t s) {
-  static int num_cu = 0;
-  if (num_cu == 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorInvalidDevice;
-    num_cu = prop.multiProcessorCount / 8 * 8;
-    if (num_cu < 8) num_cu = 8;
-  }
+  int num_cu = device_cu_count();
+  if (num_cu < 1) return hipErrorInvalidDevice;
+  num_cu = num_cu / 8 * 8;
+  if (num_cu < 8) num_cu = 8;
   const int ksp = epi == EPI_ATOMIC && g.k_splits > 1 ? g.k_splits : 1;
   if ((g.K / BK) % ksp != 0) return hipErrorInvalidValue;
   if (g.kb_tiles > 0 && (ksp != 1 || g.tn || g.fmt == FMT_MIXED || g.kb_steps <= 0 || g.tiles_n % g.kb_tiles != 0 ||

@@ -50,6 +50,9 @@ struct GemmArgs {
 bool env_knob_is(const char* name, const char* value);   // the variable is set to exactly `value`
 int env_knob_int(const char* name, int dflt);
 int gemm_rows_padded(int m);
+// compute units of the CURRENT device (hipGetDevice), cached per device ordinal: the persistent kernels size their grids with it
+// (a process-wide cache of the first device's count would be wrong on a node with unlike devices); <= 0 on error
+int device_cu_count();
 // precision: 0 = three split-bf16 terms, 1 = one; g.fmt == FMT_MIXED selects the fp16 + e4m3 kernel regardless
 hipError_t launch_gemm_split(GemmArgs g, int epi, int precision, hipStream_t s);
 hipError_t launch_gemm_split_ps(GemmArgs g, int epi, int precision, hipStream_t s);

@@ -877,14 +877,10 @@ size_t qkv_attn_rows_padded(int n_pair) { return (size_t)((n_pair + TP - 1) / TP
 
 hipError_t launch_qkv_attn_fused(const QkvAttnArgs& g, hipStream_t s) {
   if (!g.a || !g.w || !g.w_exp || !g.o || g.n_pair <= 0 || !qkv_attn_fused_supports(g.heads)) return hipErrorInvalidValue;
-  static int num_cu = 0;
-  if (num_cu == 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorInvalidDevice;
-    num_cu = prop.multiProcessorCount / 8 * 8;
-    if (num_cu < 8) num_cu = 8;
-  }
+  int num_cu = device_cu_count();
+  if (num_cu < 1) return hipErrorInvalidDevice;
+  num_cu = num_cu / 8 * 8;
+  if (num_cu < 8) num_cu = 8;
   const int ntiles = (g.n_pair + TP - 1) / TP * g.heads;
   int nblocks = num_cu;       // one persistent workgroup per CU (the whole LDS each)
   if (ntiles < nblocks) nblocks = (ntiles + 7) / 8 * 8;

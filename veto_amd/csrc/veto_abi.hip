@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <map>
 #include <string>
 #include <vector>
@@ -67,6 +68,15 @@ namespace veto {
 bool env_knob_is(const char* name, const char* value) {
   const char* v = getenv(name);
   return v && !strcmp(v, value);
+}
+int device_cu_count() {
+  static std::atomic<int> cache[64];      // per device ordinal; 0 = not queried yet (a benign race: every thread stores the same value)
+  int dev = 0, cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0) return -1;
+  if (dev < 64 && (cus = cache[dev].load(std::memory_order_relaxed)) > 0) return cus;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) return -1;
+  if (dev < 64) cache[dev].store(cus, std::memory_order_relaxed);
+  return cus;
 }
 int env_knob_int(const char* name, int dflt) {
   const char* v = getenv(name);
