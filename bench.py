@@ -417,11 +417,13 @@ def extra_lines(args, dev, batch, sd):
 def train_line(args, dev, batch, sd, steps=3):
     """One training step of the same architecture on the same batch (BASELINE configs 3-5 are training configs): veto_forward_train +
     veto_ce_loss + veto_backward through autograd (every layer on all 19 tokens, activations kept, 3-term split-bf16 operands -- none of
-    the inference path's fused kernels), SGD step outside the timed forward / backward spans.  A driver-observed number, no tuning
-    target of this round.  Reference: roi_relation_predictors.py:4129-4136, tools/relation_train_net.py:372-380."""
+    the inference path's fused kernels), SGD step outside the timed forward / backward spans.  training_memory_gb = the peak minus what
+    this process held before the training model was built.  Reference: roi_relation_predictors.py:4129-4136, tools/relation_train_net.py:372-380."""
     from veto_amd import synth, testing
     from veto_amd.pairs import prepare_test_pairs
     torch.cuda.empty_cache()
+    torch.cuda.reset_peak_memory_stats(dev)
+    resident = torch.cuda.memory_allocated(dev)      # what the headline model of this process still holds (its inference workspace)
     model = testing.make_predictor(testing.make_config(args.layers, args.heads), sd, dev).train()
     props = testing.make_proposals(batch, "predcls", dev)
     pairs = prepare_test_pairs(dev, props)
@@ -454,7 +456,8 @@ def train_line(args, dev, batch, sd, steps=3):
     return {"workload": "one training step (forward + weighted-CE loss + backward + SGD) of the headline architecture on the same 12 x %d batch, "
                         "dropout at the reference's rates" % args.objs, "steps": steps, "ms_per_step": wall / steps * 1e3,
             "pairs_per_s": n / (wall / steps), "forward_ms": t_f / steps, "backward_ms": t_b / steps, "loss": float(loss.detach()),
-            "peak_memory_gb": round(peak, 1), "dtype": "bf16x3 (split-bf16 MFMA, fp32 accumulate)"}
+            "peak_memory_gb": round(peak, 1), "training_memory_gb": round(peak - resident / 2 ** 30, 1),
+            "dtype": "bf16x3 (split-bf16 MFMA, fp32 accumulate)"}
 
 
 def usable_cores():
