@@ -417,8 +417,8 @@ def extra_lines(args, dev, batch, sd):
 def train_line(args, dev, batch, sd, steps=3):
     """One training step of the same architecture on the same batch (BASELINE configs 3-5 are training configs): veto_forward_train +
     veto_ce_loss + veto_backward through autograd (every layer on all 19 tokens, activations kept, 3-term split-bf16 operands -- none of
-    the inference path's fused kernels), SGD step outside the timed forward / backward spans.  training_memory_gb = the peak minus what
-    this process held before the training model was built.  Reference: roi_relation_predictors.py:4129-4136, tools/relation_train_net.py:372-380."""
+    the inference path's fused kernels), SGD step outside the timed forward / backward spans.  peak_memory_gb is the process's peak
+    (resident_before_gb of it were held before the training model was built); train_workspace_gb is the path's own workspace.  Reference: roi_relation_predictors.py:4129-4136, tools/relation_train_net.py:372-380."""
     from veto_amd import synth, testing
     from veto_amd.pairs import prepare_test_pairs
     torch.cuda.empty_cache()
@@ -451,12 +451,15 @@ def train_line(args, dev, batch, sd, steps=3):
             t_f += ev[0].elapsed_time(ev[1])
             t_b += ev[1].elapsed_time(ev[2])
     peak = torch.cuda.max_memory_allocated(dev) / 2 ** 30
-    del model, opt
+    ws = model.__dict__.get("_train_ws")      # the cached activation + scratch workspace of veto_forward_train / veto_backward
+    ws_gb = ws.numel() * ws.element_size() / 2 ** 30 if torch.is_tensor(ws) else None
+    del model, opt, ws
     torch.cuda.empty_cache()
     return {"workload": "one training step (forward + weighted-CE loss + backward + SGD) of the headline architecture on the same 12 x %d batch, "
                         "dropout at the reference's rates" % args.objs, "steps": steps, "ms_per_step": wall / steps * 1e3,
             "pairs_per_s": n / (wall / steps), "forward_ms": t_f / steps, "backward_ms": t_b / steps, "loss": float(loss.detach()),
-            "peak_memory_gb": round(peak, 1), "training_memory_gb": round(peak - resident / 2 ** 30, 1),
+            "peak_memory_gb": round(peak, 1), "resident_before_gb": round(resident / 2 ** 30, 1),
+            "train_workspace_gb": round(ws_gb, 1) if ws_gb is not None else None,
             "dtype": "bf16x3 (split-bf16 MFMA, fp32 accumulate)"}
 
 
