@@ -420,3 +420,17 @@ def test_training_workspace_is_released_without_a_backward_and_weights_refresh()
         model.load_state_dict(sd)
         d = torch.cat(list(model(props, pairs, None, None, roi_features=rgb, roi_depth_features=dep)[1]))
         assert (d - a).abs().max() < 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env", [{"VETO_TRAIN_LN_SPLIT": "1"}, {"VETO_TRAIN_GELU_EPI": "0", "VETO_TRAIN_QKV_F24": "0"}],
+                         ids=["ln-backward-emits-split-rows", "round5-forms"])
+def test_training_variants_behind_the_knobs_match_reference_gradients(env):
+    """The forms of the training path that a knob selects (read once per process, hence a child process): the LayerNorm backward that emits the
+    split rows of the Linear behind it (round 6: measured slower, off by default), and round 5's forms of what round 6 changed (gelu' as a pass
+    of its own, fp32 q / k / v).  Same gradient and finite-difference tests as the default path."""
+    import subprocess
+    import sys
+    picked = "(test_training_backward_matches_reference_gradients or test_training_dropout_masks_are_seeded) and (train_vanilla- or train_meet_vg or seeded)"
+    subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k", picked, "-p", "no:cacheprovider"],
+                   env=dict(os.environ, **env), check=True, timeout=900, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

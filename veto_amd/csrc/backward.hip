@@ -460,12 +460,28 @@ constexpr int kLnLanes = 32;                       // lanes per row: 18 values p
 constexpr int kLnSlots = 256 / kLnLanes;           // rows in flight per block
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+// SPLIT (round 6): the result is the gradient matrix of the Linear behind this LayerNorm in the backward chain, so its split rows (the
+// operand of that Linear's two gradient GEMMs) and the column sums of every 32 rows (its bias gradient's partials, [rows / 32, 576]) leave
+// from here, with the forward's dropout mask applied where the Linear's output was dropped (drop_thresh != 0: the attention out
+// projection) -- the preparation pass that read the matrix back (train.hip, prep_grad_kernel) is gone for these Linears.
+template <bool SPLIT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void layernorm_backward_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                                  const float* __restrict__ gamma, const float* dres,
-                                                                 float* dx, float* __restrict__ partial, int rows) {   // dres may be dx
+                                                                 float* dx, float* __restrict__ partial, int rows,      // dres may be dx
+                                                                 __bf16* __restrict__ split_out, float* __restrict__ colp,
+                                                                 unsigned long long drop_seed, unsigned drop_thresh, float drop_scale) {
   __shared__ float s_dg[kDim], s_db[kDim], s_w[kDim];
-  for (int c = threadIdx.x; c < kDim; c += 256) { s_dg[c] = 0.f; s_db[c] = 0.f; s_w[c] = gamma[c]; }
+  __shared__ float s_cs[SPLIT ? 2 : 1][SPLIT ? kDim : 1];
+  for (int c = threadIdx.x; c < kDim; c += 256) {
+    s_dg[c] = 0.f; s_db[c] = 0.f; s_w[c] = gamma[c];
+    if (SPLIT) { s_cs[0][c] = 0.f; s_cs[SPLIT ? 1 : 0][c] = 0.f; }
+  }
   __syncthreads();
+  f32x2 acc_c[SPLIT ? 9 : 1];
+  if (SPLIT) {
+#pragma unroll
+    for (int j = 0; j < 9; ++j) acc_c[j] = f32x2{0.f, 0.f};
+  }
   const int q = threadIdx.x & (kLnLanes - 1);
   auto gsum = [](float t) {
 #pragma unroll
@@ -478,9 +494,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
     acc_g[j] = f32x2{0.f, 0.f};
     acc_b[j] = f32x2{0.f, 0.f};
   }
+  // (SPLIT: the column sums of rows 0..31 and 32..63 of the block are flushed behind iterations 3 and 7)
+  auto flush_cs = [&](int grp) {
+    if constexpr (SPLIT) {
+#pragma unroll
+      for (int j = 0; j < 9; ++j)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          atomicAdd(&s_cs[grp][2 * (q + kLnLanes * j) + e], acc_c[j][e]);
+          acc_c[j][e] = 0.f;
+        }
+    }
+  };
   for (int it = 0; it < kLnRowsPerBlock / kLnSlots; ++it) {
     const int row = blockIdx.x * kLnRowsPerBlock + it * kLnSlots + threadIdx.x / kLnLanes;
-    if (row >= rows) continue;      // uniform per half wave
+    if (row >= rows) {      // uniform per half wave
+      if (SPLIT && (it & 3) == 3) flush_cs(it >> 2);
+      continue;
+    }
     const float* xr = x + (size_t)row * kDim;
     const float* gr = dy + (size_t)row * kDim;
     f32x2 xv[9], gv[9];
@@ -523,7 +554,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
       for (int e = 0; e < 2; ++e) o[e] = rstd * (gv[j][e] - mg - xv[j][e] * mgx);
       if (dres) o += *(const f32x2*)(dres + (size_t)row * kDim + 2 * (q + kLnLanes * j));
       *(f32x2*)(dr + 2 * (q + kLnLanes * j)) = o;
+      if constexpr (SPLIT) {
+        const int c = 2 * (q + kLnLanes * j);
+        if (drop_thresh) {
+#pragma unroll
+          for (int e = 0; e < 2; ++e) o[e] = dropout_keep(drop_seed, (unsigned long long)row * kDim + c + e, drop_thresh) ? o[e] * drop_scale : 0.f;
+        }
+        acc_c[j] += o;
+        __bf16 h0, l0, h1, l1;
+        split_bf16(o[0], h0, l0);
+        split_bf16(o[1], h1, l1);
+        __bf16* d = split_out + (size_t)row * (2 * kDim) + split_index(c);
+        *(bf16x2*)d = bf16x2{h0, h1};
+        *(bf16x2*)(d + 32) = bf16x2{l0, l1};
+      }
     }
+    if (SPLIT && (it & 3) == 3) flush_cs(it >> 2);
   }
 #pragma unroll
   for (int j = 0; j < 9; ++j)
@@ -536,6 +582,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
   __syncthreads();
   float* pr = partial + (size_t)blockIdx.x * 2 * kDim;
   for (int c = threadIdx.x; c < kDim; c += 256) { pr[c] = s_dg[c]; pr[kDim + c] = s_db[c]; }
+  if constexpr (SPLIT) {
+    float* cp = colp + (size_t)blockIdx.x * 2 * kDim;      // two rows of partials per block: rows 0..31, rows 32..63
+    for (int c = threadIdx.x; c < kDim; c += 256) { cp[c] = s_cs[0][c]; cp[kDim + c] = s_cs[1][c]; }
+  }
 }
 
 // out[c] = sum over `n_rows` rows of src[r][c], rows folded in order, in double: used for the LayerNorm partials and
@@ -637,10 +687,16 @@ size_t layernorm_backward_partial_floats(int rows) {
   return (size_t)((rows + kLnRowsPerBlock - 1) / kLnRowsPerBlock) * 2 * kDim + (size_t)kColChunks * 2 * kDim;
 }
 
+int layernorm_backward_col_partials(int rows) { return (rows + kLnRowsPerBlock - 1) / kLnRowsPerBlock * 2; }
+
 hipError_t launch_layernorm_backward(const float* x, const float* dy, const float* gamma, const float* dres, float* dx,
-                                     float* dgamma_dbeta, float* partial, int rows, hipStream_t s) {
+                                     float* dgamma_dbeta, float* partial, int rows, hipStream_t s, __bf16* split_out, float* colp,
+                                     unsigned long long drop_seed, unsigned drop_thresh, float drop_scale) {
   const int blocks = (rows + kLnRowsPerBlock - 1) / kLnRowsPerBlock;
-  VETO_LAUNCH(layernorm_backward_kernel, dim3(blocks), dim3(256), 0, s, x, dy, gamma, dres, dx, partial, rows);
+  if (!split_out != !colp) return hipErrorInvalidValue;
+  if (split_out) VETO_LAUNCH(layernorm_backward_kernel<true>, dim3(blocks), dim3(256), 0, s, x, dy, gamma, dres, dx, partial, rows, split_out, colp,
+                             drop_seed, drop_thresh, drop_scale);
+  else VETO_LAUNCH(layernorm_backward_kernel<false>, dim3(blocks), dim3(256), 0, s, x, dy, gamma, dres, dx, partial, rows, nullptr, nullptr, 0ull, 0u, 1.f);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   return launch_column_sums(partial, 2 * kDim, blocks, 2 * kDim, dgamma_dbeta, partial + (size_t)blocks * 2 * kDim, kColChunks, s);

@@ -226,6 +226,17 @@ __device__ __forceinline__ float gelu_erf(float x) {
   return 0.5f * x * (1.0f + copysignf(erf_abs, x));
 }
 
+// d/dx of the exact-erf GELU, Phi(x) + x phi(x), with the same erf approximation: exp(-z^2) of z = |x| / sqrt(2) IS exp(-x^2 / 2), so the
+// density shares the one exponential (|error| <= 1e-7 absolute; the training path's fc2 input-gradient epilogue)
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
+  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  const float e = __expf(-z * z);
+  const float cdf = 0.5f * (1.0f + copysignf(1.0f - poly * e, x));
+  return cdf + x * (0.39894228040143267794f * e);
+}
+
 // The same function through ONE exponential: x Phi(x) = x sigmoid(g(x)) with g = logit(Phi) fitted by an odd polynomial of
 // degree 11 on [-6, 6] (minimax-reweighted least squares, tools/precision_study.py --gelu; |error| <= 1e-6 absolute in fp32,
 // beyond +-6 Phi is 0 / 1 to 1e-9).  10 VALU + 2 transcendental instructions against 17 + 2: the FeedForward epilogue of the

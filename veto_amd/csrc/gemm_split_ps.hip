@@ -121,7 +121,8 @@ __global__ __launch_bounds__(64 * (NCONS + NLOAD), 3) void gemm_split_ps_kernel(
   constexpr bool kMixed = NTERMS == 2;                     // fp16 + e4m3 operands (mixed rows)
   if constexpr (kMixed) saturating_conversions_on();       // (only these instantiations can write mixed rows: the fc1 epilogue)
   static_assert(!(kMixed && TN), "the mixed-row format has no transposed (weight-gradient) form");
-  constexpr int EPI = kDrop ? (int)EPI_RESID : EPI_T;
+  constexpr bool kGeluBwd = EPI_T == EPI_GELU_BWD;         // training-only: the residual machinery reads the pre-activation, the result leaves as split rows
+  constexpr int EPI = kDrop || kGeluBwd ? (int)EPI_RESID : EPI_T;
   __shared__ __attribute__((aligned(16))) char smem[kLdsBytes];
 
   const int tid = threadIdx.x;
@@ -473,7 +474,13 @@ __global__ __launch_bounds__(64 * (NCONS + NLOAD), 3) void gemm_split_ps_kernel(
           for (int e = 0; e < 4; ++e)
             t[e] = __int_as_float(__builtin_amdgcn_ds_bpermute(perm_addr, __float_as_int(acc[n][m][e])));
         }
-        if (EPI == EPI_RESID && !kDrop) {
+        if (kGeluBwd) {
+          // dH * gelu'(pre); rows past M contribute zeros to the column sums below (they are never stored)
+          f32x4 v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = row < g.M ? t[e] * gelu_erf_grad(res[u & 1][j][e]) : 0.f;
+          acc[n][m] = v;
+        } else if (EPI == EPI_RESID && !kDrop) {
           // every lane consumes its residual load (rows past M read a clamped row): a load left pending on a skipped
           // path would have to be waited for -- behind this tile's stores -- when the k-loop reuses its register
           f32x4 v = t + res[u & 1][j];
@@ -514,7 +521,35 @@ __global__ __launch_bounds__(64 * (NCONS + NLOAD), 3) void gemm_split_ps_kernel(
         }
       }
     }
-    if (EPI == EPI_RESID) {
+    if (kGeluBwd) {
+      // column sums of this wave's 64 rows (bias gradient partials): per column block the four row groups, then the 16 lanes that hold the
+      // block's rows (lane = 4 row + chunk with the transposition, 16 chunk + row without); a fixed order: deterministic
+      float* cp = g.col_partial + (size_t)(tile_m * 4 + wm) * g.N + col0;
+#pragma unroll
+      for (int n = 0; n < 6; ++n) {
+        f32x4 sum = (acc[n][0] + acc[n][1]) + (acc[n][2] + acc[n][3]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float x = sum[e];
+          if (kEpiT) { x += __shfl_xor(x, 4, 64); x += __shfl_xor(x, 8, 64); x += __shfl_xor(x, 16, 64); x += __shfl_xor(x, 32, 64); }
+          else { x += __shfl_xor(x, 1, 64); x += __shfl_xor(x, 2, 64); x += __shfl_xor(x, 4, 64); x += __shfl_xor(x, 8, 64); }
+          sum[e] = x;
+        }
+        if (er == 0) *(f32x4*)(cp + n * 16) = sum;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int m = u >> 1, h = u & 1;
+        const int row = row0 + m * 16;
+        if (row < g.M) {
+#pragma unroll
+          for (int j = 0; j < 3; ++j) {
+            const int n = h * 3 + j;
+            store_act4<FMT_SPLIT>(g.c_split + (size_t)row * g.ldc, col0 + n * 16, acc[n][m]);
+          }
+        }
+      }
+    } else if (EPI == EPI_RESID) {
       // Two phases: loads, stores and LDS-DMA share ONE in-order counter per wave, so a residual load issued behind a store
       // cannot return before that store has drained -- and with every CU in its epilogue at once the stores drain slowly (the
       // store-only epilogue of a 256 x 192 tile takes ~10 k cycles).  Interleaved (load group m+1, store group m) the eight units
@@ -565,6 +600,12 @@ hipError_t launch_ps_terms(GemmArgs g, int epi, int nblocks, hipStream_t s) {
     case EPI_PRE_GELU:
       if constexpr (NTERMS == 3) { VETO_LAUNCH((gemm_split_ps_kernel<NTERMS, EPI_PRE_GELU>), grid, block, 0, s, g); break; }
       else return hipErrorInvalidValue;
+    case EPI_GELU_BWD:
+      if constexpr (NTERMS == 3) {
+        if (!g.resid || !g.c_split || !g.col_partial || g.bias) return hipErrorInvalidValue;
+        VETO_LAUNCH((gemm_split_ps_kernel<NTERMS, EPI_GELU_BWD>), grid, block, 0, s, g);
+        break;
+      } else return hipErrorInvalidValue;
     case EPI_ATOMIC:
       if (g.tn) VETO_LAUNCH((gemm_split_ps_kernel<NTERMS, EPI_ATOMIC, true>), grid, block, 0, s, g);
       else VETO_LAUNCH((gemm_split_ps_kernel<NTERMS, EPI_ATOMIC>), grid, block, 0, s, g);

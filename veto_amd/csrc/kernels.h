@@ -4,7 +4,7 @@
 
 namespace veto {
 
-enum Epi { EPI_F32 = 0, EPI_RESID = 1, EPI_GELU_SPLIT = 2, EPI_ATOMIC = 3, EPI_RESID_DROP = 4, EPI_F24 = 5, EPI_SPLIT = 6, EPI_PRE_GELU = 7 };   // EPI_F24: EPI_F32 written as 3-byte floats (common.h); EPI_SPLIT: split rows, no activation; EPI_PRE_GELU (training, split rows): the fp32 pre-activation to c (row stride ldc_f32) AND exact-erf gelu of it as split rows to c_split
+enum Epi { EPI_F32 = 0, EPI_RESID = 1, EPI_GELU_SPLIT = 2, EPI_ATOMIC = 3, EPI_RESID_DROP = 4, EPI_F24 = 5, EPI_SPLIT = 6, EPI_PRE_GELU = 7, EPI_GELU_BWD = 8 };   // EPI_F24: EPI_F32 written as 3-byte floats (common.h); EPI_SPLIT: split rows, no activation; EPI_PRE_GELU (training, split rows): the fp32 pre-activation to c (row stride ldc_f32) AND exact-erf gelu of it as split rows to c_split
 
 // C[M,N] = A[M,K] . W[N,K]^T with A and W in the split-row format (common.h): rows of 2K bf16.
 struct GemmArgs {
@@ -19,6 +19,10 @@ struct GemmArgs {
   long ldr;
   long ldc;
   long ldc_f32;        // EPI_PRE_GELU: row stride of c in floats (ldc is c_split's)
+  // EPI_GELU_BWD (training, split rows): the input gradient of fc2 times gelu'(pre) -- resid = the fp32 pre-activation (row stride ldr) --
+  // written straight as the split rows of fc1's backward (c_split, ldc), with the column sums of every 64-row slice of a tile (the rows of
+  // one wave row) to col_partial[(tile_m * 4 + wave row) * N + column]: the bias gradient's partials, folded by launch_column_sums
+  float* col_partial;
   int k_splits;          // EPI_ATOMIC: the reduction K is cut into this many equal ranges (K/32 % k_splits == 0), each a
                          // tile of its own that ADDS into c with fp32 atomics (c zero-initialised); 0/1 = one range
   // EPI_RESID_DROP (training only): EPI_RESID with dropout on (A.W^T + bias) before the residual is added; element (row, col) uses index
@@ -375,8 +379,13 @@ hipError_t launch_attention_backward(const float* qkv, const float* dout, float*
 // dx = LayerNorm backward of dy w.r.t. x (+ dres if given); dgamma_dbeta [2, 576]; partial: workspace of
 // layernorm_backward_partial_floats(rows) floats
 size_t layernorm_backward_partial_floats(int rows);
+// split_out / colp (both or neither): also write the result's split rows [rows, 2 * 576] (with the dropout mask of site drop_seed applied
+// when drop_thresh != 0: element (row, col) -> index row * 576 + col) and layernorm_backward_col_partials(rows) rows of column sums [*, 576]
+// of those rows -- what launch_prep_grad would produce from dx, for the Linear behind this LayerNorm in the backward chain
+int layernorm_backward_col_partials(int rows);
 hipError_t launch_layernorm_backward(const float* x, const float* dy, const float* gamma, const float* dres, float* dx,
-                                     float* dgamma_dbeta, float* partial, int rows, hipStream_t s);
+                                     float* dgamma_dbeta, float* partial, int rows, hipStream_t s, __bf16* split_out = nullptr,
+                                     float* colp = nullptr, unsigned long long drop_seed = 0, unsigned drop_thresh = 0, float drop_scale = 1.f);
 // out[c] = sum_r dy[r][c]; partial: workspace [n_chunks, n_cols]; column_sums_chunks() chunks keep every stage short
 int column_sums_chunks();
 hipError_t launch_column_sums(const float* dy, long ld, int rows, int n_cols, float* out, float* partial, int n_chunks, hipStream_t s);

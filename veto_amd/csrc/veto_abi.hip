@@ -956,6 +956,8 @@ struct TrainWs {
   // backward scratch
   float *dx, *dmid, *dtmp, *dbig;
   __bf16 *dsplit, *wdg, *zero;
+  __bf16* dsplit_b;   // the last two thirds of dsplit: rows of 2 * 1152 bf16 (the fc2 input-gradient epilogue writes fc1's gradient rows there
+                      // while its own operand, rows of 2 * 576 bf16, occupies the first third)
   float *ln_partial, *col_partial, *colp, *dgb, *head_partial;
   float *dpatch, *dlc, *dpos, *dpre, *xhat, *bn_out, *dbn_out, *emb, *demb, *prob, *dloc_wt, *dcls_wt, *dwcat_t;
   __bf16* wcat_t;   // Wcat^T [2112, 2*1152] split rows: weight operand of the patch projection's input gradient
@@ -970,6 +972,22 @@ struct TrainWs {
 bool train_qkv_f24(veto_handle_t h) {
   static const bool off = env_knob_is("VETO_TRAIN_QKV_F24", "0");
   return !off && (h->dh == 72 || h->dh == 96);
+}
+
+// dpre = dh * gelu'(pre) in the epilogue of fc2's input-gradient GEMM (round 6); VETO_TRAIN_GELU_EPI=0: inside the operand preparation of
+// the fc1 backward, a pass of its own over an fp32 copy of dh (rounds 1-5)
+bool train_gelu_epilogue() {
+  static const bool off = env_knob_is("VETO_TRAIN_GELU_EPI", "0");
+  return !off;
+}
+
+// VETO_TRAIN_LN_SPLIT=1 (off by default; round 6, measured SLOWER): the LayerNorm backward kernels emit the split rows and bias partials of the
+// Linear behind them instead of a preparation pass per Linear reading the fp32 gradient rows back.  63.0 ms per step with, 61.6 without on one
+// box: the kernel is at its register limit (two statistics passes over 18 values per lane and tensor) and spills with the extra column
+// sums, split conversion and dropout hash, and its 4-byte split stores are slower than the pass they replace.  Kept as a tested variant.
+bool train_ln_emits_split() {
+  static const bool on = env_knob_is("VETO_TRAIN_LN_SPLIT", "1");
+  return on;
 }
 
 TrainWs carve_train(char* base, veto_handle_t h, int n_obj, int n_pair) {
@@ -1005,11 +1023,13 @@ TrainWs carve_train(char* base, veto_handle_t h, int n_obj, int n_pair) {
   w.dx = (float*)take(mpad * kDim * 4);
   w.dmid = (float*)take(mpad * kDim * 4);
   w.dtmp = (float*)take(mpad * kDim * 4);
-  w.dbig = (float*)take(mpad * 3 * kDim * 4);
+  // (fc2's input gradient as fp32 rows [M, 1152]: only the VETO_TRAIN_GELU_EPI=0 form writes it; sized [M, 1728] until round 6, 2 GB at cfg-2)
+  w.dbig = (float*)take(train_gelu_epilogue() ? 256 : mpad * 2 * kDim * 4);
   {   // the token-row gradients (6 * 576 bf16 per row) and, for the input gradient of the patch projection, the split rows of
       // dpatch (prow rows x 2 * 1152 bf16) share this buffer: size it for the larger (n_obj * 16 can exceed 19 * n_pair / 1.5)
     const size_t tok = mpad * 6 * kDim * 2, obj = prow * 4 * kDim * 2;
     w.dsplit = (__bf16*)take(tok > obj ? tok : obj);
+    w.dsplit_b = (__bf16*)((char*)w.dsplit + mpad * 2 * kDim * 2);
   }
   w.mp2 = (M + 32 * 64 + 31) / 32 * 32;   // room for any split count up to 64
   w.zero = (__bf16*)take(1024);           // what the weight-gradient GEMM reads for reduction rows past the last one
@@ -1043,9 +1063,16 @@ TrainWs carve_train(char* base, veto_handle_t h, int n_obj, int n_pair) {
 // transposing LDS loads, of the weight-gradient GEMM (GemmArgs::tn; the saved activation x_split is its other operand as it
 // is) -- and the bias partials.  No transposed copies of dY or x exist.
 // dy == nullptr: the producer (attention backward) has already written the split rows into w.dsplit; no bias then.
+// presplit / presplit_partials: the producer wrote the split rows itself (to `presplit`; nullptr = w.dsplit) together with
+// `presplit_partials` rows of column sums in w.colp (0 = none: no bias gradient then).
+// gelu_pre (fc2 only): the input gradient is not written as fp32 rows: the GEMM's epilogue multiplies it by gelu'(gelu_pre) and writes the
+// split rows of fc1's backward to w.dsplit_b and their column-sum partials to w.colp (*next_partials rows): the pass that read dH and the
+// pre-activation back (0.9 ms per layer) is gone.
 int run_linear_backward(veto_handle_t h, hipStream_t s, const TrainWs& w, const float* dy, int M, int N, const __bf16* x_split, int K,
-                        const float* weight, float* dw, float* db, float* dx, const GradXform& xf = GradXform()) {
-  if (!dy && db) return fail(VETO_ERR_INVALID, "a pre-split gradient cannot feed a bias gradient");
+                        const float* weight, float* dw, float* db, float* dx, const GradXform& xf = GradXform(),
+                        const __bf16* presplit = nullptr, int presplit_partials = 0, const float* gelu_pre = nullptr, int* next_partials = nullptr) {
+  if (!dy && db && presplit_partials <= 0) return fail(VETO_ERR_INVALID, "a pre-split gradient without column partials cannot feed a bias gradient");
+  const __bf16* gsplit = !dy && presplit ? presplit : w.dsplit;
   const int out_tiles = ((N + 255) / 256) * (K / 192);
   int ks = 2 * 256 / out_tiles;
   const int max_ks = (M + 32 * 64 - 1) / (32 * 64);
@@ -1055,11 +1082,11 @@ int run_linear_backward(veto_handle_t h, hipStream_t s, const TrainWs& w, const 
   const size_t mp = ((size_t)M + 32 * (size_t)ks - 1) / (32 * (size_t)ks) * 32 * (size_t)ks;
   if (mp > w.mp2) return fail(VETO_ERR_WORKSPACE, "weight-gradient partial buffer too small");
   if (dy) HIP_TRY(launch_prep_grad(dy, N, M, N, w.dsplit, (int)mp, db ? w.colp : nullptr, xf, s));
-  if (db) HIP_TRY(launch_column_sums(w.colp, N, (int)(mp / 32), N, db, w.col_partial, column_sums_chunks(), s));
+  if (db) HIP_TRY(launch_column_sums(w.colp, N, dy ? (int)(mp / 32) : presplit_partials, N, db, w.col_partial, column_sums_chunks(), s));
   HIP_TRY(hipMemsetAsync(dw, 0, (size_t)N * K * 4, s));
   {
     GemmArgs g{};
-    g.a = w.dsplit; g.w = x_split; g.c = dw;
+    g.a = gsplit; g.w = x_split; g.c = dw;
     g.M = N; g.N = K; g.K = (int)mp; g.ldc = K; g.k_splits = ks;
     g.tn = 1; g.lda = 2 * (long)N; g.ldw = 2 * (long)K; g.k_valid = M; g.zero = w.zero;
     ProfScope ps(h, s, "bwd_wgrad", 2.0 * M * (double)N * K, 0);
@@ -1068,10 +1095,17 @@ int run_linear_backward(veto_handle_t h, hipStream_t s, const TrainWs& w, const 
   HIP_TRY(launch_transpose_split(weight, K, N, K, w.wdg, N, s));     // W [N, K] -> W^T split rows [K, 2N]
   {
     GemmArgs g{};
-    g.a = w.dsplit; g.w = w.wdg; g.c = dx;
+    g.a = gsplit; g.w = w.wdg; g.c = dx;
     g.M = M; g.N = K; g.K = N; g.ldc = K;
     ProfScope ps(h, s, "bwd_dgrad", 2.0 * M * (double)N * K, 0);
-    HIP_TRY(launch_gemm_split(g, EPI_F32, 0, s));
+    if (gelu_pre) {
+      if (gsplit == w.dsplit_b || !next_partials) return fail(VETO_ERR_INVALID, "internal: the fused gelu' epilogue writes w.dsplit_b");
+      g.c = nullptr; g.c_split = w.dsplit_b; g.ldc = 2L * K; g.resid = gelu_pre; g.ldr = K; g.col_partial = w.colp;
+      *next_partials = (M + 255) / 256 * 4;      // one partial row per 64-row slice of every 256-row tile
+      HIP_TRY(launch_gemm_split(g, EPI_GELU_BWD, 0, s));
+    } else {
+      HIP_TRY(launch_gemm_split(g, EPI_F32, 0, s));
+    }
   }
   return VETO_OK;
 }
@@ -1260,14 +1294,29 @@ int veto_backward(veto_handle_t h, void* stream, const veto_inputs_t* in, const 
                                n_pair, n_out, (long)kDim, s));
 
   // ---- transformer layers, last to first -------------------------------------------------------------------------
+  int dx_presplit = 0;      // > 0: ws.dsplit / ws.colp already hold the split rows / that many rows of column partials of ws.dx
   for (int l = L - 1; l >= 0; --l) {
     const LayerW& w = h->layers[l];
     TrainLayer& t = ws.layers[l];
     const bool last = l == L - 1;
     const int R = last ? n_pair : M;     // rows behind the attention: the CLS rows only in the last layer (compact buffers)
     // x_out = x_mid + gelu(LN2(x_mid) W1^T + b1) W2^T + b2
-    rc = run_linear_backward(h, s, ws, ws.dx, R, kDim, t.hid, 2 * kDim, h->p(lname(l, "1.fn.net.3.weight")),
-                             G(lname(l, "1.fn.net.3.weight")), G(lname(l, "1.fn.net.3.bias")), ws.dbig);
+    // dpre = dh * gelu'(pre): in the epilogue of fc2's input-gradient GEMM (round 6; VETO_TRAIN_GELU_EPI=0: a pass of its own inside the
+    // operand preparation of the fc1 backward, rounds 1-5)
+    // (the gradient of this layer's output: compact CLS rows from the head in the last layer, else the rows the LayerNorm1 backward of the
+    // layer above left -- with their split rows and bias partials when it emitted them)
+    const float* dy2 = dx_presplit ? nullptr : ws.dx;
+    if (train_gelu_epilogue()) {
+      int partials = 0;
+      rc = run_linear_backward(h, s, ws, dy2, R, kDim, t.hid, 2 * kDim, h->p(lname(l, "1.fn.net.3.weight")),
+                               G(lname(l, "1.fn.net.3.weight")), G(lname(l, "1.fn.net.3.bias")), nullptr, GradXform(), nullptr, dx_presplit, t.pre, &partials);
+      if (rc) return rc;
+      rc = run_linear_backward(h, s, ws, nullptr, R, 2 * kDim, t.a2, kDim, h->p(lname(l, "1.fn.net.0.weight")),
+                               G(lname(l, "1.fn.net.0.weight")), G(lname(l, "1.fn.net.0.bias")), ws.dtmp, GradXform(), ws.dsplit_b, partials);
+      if (rc) return rc;
+    } else {
+    rc = run_linear_backward(h, s, ws, dy2, R, kDim, t.hid, 2 * kDim, h->p(lname(l, "1.fn.net.3.weight")),
+                             G(lname(l, "1.fn.net.3.weight")), G(lname(l, "1.fn.net.3.bias")), ws.dbig, GradXform(), nullptr, dx_presplit);
     if (rc) return rc;
     GradXform gelu;              // dpre = dh * gelu'(pre), folded into the operand preparation of the fc1 backward
     gelu.mode = XF_GELU;
@@ -1275,22 +1324,27 @@ int veto_backward(veto_handle_t h, void* stream, const veto_inputs_t* in, const 
     rc = run_linear_backward(h, s, ws, ws.dbig, R, 2 * kDim, t.a2, kDim, h->p(lname(l, "1.fn.net.0.weight")),
                              G(lname(l, "1.fn.net.0.weight")), G(lname(l, "1.fn.net.0.bias")), ws.dtmp, gelu);
     if (rc) return rc;
-    HIP_TRY(launch_layernorm_backward(t.xmid, ws.dtmp, w.ln2_w, ws.dx, ws.dmid, ws.dgb, ws.ln_partial, R, s));
+    }
+    // x_mid = x_in + dropout(attention(LN1(x_in) Wqkv^T) Wo^T + bo): the projection sees the masked gradient
+    const DropSite dsite = drop_site(opts, 3 + l);
+    const bool ln_split = train_ln_emits_split();
+    if (ln_split)
+      HIP_TRY(launch_layernorm_backward(t.xmid, ws.dtmp, w.ln2_w, ws.dx, ws.dmid, ws.dgb, ws.ln_partial, R, s, ws.dsplit, ws.colp,
+                                        dsite.seed, dsite.thresh, dsite.scale));
+    else
+      HIP_TRY(launch_layernorm_backward(t.xmid, ws.dtmp, w.ln2_w, ws.dx, ws.dmid, ws.dgb, ws.ln_partial, R, s));
     HIP_TRY(hipMemcpyAsync(G(lname(l, "1.norm.weight")), ws.dgb, kDim * 4, hipMemcpyDeviceToDevice, s));
     HIP_TRY(hipMemcpyAsync(G(lname(l, "1.norm.bias")), ws.dgb + kDim, kDim * 4, hipMemcpyDeviceToDevice, s));
-    // x_mid = x_in + dropout(attention(LN1(x_in) Wqkv^T) Wo^T + bo): the projection sees the masked gradient
     GradXform drop;
-    {
-      const DropSite d = drop_site(opts, 3 + l);
-      if (d.thresh) {
-        drop.mode = XF_DROP;
-        drop.seed = d.seed;
-        drop.thresh = d.thresh;
-        drop.scale = d.scale;
-      }
+    if (dsite.thresh) {
+      drop.mode = XF_DROP;
+      drop.seed = dsite.seed;
+      drop.thresh = dsite.thresh;
+      drop.scale = dsite.scale;
     }
-    rc = run_linear_backward(h, s, ws, ws.dmid, R, kDim, t.ao, kDim, h->p(lname(l, "0.fn.to_out.0.weight")),
-                             G(lname(l, "0.fn.to_out.0.weight")), G(lname(l, "0.fn.to_out.0.bias")), ws.dtmp, drop);
+    rc = run_linear_backward(h, s, ws, ln_split ? nullptr : ws.dmid, R, kDim, t.ao, kDim, h->p(lname(l, "0.fn.to_out.0.weight")),
+                             G(lname(l, "0.fn.to_out.0.weight")), G(lname(l, "0.fn.to_out.0.bias")), ws.dtmp, drop, nullptr,
+                             ln_split ? layernorm_backward_col_partials(R) : 0);
     if (rc) return rc;
     HIP_TRY(launch_attention_backward(t.qkv, ws.dtmp, nullptr, ws.dsplit, n_pair, H, last ? 1 : 0, s, train_qkv_f24(h)));
     const float* dres = ws.dmid;
@@ -1305,7 +1359,13 @@ int veto_backward(veto_handle_t h, void* stream, const veto_inputs_t* in, const 
                              G(lname(l, "0.fn.to_qkv.weight")), nullptr, ws.dtmp);
     if (rc) return rc;
     // (in the last layer dres == ws.dx is also the output: every element is read and written by the same thread)
-    HIP_TRY(launch_layernorm_backward(t.xin, ws.dtmp, w.ln1_w, dres, ws.dx, ws.dgb, ws.ln_partial, M, s));
+    if (ln_split && l > 0) {      // (its result is the gradient matrix of fc2 of the layer below)
+      HIP_TRY(launch_layernorm_backward(t.xin, ws.dtmp, w.ln1_w, dres, ws.dx, ws.dgb, ws.ln_partial, M, s, ws.dsplit, ws.colp));
+      dx_presplit = layernorm_backward_col_partials(M);
+    } else {
+      HIP_TRY(launch_layernorm_backward(t.xin, ws.dtmp, w.ln1_w, dres, ws.dx, ws.dgb, ws.ln_partial, M, s));
+      dx_presplit = 0;
+    }
     HIP_TRY(hipMemcpyAsync(G(lname(l, "0.norm.weight")), ws.dgb, kDim * 4, hipMemcpyDeviceToDevice, s));
     HIP_TRY(hipMemcpyAsync(G(lname(l, "0.norm.bias")), ws.dgb + kDim, kDim * 4, hipMemcpyDeviceToDevice, s));
   }
