@@ -48,7 +48,8 @@
 // of their bytes: the DMA volume of 3-byte operand rows (fp16 + ONE e4m3 plane) without their conversion work,
 // 256 = no residual-row loads (the accumulators start at zero: what the read burst at the top of a panel costs),
 // 128 = the activation half of 32 alone (the LayerNorm2 rows of fc1 as fp16 + one e4m3 plane: upper bound of DESIGN.md section 11 item 1a),
-// 64 = every workgroup streams the SAME FeedForward input panel (L2-resident) instead of its own: what the re-reads of the LayerNorm2 rows cost
+// 64 = every workgroup streams the SAME FeedForward input panel (L2-resident) instead of its own: what the re-reads of the LayerNorm2 rows cost,
+// 512 = no workgroup barriers
 #ifndef FFN_ABLATE
 #define FFN_ABLATE 0
 #endif
@@ -140,7 +141,7 @@ __device__ __forceinline__ void glds16_nt(const char* base, unsigned voff, unsig
 }
 __device__ __forceinline__ void wg_barrier() {
   asm volatile("" ::: "memory");
-  __builtin_amdgcn_s_barrier();
+  if (!(FFN_ABLATE & 512)) __builtin_amdgcn_s_barrier();      // (ablation 512: no stage barriers -- what the lockstep of the eight waves costs)
   asm volatile("" ::: "memory");
 }
 
