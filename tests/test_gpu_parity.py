@@ -620,6 +620,9 @@ def test_saturation_audit_counts_what_the_mixed_format_clamps():
     model = testing.make_predictor(cfg, _trained_like_state_dict(layers, hidden_factor=60000.0), dev)
     _run(model, batch, "predcls", dev)
     assert sum(r["hidden"]["f16_saturated"] for r in model.last_saturation) > 0, model.last_saturation
+    # ... and the audit sees it in the LAST layer too, whose FeedForward runs on the pairs' CLS rows as mixed operands (round 6: those rows
+    # are the classifier's input, and rounds 2-5 reported zeros for them)
+    assert model.last_saturation[layers - 1]["hidden"]["f16_saturated"] > 0, model.last_saturation[layers - 1]
 
 
 @pytest.mark.parametrize("name", ["predcls_n10_l4h8", "predcls_n36_l4h8", "predcls_b12_n36_l6h6"])
