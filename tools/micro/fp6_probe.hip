@@ -87,7 +87,7 @@ __global__ void cvt_kernel(const float* x, float scale, unsigned* out32, unsigne
 }
 
 __global__ void dma_kernel(const unsigned* src, unsigned* out) {
-  __shared__ unsigned sm[512];
+  __shared__ unsigned sm[512];      // (64 lanes x 16 bytes = 256 dwords are enough for either hypothesis)
   const int l = threadIdx.x;
   for (int i = l; i < 512; i += 64) sm[i] = 0xdeadbeefu;
   __syncthreads();
@@ -197,11 +197,16 @@ int main() {
     dma_kernel<<<1, 64>>>(ds, dd);
     std::vector<unsigned> o(512);
     CK(hipMemcpy(o.data(), dd, 2048, hipMemcpyDeviceToHost));
-    int bad = 0;
-    for (int l = 0; l < 64; ++l)
-      for (int j = 0; j < 3; ++j) if (o[3 * l + j] != (unsigned)(4 * l + j)) ++bad;
-    printf("part3 global_load_lds_dwordx3: lane l's 12 bytes at LDS m0 + 12 l: %d / 192 dwords differ; dword 192 = %08x (untouched: deadbeef); first dwords: %x %x %x %x %x %x %x\n",
-           bad, o[192], o[0], o[1], o[2], o[3], o[4], o[5], o[6]);
+    int bad12 = 0, bad16 = 0, holes = 0;
+    for (int l = 0; l < 64; ++l) {
+      for (int j = 0; j < 3; ++j) {
+        if (o[3 * l + j] != (unsigned)(4 * l + j)) ++bad12;      // hypothesis A: lane l's 12 bytes at m0 + 12 l
+        if (o[4 * l + j] != (unsigned)(4 * l + j)) ++bad16;      // hypothesis B: at m0 + 16 l (a 4-byte hole behind every lane's piece)
+      }
+      holes += o[4 * l + 3] == 0xdeadbeefu;
+    }
+    printf("part3 global_load_lds_dwordx3, lane l's 12 bytes: at LDS m0 + 12 l: %d / 192 dwords differ; at m0 + 16 l: %d / 192 differ, %d / 64 of the dwords behind the pieces untouched\n",
+           bad12, bad16, holes);
   }
   return 0;
 }
