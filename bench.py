@@ -400,7 +400,7 @@ def extra_lines(args, dev, batch, sd):
                                    "traffic": tj6["kernels"].get(dom6, {}).get("hbm_bytes_per_launch") if tj6 else None,
                                    "traffic_source": "profiles/%s_pmc_*.txt" % tj6["tag"] if tj6 else None}
         out["l6h6"]["kernels_ms_per_step"] = {k: round(v["total_ms"] / 3, 4) for k, v in sorted(prof6.items(), key=lambda kv: -kv[1]["total_ms"])[:8]}
-    del m6
+    del m6, eng6, prof6      # (the engine holds the handle and its workspace)
     ref, _, _ = vo.forward(sd, vo.OracleConfig(layers=args.layers, heads=args.heads), img0)
     for prec in sorted(DTYPE_OF):
         if prec == args.precision:
@@ -410,6 +410,8 @@ def extra_lines(args, dev, batch, sd):
         out["precision_" + prec] = {"dtype": DTYPE_OF[prec], "pairs_per_s": n_pairs / dt, "ms_per_step": dt * 1e3,
                                     "logit_max_abs_err_image0": float((lg[:ppi] - ref).abs().max())}
         del m
+    import gc
+    gc.collect()
     out["train"] = train_line(args, dev, batch, sd)
     return out
 
