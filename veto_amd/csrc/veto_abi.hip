@@ -1008,18 +1008,22 @@ TrainWs carve_train(char* base, veto_handle_t h, int n_obj, int n_pair) {
   w.pa = (__bf16*)take(prow * 2 * 2048 * 2);
   w.patch_tab = (float*)take((size_t)n_obj * 16 * 2 * kDim * 4);
   w.layers.resize(L);
+  const size_t cpad = (size_t)gemm_rows_padded(n_pair);
   for (int l = 0; l < L; ++l) {
     TrainLayer& t = w.layers[l];
+    // (the last layer runs on the pairs' CLS rows behind its attention: those buffers are compact, one row per pair -- sized for every token
+    // row until round 6, 4.4 GB too many at cfg-2)
+    const size_t rows = l == L - 1 ? cpad : mpad;
     t.xin = (float*)take(mpad * kDim * 4);
     t.a1 = (__bf16*)take(mpad * 2 * kDim * 2);
     t.qkv = (float*)take(mpad * 3 * kDim * (train_qkv_f24(h) ? 3 : 4));
-    t.ao = (__bf16*)take(mpad * 2 * kDim * 2);
-    t.xmid = (float*)take(mpad * kDim * 4);
-    t.a2 = (__bf16*)take(mpad * 2 * kDim * 2);
-    t.pre = (float*)take(mpad * 2 * kDim * 4);
-    t.hid = (__bf16*)take(mpad * 4 * kDim * 2);
+    t.ao = (__bf16*)take(rows * 2 * kDim * 2);
+    t.xmid = (float*)take(rows * kDim * 4);
+    t.a2 = (__bf16*)take(rows * 2 * kDim * 2);
+    t.pre = (float*)take(rows * 2 * kDim * 4);
+    t.hid = (__bf16*)take(rows * 4 * kDim * 2);
   }
-  w.xout = (float*)take(mpad * kDim * 4);
+  w.xout = (float*)take(cpad * kDim * 4);      // (compact: the last layer's CLS rows)
   w.dx = (float*)take(mpad * kDim * 4);
   w.dmid = (float*)take(mpad * kDim * 4);
   w.dtmp = (float*)take(mpad * kDim * 4);
