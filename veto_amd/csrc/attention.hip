@@ -237,7 +237,14 @@ __global__ __launch_bounds__(64 * ATT_WPB, TAB && (!TAB_SPLIT_LOADS || DH > 72) 
   constexpr int ROUNDS4 = (3 * PER_MAT4 + 63) / 64;
   f32x4 ld[TAB ? 1 : ROUNDS][2];      // (not TAB) a lane's 32-byte chunk of round r
   f32x4 lt[TAB ? ROUNDS4 : 1], lo_[TAB ? ROUNDS4 : 1];      // TAB: subject-side piece (or the plain row's), object-side piece
-  const int pair = (int)(item / a.heads), head = (int)(item % a.heads);
+  // item -> (pair, head), head fastest: neighbouring waves read adjacent 288-byte slices of the SAME table rows.  ATT_PAIR_FASTEST=1 (TAB only;
+  // measured SLOWER in round 6: 0.50 against 0.44 ms per launch): consecutive items = consecutive pairs of one head, i.e. the same subject-side
+  // rows for a run of pairs but a head's slice alone of every row
+#ifndef ATT_PAIR_FASTEST
+#define ATT_PAIR_FASTEST 0
+#endif
+  const int pair = TAB && ATT_PAIR_FASTEST ? (int)(item % a.n_pair) : (int)(item / a.heads);
+  const int head = TAB && ATT_PAIR_FASTEST ? (int)(item / a.n_pair) : (int)(item % a.heads);
   const float* src0 = a.qkv + (size_t)pair * kTokens * (3 * kDim) + head * DH;
   const float* tab_s = nullptr;
   const float* tab_o = nullptr;
