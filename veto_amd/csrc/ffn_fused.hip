@@ -89,6 +89,15 @@
 #ifndef FFN_LN16
 #define FFN_LN16 1
 #endif
+// 1 (layer tail on fp32 residual rows; round 6, measured NULL, not the default): the accumulators start at ZERO and the panel's residual rows are
+// added during the out projection, a column third at a time: twelve 16-byte loads per lane into the registers the FeedForward's fc1 accumulators
+// will use (idle until then), issued at the top of an interval in front of its LDS-DMA instructions -- so the next interval's own vmcnt wait
+// covers them -- and added at the top of a later interval of their column third (that third's MFMAs are three intervals old: no hazard).  The
+// 36-load burst at the top of a panel becomes three trickles.  2.215 / 2.187 / 2.192 ms with the burst, 2.202 / 2.178 / 2.191 with the trickles
+// (same box, parity-green, audit clean, 256 registers): the bytes have to come either way.  0: the accumulators start as the residual rows.
+#ifndef FFN_MIDRES
+#define FFN_MIDRES 0
+#endif
 // TIMING PROBE (results are WRONG): the correction stages of the FeedForward (fc1, fc2; not the out projection) as block-scaled fp6
 // (e2m3) operands -- the K = 128 MFMA in its fp6 form (6 registers per operand, half the cycles of the e4m3 form), 96 instead of 128 bytes
 // of every row per correction stage through the LDS-DMA (12 + 18 instead of 16 + 24 pieces of an fc1 stage, 18 instead of 24 of an fc2
@@ -138,6 +147,11 @@ __device__ __forceinline__ void glds16(const char* base, unsigned voff, unsigned
 __device__ __forceinline__ void glds16_nt(const char* base, unsigned voff, unsigned lds_addr) {
   if (FFN_ABLATE & 1) return;
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %1, %2 nt" ::"s"(lds_addr), "v"(voff), "s"(base) : "memory");
+}
+// a 16-byte global load the compiler does not count (see glds16): the caller's own s_waitcnt vmcnt covers it before the value is used
+template <int OFF>
+__device__ __forceinline__ void gload16(f32x4& dst, const float* p) {
+  asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(dst) : "v"(p), "n"(OFF) : "memory");
 }
 __device__ __forceinline__ void wg_barrier() {
   asm volatile("" ::: "memory");
@@ -193,6 +207,7 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs g) {
   constexpr int kS2 = FC / 64 * NK * 3;      // fc2 sub-stages per chunk: 18 / 9
   constexpr int kPer = kS1 + kS2;            // a multiple of the ring length either way
   constexpr int kOutPos = kDim / 64 * NK * 3;   // positions of the out projection: 54 / 27
+  constexpr bool kMidRes = FFN_MIDRES && MODE == 2 && !RF24 && !FAST && !(FFN_ABLATE & 256);   // residual rows added during the out projection
   static_assert(kPer % kRing == 0 && kOutPos % kRing == 0, "a position's ring slot is a compile-time constant");
   saturating_conversions_on();   // (the hidden and LayerNorm conversions to mixed rows carry no clamps, common.h)
   __shared__ __attribute__((aligned(16))) char smem[kLds];
@@ -715,8 +730,11 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs g) {
           for (int m = 0; m < 2; ++m) {
             int row = panel * FR + wm * 32 + m * 16 + r;
             if (row >= g.M) row = g.M - 1;          // clamp: rows past the end are never stored
-            if (FFN_ABLATE & 256) acc2[t][i][m] = f32x4{0.f, 0.f, 0.f, 0.f};
-            else if constexpr (RF24) {
+            if ((FFN_ABLATE & 256) || kMidRes) {
+              acc2[t][i][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+              // (opaque zeros: knowing them, the compiler would peel the first stages into MFMAs with a constant C operand in fresh registers)
+              if (kMidRes) asm volatile("" : "+v"(acc2[t][i][m]));
+            } else if constexpr (RF24) {
               const u32x3 d = *(const u32x3*)((const char*)g.resid + ((size_t)row * kDim + wn * 32 + q * 4 + t * FC + (i >> 1) * 64 + (i & 1) * 16) * 3);
               acc2[t][i][m] = unpack_f24x4(d[0], d[1], d[2]);
             }
@@ -727,7 +745,7 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs g) {
 #endif
           }
       if (it == 0) {
-        if (FFN_ABLATE & 256) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if ((FFN_ABLATE & 256) || kMidRes) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(36)" ::: "memory");   // the prologue's stages 0 and 1 have landed (they are older than the 36 loads)
         skip = 2;
       }
@@ -740,6 +758,12 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs g) {
       const bool stream_ends = MODE == 2 || it == my_panels - 1;
       const char* a_next = panel_base(it + 1);          // (not dereferenced when the stream ends)
       i32x4 fa0[2], fa1[2];
+      // kMidRes: the residual rows of column third t are requested at the top of position kResLoad(t) and added at the top of position
+      // kResAdd(t) (a position of that third; the requests of the next third follow the add: one set of 48 registers)
+      f32x4 rres[6][2];
+      (void)rres;
+      auto res_load_pos = [](int t) { return t == 0 ? 0 : t == 1 ? 7 : 17; };
+      auto res_add_pos = [](int t) { return t == 0 ? 6 : t == 1 ? 16 : 26; };
       static_for<0, kOutPos>([&](auto p_tag) {
         constexpr int P = decltype(p_tag)::value, KS = P / 3, T = P % 3;
         STAMP(t0);
@@ -753,6 +777,40 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs g) {
         wg_barrier();
         STAMP(t2);
         ACC(s_wait, t1, t0); ACC(s_bar, t2, t1);
+        if constexpr (kMidRes) {
+          static_for<0, 3>([&](auto t_tag) {
+            constexpr int TT = decltype(t_tag)::value;
+            if constexpr (P == res_add_pos(TT)) {
+              static_assert(res_add_pos(TT) % 3 == TT && res_add_pos(TT) >= res_load_pos(TT) + 2, "an interval of the third, two waits behind the requests");
+              // (the requests are two of this wave's vmcnt waits old -- each covers everything older than the next stage's DMA instructions --;
+              // the launder ties the values to THIS point: the compiler must not move the adds in front of the waits, which it cannot see)
+#pragma unroll
+              for (int i = 0; i < 6; ++i)
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                  asm volatile("" : "+v"(rres[i][m]));
+                  acc2[TT][i][m] += rres[i][m];
+                }
+            }
+          });
+          static_for<0, 3>([&](auto t_tag) {
+            constexpr int TT = decltype(t_tag)::value;
+            if constexpr (P == res_load_pos(TT)) {
+              static_assert(TT == 0 || res_load_pos(TT) > res_add_pos(TT - 1), "the registers are free again");
+              const int lane_r = lane_now();
+              const int rr_ = lane_r & 15, qq_ = lane_r >> 4;
+#pragma unroll
+              for (int m = 0; m < 2; ++m) {
+                int row = panel * FR + wm * 32 + m * 16 + rr_;
+                if (row >= g.M) row = g.M - 1;          // clamp: rows past the end are never stored
+                const float* rp = g.resid + (size_t)row * g.ldr + wn * 32 + qq_ * 4 + TT * FC;
+                // (inline asm: invisible to the compiler's wait counting, like the LDS-DMA; the kernel's own waits cover them)
+                gload16<0>(rres[0][m], rp); gload16<64>(rres[1][m], rp); gload16<256>(rres[2][m], rp);
+                gload16<320>(rres[3][m], rp); gload16<512>(rres[4][m], rp); gload16<576>(rres[5][m], rp);
+              }
+            }
+          });
+        }
         auto dma = [&](int k) {
           constexpr int P2 = P + 2;
           if constexpr (P2 < kOutPos) issue_out(a_panel, P2 / 3 * SL, P2 % 3, P2 % 3, k);
