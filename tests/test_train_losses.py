@@ -423,12 +423,13 @@ def test_training_workspace_is_released_without_a_backward_and_weights_refresh()
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("env", [{"VETO_TRAIN_LN_SPLIT": "1"}, {"VETO_TRAIN_GELU_EPI": "0", "VETO_TRAIN_QKV_F24": "0"}],
-                         ids=["ln-backward-emits-split-rows", "round5-forms"])
+@pytest.mark.parametrize("env", [{"VETO_TRAIN_LN_SPLIT": "1"}, {"VETO_TRAIN_GELU_EPI": "0", "VETO_TRAIN_QKV_F24": "0"}, {"VETO_TRAIN_RECOMPUTE": "1"}],
+                         ids=["ln-backward-emits-split-rows", "round5-forms", "recompute-instead-of-keeping"])
 def test_training_variants_behind_the_knobs_match_reference_gradients(env):
     """The forms of the training path that a knob selects (read once per process, hence a child process): the LayerNorm backward that emits the
     split rows of the Linear behind it (round 6: measured slower, off by default), and round 5's forms of what round 6 changed (gelu' as a pass
-    of its own, fp32 q / k / v).  Same gradient and finite-difference tests as the default path."""
+    of its own, fp32 q / k / v), and the form that recomputes the LayerNorm / GELU rows in the backward instead of keeping them.  Same gradient and
+    finite-difference tests as the default path."""
     import subprocess
     import sys
     picked = "(test_training_backward_matches_reference_gradients or test_training_dropout_masks_are_seeded) and (train_vanilla- or train_meet_vg or seeded)"

@@ -974,6 +974,14 @@ bool train_qkv_f24(veto_handle_t h) {
   return !off && (h->dh == 72 || h->dh == 96);
 }
 
+// VETO_TRAIN_RECOMPUTE=1 (off by default): the LayerNorm1 / LayerNorm2 rows and the GELU rows of a layer are not kept for the backward but
+// recomputed there from the residual rows and the pre-activation that ARE kept (the same kernels on the same inputs: bit-identical operands,
+// bit-identical gradients): 8.6 GB less workspace at cfg-2 for three more passes per layer (~3 ms per step).  With 288 GB of HBM the default keeps them.
+bool train_recompute() {
+  static const bool on = env_knob_is("VETO_TRAIN_RECOMPUTE", "1");
+  return on;
+}
+
 // dpre = dh * gelu'(pre) in the epilogue of fc2's input-gradient GEMM (round 6); VETO_TRAIN_GELU_EPI=0: inside the operand preparation of
 // the fc1 backward, a pass of its own over an fp32 copy of dh (rounds 1-5)
 bool train_gelu_epilogue() {
@@ -1009,19 +1017,22 @@ TrainWs carve_train(char* base, veto_handle_t h, int n_obj, int n_pair) {
   w.patch_tab = (float*)take((size_t)n_obj * 16 * 2 * kDim * 4);
   w.layers.resize(L);
   const size_t cpad = (size_t)gemm_rows_padded(n_pair);
+  const bool recompute = train_recompute();
+  __bf16* a_scr = recompute ? (__bf16*)take(mpad * 2 * kDim * 2) : nullptr;      // LayerNorm rows of whichever Linear is next (forward) / being differentiated (backward)
+  __bf16* hid_scr = recompute ? (__bf16*)take(mpad * 4 * kDim * 2) : nullptr;    // the same for the GELU rows
   for (int l = 0; l < L; ++l) {
     TrainLayer& t = w.layers[l];
     // (the last layer runs on the pairs' CLS rows behind its attention: those buffers are compact, one row per pair -- sized for every token
     // row until round 6, 4.4 GB too many at cfg-2)
     const size_t rows = l == L - 1 ? cpad : mpad;
     t.xin = (float*)take(mpad * kDim * 4);
-    t.a1 = (__bf16*)take(mpad * 2 * kDim * 2);
+    t.a1 = recompute ? a_scr : (__bf16*)take(mpad * 2 * kDim * 2);
     t.qkv = (float*)take(mpad * 3 * kDim * (train_qkv_f24(h) ? 3 : 4));
     t.ao = (__bf16*)take(rows * 2 * kDim * 2);
     t.xmid = (float*)take(rows * kDim * 4);
-    t.a2 = (__bf16*)take(rows * 2 * kDim * 2);
+    t.a2 = recompute ? a_scr : (__bf16*)take(rows * 2 * kDim * 2);
     t.pre = (float*)take(rows * 2 * kDim * 4);
-    t.hid = (__bf16*)take(rows * 4 * kDim * 2);
+    t.hid = recompute ? hid_scr : (__bf16*)take(rows * 4 * kDim * 2);
   }
   w.xout = (float*)take(cpad * kDim * 4);      // (compact: the last layer's CLS rows)
   w.dx = (float*)take(mpad * kDim * 4);
@@ -1310,11 +1321,14 @@ int veto_backward(veto_handle_t h, void* stream, const veto_inputs_t* in, const 
     // (the gradient of this layer's output: compact CLS rows from the head in the last layer, else the rows the LayerNorm1 backward of the
     // layer above left -- with their split rows and bias partials when it emitted them)
     const float* dy2 = dx_presplit ? nullptr : ws.dx;
+    const bool recompute = train_recompute();
+    if (recompute) HIP_TRY(launch_gelu_split(t.pre, t.hid, (size_t)R, 2 * kDim, s));      // gelu(pre): fc2's operand, as the forward's epilogue wrote it
     if (train_gelu_epilogue()) {
       int partials = 0;
       rc = run_linear_backward(h, s, ws, dy2, R, kDim, t.hid, 2 * kDim, h->p(lname(l, "1.fn.net.3.weight")),
                                G(lname(l, "1.fn.net.3.weight")), G(lname(l, "1.fn.net.3.bias")), nullptr, GradXform(), nullptr, dx_presplit, t.pre, &partials);
       if (rc) return rc;
+      if (recompute) HIP_TRY(launch_layernorm(t.xmid, kDim, w.ln2_w, w.ln2_b, t.a2, R, s));      // LayerNorm2 rows: fc1's operand
       rc = run_linear_backward(h, s, ws, nullptr, R, 2 * kDim, t.a2, kDim, h->p(lname(l, "1.fn.net.0.weight")),
                                G(lname(l, "1.fn.net.0.weight")), G(lname(l, "1.fn.net.0.bias")), ws.dtmp, GradXform(), ws.dsplit_b, partials);
       if (rc) return rc;
@@ -1325,6 +1339,7 @@ int veto_backward(veto_handle_t h, void* stream, const veto_inputs_t* in, const 
     GradXform gelu;              // dpre = dh * gelu'(pre), folded into the operand preparation of the fc1 backward
     gelu.mode = XF_GELU;
     gelu.pre = t.pre;
+    if (recompute) HIP_TRY(launch_layernorm(t.xmid, kDim, w.ln2_w, w.ln2_b, t.a2, R, s));
     rc = run_linear_backward(h, s, ws, ws.dbig, R, 2 * kDim, t.a2, kDim, h->p(lname(l, "1.fn.net.0.weight")),
                              G(lname(l, "1.fn.net.0.weight")), G(lname(l, "1.fn.net.0.bias")), ws.dtmp, gelu);
     if (rc) return rc;
@@ -1359,6 +1374,7 @@ int veto_backward(veto_handle_t h, void* stream, const veto_inputs_t* in, const 
                                hipMemcpyDeviceToDevice, s));
       dres = ws.dx;
     }
+    if (recompute) HIP_TRY(launch_layernorm(t.xin, kDim, w.ln1_w, w.ln1_b, t.a1, M, s));      // LayerNorm1 rows: the QKV projection's operand
     rc = run_linear_backward(h, s, ws, nullptr, M, 3 * kDim, t.a1, kDim, h->p(lname(l, "0.fn.to_qkv.weight")),
                              G(lname(l, "0.fn.to_qkv.weight")), nullptr, ws.dtmp);
     if (rc) return rc;
