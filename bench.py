@@ -413,7 +413,25 @@ def extra_lines(args, dev, batch, sd):
     import gc
     gc.collect()
     out["train"] = train_line(args, dev, batch, sd)
+    out["train_recompute"] = train_recompute_line()
     return out
+
+
+def train_recompute_line():
+    """The same training step with VETO_TRAIN_RECOMPUTE=1 (LayerNorm / GELU rows recomputed in the backward instead of kept; the knob is read
+    once per process, hence a child process running tools/train_bench.py).  None when the child fails: context, not the headline."""
+    import re
+    import subprocess
+    try:
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "train_bench.py"), "3"], env=dict(os.environ, VETO_TRAIN_RECOMPUTE="1"),
+                           capture_output=True, text=True, timeout=300)
+        m = re.search(r"training step: ([0-9.]+) ms \(forward\+loss ([0-9.]+) ms, backward ([0-9.]+) ms.*peak memory ([0-9.]+) GB", p.stdout)
+        if not m:
+            return None
+        return {"workload": "the training step above with VETO_TRAIN_RECOMPUTE=1, in a child process (its peak memory is the child's own)",
+                "ms_per_step": float(m.group(1)), "forward_ms": float(m.group(2)), "backward_ms": float(m.group(3)), "peak_memory_gb": float(m.group(4))}
+    except (OSError, subprocess.SubprocessError, ValueError):
+        return None
 
 
 def train_line(args, dev, batch, sd, steps=3):
